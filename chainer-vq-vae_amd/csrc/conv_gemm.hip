@@ -1,0 +1,895 @@
+// conv_gemm.hip -- the MFMA contraction kernels of the hot path (gfx950, fp32).
+//
+// Every convolution on the path is a (K,1) filter over the time axis of a
+// (B, C, T) tensor with T contiguous, i.e. for one batch element
+//     Y[co, t] = sum_{tap, ci} W[co, ci, tap] * X[ci, t*stride + tap*dil - pad]
+// which is a GEMM  Y[M=co, N=t] = A[M, K=(tap,ci)] * B[K, N]  whose B operand is
+// a time-shifted window of X.  Time is the contiguous axis, so the MFMA B
+// fragment (lane -> 32 consecutive t) is read straight out of coalesced rows.
+//
+//   conv_gemm_kernel<EPI>   fwd and bwd-data of every conv (the K dimension is a
+//                           list of up to 4 "segments" = (input tensor, tap shift,
+//                           packed weight slab)); 128x128 output tile per 256-thread
+//                           workgroup, 4 wavefronts as 2x2, each 2x2 tiles of
+//                           v_mfma_f32_32x32x2_f32; LDS double buffer, register
+//                           prefetch, one barrier per K step; XCD-aware tile order.
+//                           Epilogues: linear (+bias, +residual, +=, relu),
+//                           gated tanh*sigmoid (ResidualBlock fwd), gate derivative
+//                           (ResidualBlock bwd).
+//   wgrad_kernel            bwd-weight: contraction over (b, t), split-K over
+//                           batch x time chunks into deterministic partial slabs,
+//                           reduced in fixed order by wgrad_reduce_kernel.
+//   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A^T
+//                           slabs the GEMM wants ([k][m], m contiguous, zero padded).
+#include "common.h"
+
+namespace vq {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
+constexpr int MAXSEG = 4;
+
+struct Seg {
+  const float* x;      // activations, channel 0 of this segment
+  long x_bstride;      // elements between batch items
+  int x_cstride;       // elements between channels (= time length of x)
+  int cin;             // contraction length of this segment
+  int Tin;             // valid input times [0, Tin)
+  int tmul, toff, tdiv;  // t_in = (t_out*tmul + toff) / tdiv  (must divide exactly)
+  int vec;             // host says: strides/pointer allow aligned float4 rows
+  const float* w;      // packed A^T slab [cin_pad16][ldw]
+  int ldw;
+};
+
+struct OutR {          // one row range of M
+  float* y; long y_bstride;
+  const float* add; long add_bstride;   // residual add / gates input
+  const float* bias; const float* bias2;
+  int rows; int accumulate; int relu;
+};
+
+enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_GATE_BWD = 2 };
+
+struct GemmArgs {
+  Seg seg[MAXSEG];
+  int nseg;
+  int M;         // logical rows (packed rows for EPI_GATE)
+  int Tout;
+  int B;
+  int ntile_m, ntile_n;
+  OutR out[2];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+  // same form as the oracle / Chainer: tanh(x/2)/2 + 1/2
+  return tanhf(x * 0.5f) * 0.5f + 0.5f;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT) void conv_gemm_kernel(const GemmArgs a) {
+  __shared__ float As[2][BK][BM];
+  __shared__ float Bs[2][BK][BN];
+
+  // ---- XCD-aware tile order: consecutive logical tiles (which share the same
+  // activation window across their M tiles) land on the same XCD / L2. -------
+  const int nblk = gridDim.x;
+  int logical;
+  {
+    const int id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = logical % a.ntile_m;
+  const int rest = logical / a.ntile_m;
+  const int nt = rest % a.ntile_n;
+  const int b = rest / a.ntile_n;
+  const int m0 = mt * BM, t0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int nk = 0;
+  for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
+
+  float4 ra0, ra1;
+  float4 rb0, rb1;
+  bool rvec = false;
+
+  // thread roles for the staging loads
+  const int a_k = tid >> 5, a_col = (tid & 31) * 4;   // A (and vector B): rows a_k, a_k+8
+  const int b_n = tid & 127, b_k = tid >> 7;          // scalar B: rows b_k + 2i
+
+  auto load_tiles = [&](int s, int c0) {
+    const Seg& sg = a.seg[s];
+    const float* wp = sg.w + (long)(c0 + a_k) * sg.ldw + m0 + a_col;
+    ra0 = *reinterpret_cast<const float4*>(wp);
+    ra1 = *reinterpret_cast<const float4*>(wp + 8L * sg.ldw);
+    const float* xb = sg.x + (long)b * sg.x_bstride;
+    const int tw = t0 * sg.tmul + sg.toff;   // window start (when tmul==1,tdiv==1)
+    rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
+    if (rvec) {
+      const int ci0 = c0 + a_k, ci1 = c0 + a_k + 8;
+      rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci0 < sg.cin) rb0 = *reinterpret_cast<const float4*>(xb + (long)ci0 * sg.x_cstride + tw + a_col);
+      if (ci1 < sg.cin) rb1 = *reinterpret_cast<const float4*>(xb + (long)ci1 * sg.x_cstride + tw + a_col);
+    } else {
+      const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
+      bool ok = tnum >= 0;
+      int tin = tnum;
+      if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+      ok = ok && tin < sg.Tin;
+      const float* xp = xb + (long)(c0 + b_k) * sg.x_cstride + tin;
+      const long cs2 = 2L * sg.x_cstride;
+      const int cb = c0 + b_k;
+      rb0.x = (ok && cb + 0 < sg.cin) ? xp[0 * cs2] : 0.f;
+      rb0.y = (ok && cb + 2 < sg.cin) ? xp[1 * cs2] : 0.f;
+      rb0.z = (ok && cb + 4 < sg.cin) ? xp[2 * cs2] : 0.f;
+      rb0.w = (ok && cb + 6 < sg.cin) ? xp[3 * cs2] : 0.f;
+      rb1.x = (ok && cb + 8 < sg.cin) ? xp[4 * cs2] : 0.f;
+      rb1.y = (ok && cb + 10 < sg.cin) ? xp[5 * cs2] : 0.f;
+      rb1.z = (ok && cb + 12 < sg.cin) ? xp[6 * cs2] : 0.f;
+      rb1.w = (ok && cb + 14 < sg.cin) ? xp[7 * cs2] : 0.f;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    *reinterpret_cast<float4*>(&As[buf][a_k][a_col]) = ra0;
+    *reinterpret_cast<float4*>(&As[buf][a_k + 8][a_col]) = ra1;
+    if (rvec) {
+      *reinterpret_cast<float4*>(&Bs[buf][a_k][a_col]) = rb0;
+      *reinterpret_cast<float4*>(&Bs[buf][a_k + 8][a_col]) = rb1;
+    } else {
+      Bs[buf][b_k + 0][b_n] = rb0.x;  Bs[buf][b_k + 2][b_n] = rb0.y;
+      Bs[buf][b_k + 4][b_n] = rb0.z;  Bs[buf][b_k + 6][b_n] = rb0.w;
+      Bs[buf][b_k + 8][b_n] = rb1.x;  Bs[buf][b_k + 10][b_n] = rb1.y;
+      Bs[buf][b_k + 12][b_n] = rb1.z; Bs[buf][b_k + 14][b_n] = rb1.w;
+    }
+  };
+
+  int s = 0, c0 = 0;
+  load_tiles(s, c0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    const bool more = (it + 1) < nk;
+    if (more) {
+      c0 += BK;
+      if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
+      load_tiles(s, c0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
+      const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
+      const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
+      const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----------------------------------------------------------
+  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int T = a.Tout;
+  if (EPI == EPI_LINEAR) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= a.M) continue;
+        const int o = (m < a.out[0].rows) ? 0 : 1;
+        const OutR& od = a.out[o];
+        const int mr = o ? m - a.out[0].rows : m;
+        const float bias = od.bias ? od.bias[mr] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          if (t >= T) continue;
+          float v = acc[mi][ni][r] + bias;
+          const long off = (long)mr * T + t;
+          if (od.add) v += od.add[(long)b * od.add_bstride + off];
+          float* yp = od.y + (long)b * od.y_bstride + off;
+          if (od.accumulate) v += *yp;
+          if (od.relu) v = fmaxf(v, 0.f);
+          *yp = v;
+        }
+      }
+  } else if (EPI == EPI_GATE) {
+    // packed rows: each 64-row wave tile = 32 tanh rows (mi=0) + the matching 32
+    // sigmoid rows (mi=1) of channel group g.
+    const int Ch = a.M >> 1;
+    const int g = (m0 + wm * 64) >> 6;
+    const OutR& og = a.out[0];   // gates (B, 2Ch, T)
+    const OutR& oz = a.out[1];   // z (B, Ch, T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (ch >= Ch) continue;
+      float ba = 0.f, bb = 0.f;
+      if (og.bias) { ba += og.bias[ch]; bb += og.bias[Ch + ch]; }
+      if (og.bias2) { ba += og.bias2[ch]; bb += og.bias2[Ch + ch]; }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int t = t0 + wn * 64 + ni * 32 + li;
+        if (t >= T) continue;
+        const float ta = tanhf(acc[0][ni][r] + ba);
+        const float sb = sigmoidf_(acc[1][ni][r] + bb);
+        float* gp = og.y + (long)b * og.y_bstride;
+        gp[(long)ch * T + t] = ta;
+        gp[(long)(Ch + ch) * T + t] = sb;
+        oz.y[(long)b * oz.y_bstride + (long)ch * T + t] = ta * sb;
+      }
+    }
+  } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
+    const int Ch = a.M;
+    const OutR& od = a.out[0];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= Ch) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          if (t >= T) continue;
+          const float* gp = od.add + (long)b * od.add_bstride;
+          const float ta = gp[(long)m * T + t];
+          const float sb = gp[(long)(Ch + m) * T + t];
+          const float gz = acc[mi][ni][r];
+          float* yp = od.y + (long)b * od.y_bstride;
+          yp[(long)m * T + t] = gz * sb * (1.f - ta * ta);
+          yp[(long)(Ch + m) * T + t] = gz * ta * sb * (1.f - sb);
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing: dst[(tap*Rpad + k)*ldw + m_off + mp] = src[k*s_k + m*s_m + tap*s_tap]
+// where m = unpermute(mp) (gate interleave) ; zero for k >= R or m >= Cm.
+// ---------------------------------------------------------------------------
+struct PackJob {
+  float* dst; const float* src;
+  int R, Cm, K;          // k extent, m extent, taps
+  long s_k, s_m, s_tap;  // source strides
+  int gate_half;         // 0, or Ch: interleave 32-row groups of [0,Ch) and [Ch,2Ch)
+  int Rpad, ldw, m_off;
+  int mspan;             // columns of dst this job owns (multiple of 4, zero filled)
+};
+struct PackArgs { PackJob job[8]; int njob; };
+
+__global__ void pack_kernel(const PackArgs pa) {
+  const PackJob& j = pa.job[blockIdx.y];
+  const long total = (long)j.K * j.Rpad * j.mspan;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int mp = (int)(i % j.mspan);
+    const long rest = i / j.mspan;
+    const int k = (int)(rest % j.Rpad);
+    const int tap = (int)(rest / j.Rpad);
+    int m = mp;
+    if (j.gate_half) {
+      const int g = mp >> 6, r = mp & 63;
+      m = (r < 32) ? (32 * g + r) : (j.gate_half + 32 * g + (r - 32));
+      if (32 * g + (r & 31) >= j.gate_half) m = j.Cm;   // beyond the real channels
+    }
+    float v = 0.f;
+    if (k < j.R && m < j.Cm) v = j.src[(long)k * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap];
+    j.dst[((long)tap * j.Rpad + k) * j.ldw + j.m_off + mp] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bwd-weight: gW[co, (seg,ci)] = sum_{b,t} gy[b,co,t] * x_seg[b,ci,tin(t)]
+// ---------------------------------------------------------------------------
+constexpr int WBK = 32, WP = WBK + 1;
+
+struct WSeg {
+  const float* x; long x_bstride; int x_cstride; int cin; int Tin;
+  int tmul, toff, tdiv;
+  float* gw; long gw_co_stride, gw_ci_stride;
+  int tile0;          // first global n-tile of this segment
+};
+struct WgradArgs {
+  const float* gy; long gy_bstride;
+  int M, Tout, B;
+  WSeg seg[MAXSEG]; int nseg;
+  int ntile_m, ntile_n;      // ntile_n = total over segments
+  int tchunk, nsplit_t;
+  float* slabs;              // [nsplit][ntile_m][ntile_n][128][128]
+  float* bslabs;             // [nsplit][ntile_m*128]
+  float* gb; float* gb2;     // bias grad destinations (nullable)
+  int accumulate;
+};
+
+__global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
+  __shared__ float As[BM][WP];
+  __shared__ float Bs[BN][WP];
+  const int tile = blockIdx.x;
+  const int mt = tile % a.ntile_m;
+  const int ntg = tile / a.ntile_m;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i)
+    if (i < a.nseg && ntg >= a.seg[i].tile0) s = i;
+  const WSeg& sg = a.seg[s];
+  const int n0 = (ntg - sg.tile0) * BN;
+  const int m0 = mt * BM;
+  const int split = blockIdx.y;
+  const int b = split / a.nsplit_t;
+  const int tc = split % a.nsplit_t;
+  const int tbeg = tc * a.tchunk;
+  const int tend = min(a.Tout, tbeg + a.tchunk);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int l_k = tid & 31, l_r = tid >> 5;   // staging: column k, rows l_r + 8i
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
+
+  const float* gyb = a.gy + (long)b * a.gy_bstride;
+  const float* xb = sg.x + (long)b * sg.x_bstride;
+  const bool do_bias = (ntg == 0) && (a.bslabs != nullptr);
+
+  float ra[16], rbv[16];
+  auto load = [&](int tb) {
+    const int t = tb + l_k;
+    const bool tok = t < tend;
+    const int tnum = t * sg.tmul + sg.toff;
+    bool xok = tok && tnum >= 0;
+    int tin = tnum;
+    if (sg.tdiv > 1) { xok = xok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+    xok = xok && tin < sg.Tin;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + l_r + 8 * i;
+      ra[i] = (tok && m < a.M) ? gyb[(long)m * a.Tout + t] : 0.f;
+      const int ci = n0 + l_r + 8 * i;
+      rbv[i] = (xok && ci < sg.cin) ? xb[(long)ci * sg.x_cstride + tin] : 0.f;
+    }
+  };
+
+  if (tbeg < tend) load(tbeg);
+  for (int tb = tbeg; tb < tend; tb += WBK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      As[l_r + 8 * i][l_k] = ra[i];
+      Bs[l_r + 8 * i][l_k] = rbv[i];
+      bsum[i] += ra[i];
+    }
+    __syncthreads();
+    if (tb + WBK < tend) load(tb + WBK);
+#pragma unroll
+    for (int kk = 0; kk < WBK / 2; ++kk) {
+      const float a0 = As[wm * 64 + li][kk * 2 + lk];
+      const float a1 = As[wm * 64 + 32 + li][kk * 2 + lk];
+      const float b0 = Bs[wn * 64 + li][kk * 2 + lk];
+      const float b1 = Bs[wn * 64 + 32 + li][kk * 2 + lk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  float* slab = a.slabs + (((long)split * a.ntile_m + mt) * a.ntile_n + ntg) * (BM * BN);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = wn * 64 + ni * 32 + li;
+        slab[row * BN + col] = acc[mi][ni][r];
+      }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
+      if (l_k == 0) a.bslabs[((long)split * a.ntile_m + mt) * BM + l_r + 8 * i] = v;
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
+  // one thread per (row, global column)
+  const long ncol = (long)a.ntile_n * BN;
+  const long total = (long)a.ntile_m * BM * ncol;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int colg = (int)(i % ncol);
+    const int row = (int)(i / ncol);
+    if (row >= a.M) continue;
+    const int ntg = colg / BN, col = colg % BN;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < MAXSEG; ++k)
+      if (k < a.nseg && ntg >= a.seg[k].tile0) s = k;
+    const WSeg& sg = a.seg[s];
+    const int ci = (ntg - sg.tile0) * BN + col;
+    if (ci >= sg.cin || sg.gw == nullptr) continue;
+    const int mt = row / BM, r = row % BM;
+    const float* p = a.slabs + ((long)mt * a.ntile_n + ntg) * (BM * BN) + r * BN + col;
+    const long sstride = (long)a.ntile_m * a.ntile_n * (BM * BN);
+    float v = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) v += p[sp * sstride];
+    float* dst = sg.gw + (long)row * sg.gw_co_stride + (long)ci * sg.gw_ci_stride;
+    if (a.accumulate) v += *dst;
+    *dst = v;
+  }
+  if (a.bslabs) {
+    const long totb = a.M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totb;
+         i += (long)gridDim.x * blockDim.x) {
+      float v = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) v += a.bslabs[(long)sp * a.ntile_m * BM + i];
+      if (a.gb) { a.gb[i] = a.accumulate ? a.gb[i] + v : v; }
+      if (a.gb2) { a.gb2[i] = a.accumulate ? a.gb2[i] + v : v; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------
+static inline int pad16(int v) { return (v + 15) / 16 * 16; }
+static inline int pad128(int v) { return (v + 127) / 128 * 128; }
+
+static bool seg_vec_ok(const Seg& s) {
+  return s.tmul == 1 && s.tdiv == 1 && (s.x_cstride % 4 == 0) && (s.x_bstride % 4 == 0) &&
+         (((uintptr_t)s.x) % 16 == 0);
+}
+
+template <int EPI>
+static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
+  g.ntile_m = cdiv(g.M, BM);
+  g.ntile_n = cdiv(g.Tout, BN);
+  for (int i = 0; i < g.nseg; ++i) g.seg[i].vec = seg_vec_ok(g.seg[i]) ? 1 : 0;
+  const long nblk = (long)g.ntile_m * g.ntile_n * g.B;
+  if (nblk <= 0) return 0;
+  VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
+  ProfScope ps(tag, st);
+  hipLaunchKernelGGL(conv_gemm_kernel<EPI>, dim3((unsigned)nblk), dim3(NT), 0, st, g);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_pack(PackArgs& pa, hipStream_t st) {
+  if (pa.njob == 0) return 0;
+  long mx = 0;
+  for (int i = 0; i < pa.njob; ++i) {
+    long t = (long)pa.job[i].K * pa.job[i].Rpad * pa.job[i].mspan;
+    if (t > mx) mx = t;
+  }
+  int nb = (int)((mx + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(pack_kernel, dim3(nb, pa.njob), dim3(256), 0, st, pa);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// A^T slab for the forward GEMM of a Chainer (Cout,Cin,K) weight: k=ci, m=co
+static PackJob pack_fwd_job(float* dst, const float* W, int Cout, int Cin, int K, int gate_half,
+                            int ldw, int m_off, int mspan) {
+  PackJob j;
+  j.dst = dst; j.src = W; j.R = Cin; j.Cm = Cout; j.K = K;
+  j.s_k = K; j.s_m = (long)Cin * K; j.s_tap = 1;
+  j.gate_half = gate_half; j.Rpad = pad16(Cin); j.ldw = ldw; j.m_off = m_off; j.mspan = mspan;
+  return j;
+}
+// A^T slab for the bwd-data GEMM: k=co, m=ci
+static PackJob pack_bwd_job(float* dst, const float* W, int Cout, int Cin, int K, int ldw) {
+  PackJob j;
+  j.dst = dst; j.src = W; j.R = Cout; j.Cm = Cin; j.K = K;
+  j.s_k = (long)Cin * K; j.s_m = K; j.s_tap = 1;
+  j.gate_half = 0; j.Rpad = pad16(Cout); j.ldw = ldw; j.m_off = 0; j.mspan = ldw;
+  return j;
+}
+
+struct WgradPlan { int ntile_m, ntile_n, nsplit_t, tchunk, nsplit; size_t slab_floats, bslab_floats; };
+
+static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
+  WgradPlan p;
+  p.ntile_m = cdiv(M, BM);
+  p.ntile_n = 0;
+  for (int i = 0; i < nseg; ++i) p.ntile_n += cdiv(cins[i], BN);
+  const long tiles = (long)p.ntile_m * p.ntile_n * B;
+  int want = (int)((1024 + tiles - 1) / tiles);
+  int maxs = Tout / 256;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  p.tchunk = cdiv(cdiv(Tout, want), WBK) * WBK;
+  p.nsplit_t = cdiv(Tout, p.tchunk);
+  p.nsplit = p.nsplit_t * B;
+  p.slab_floats = (size_t)p.nsplit * p.ntile_m * p.ntile_n * BM * BN;
+  p.bslab_floats = (size_t)p.nsplit * p.ntile_m * BM;
+  return p;
+}
+
+static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream_t st) {
+  w.ntile_m = p.ntile_m; w.ntile_n = p.ntile_n; w.tchunk = p.tchunk; w.nsplit_t = p.nsplit_t;
+  w.slabs = ws;
+  w.bslabs = (w.gb || w.gb2) ? ws + p.slab_floats : nullptr;
+  int t0 = 0;
+  for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
+  ProfScope ps(tag, st);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
+  VQ_LAUNCH_CHECK();
+  const long total = (long)p.ntile_m * BM * p.ntile_n * BN;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, w, p.nsplit);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+// ---------------------------------------------------------------------------
+// C ABI: generic conv1d
+// ---------------------------------------------------------------------------
+static int check_conv_desc(const vqvae_conv1d_desc* d) {
+  VQ_REQUIRE(d, "conv1d: null desc");
+  VQ_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Tin > 0 && d->Tout > 0, "conv1d: bad dims");
+  VQ_REQUIRE(d->K >= 1 && d->K <= MAXSEG, "conv1d: K=%d unsupported (1..%d)", d->K, MAXSEG);
+  VQ_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "conv1d: bad stride/dil/pad");
+  const int nat = (d->Tin + 2 * d->pad - d->dil * (d->K - 1) - 1) / d->stride + 1;
+  VQ_REQUIRE(d->Tout <= nat, "conv1d: Tout=%d exceeds natural output length %d", d->Tout, nat);
+  return 0;
+}
+
+static size_t conv_pack_floats(const vqvae_conv1d_desc* d) {
+  size_t f = (size_t)d->K * pad16(d->Cin) * pad128(d->Cout);
+  size_t b = (size_t)d->K * pad16(d->Cout) * pad128(d->Cin);
+  return f > b ? f : b;
+}
+
+extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
+  if (!d) return 0;
+  int cins[MAXSEG];
+  for (int i = 0; i < d->K && i < MAXSEG; ++i) cins[i] = d->Cin;
+  WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K < MAXSEG ? d->K : MAXSEG);
+  size_t wg = (p.slab_floats + p.bslab_floats) * sizeof(float);
+  size_t pk = conv_pack_floats(d) * sizeof(float);
+  return align_up(wg > pk ? wg : pk, 256) + 256;
+}
+
+extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                                const float* b, float* y, void* ws, size_t ws_bytes,
+                                vqvae_stream_t s) {
+  if (int e = check_conv_desc(d)) return e;
+  VQ_REQUIRE(x && W && y && ws, "conv1d_fwd: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const int ldw = pad128(d->Cout), rp = pad16(d->Cin);
+  if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  float* pk = (float*)ws;
+  PackArgs pa; pa.njob = 1;
+  pa.job[0] = pack_fwd_job(pk, W, d->Cout, d->Cin, d->K, 0, ldw, 0, ldw);
+  if (int e = launch_pack(pa, st)) return e;
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.nseg = d->K;
+  for (int j = 0; j < d->K; ++j) {
+    Seg& sg = g.seg[j];
+    sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
+    sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
+    sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
+  }
+  g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
+  g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
+  g.out[0].bias = b; g.out[0].relu = d->relu;
+  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_FWD, st);
+}
+
+extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const float* gy,
+                                     float* gx, int accumulate, void* ws, size_t ws_bytes,
+                                     vqvae_stream_t s) {
+  if (int e = check_conv_desc(d)) return e;
+  VQ_REQUIRE(W && gy && gx && ws, "conv1d_bwd_data: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const int ldw = pad128(d->Cin), rp = pad16(d->Cout);
+  if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_bwd_data: workspace too small"); return VQVAE_E_WORKSPACE; }
+  float* pk = (float*)ws;
+  PackArgs pa; pa.njob = 1;
+  pa.job[0] = pack_bwd_job(pk, W, d->Cout, d->Cin, d->K, ldw);
+  if (int e = launch_pack(pa, st)) return e;
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.nseg = d->K;
+  for (int j = 0; j < d->K; ++j) {
+    Seg& sg = g.seg[j];
+    sg.x = gy; sg.x_bstride = (long)d->Cout * d->Tout; sg.x_cstride = d->Tout; sg.cin = d->Cout; sg.Tin = d->Tout;
+    // t_out(gy) = (u + pad - j*dil) / stride
+    sg.tmul = 1; sg.toff = d->pad - j * d->dil; sg.tdiv = d->stride;
+    sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
+  }
+  g.M = d->Cin; g.Tout = d->Tin; g.B = d->B;
+  g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;
+  g.out[0].accumulate = accumulate;
+  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_BWD_DATA, st);
+}
+
+extern "C" int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                                       float* gW, float* gb, int accumulate, void* ws,
+                                       size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_conv_desc(d)) return e;
+  VQ_REQUIRE(x && gy && gW && ws, "conv1d_bwd_weight: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  int cins[MAXSEG];
+  for (int i = 0; i < d->K; ++i) cins[i] = d->Cin;
+  WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K);
+  if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("conv1d_bwd_weight: workspace too small"); return VQVAE_E_WORKSPACE; }
+  WgradArgs w; memset(&w, 0, sizeof(w));
+  w.gy = gy; w.gy_bstride = (long)d->Cout * d->Tout; w.M = d->Cout; w.Tout = d->Tout; w.B = d->B;
+  w.nseg = d->K;
+  for (int j = 0; j < d->K; ++j) {
+    WSeg& sg = w.seg[j];
+    sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
+    sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
+    sg.gw = gW + j; sg.gw_co_stride = (long)d->Cin * d->K; sg.gw_ci_stride = d->K;
+  }
+  w.gb = gb; w.gb2 = nullptr; w.accumulate = accumulate;
+  return launch_wgrad(w, p, (float*)ws, VQVAE_PROF_CONV_WGRAD, st);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: WaveNet ResidualBlock
+// ---------------------------------------------------------------------------
+namespace {
+struct RbLayout {
+  size_t gh, pk_d, pk_c, pk_o, pk_gz_r, pk_gz_s, pk_bd, pk_bc, slabs, total;   // float offsets
+  WgradPlan p_h, p_r, p_s;
+};
+
+static RbLayout rb_layout(const vqvae_resblock_desc* d) {
+  RbLayout L;
+  const int Ch = d->Cd / 2;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+  L.gh = take((size_t)d->B * d->Cd * d->T);
+  L.pk_d = take((size_t)d->K * pad16(d->Cr) * pad128(d->Cd));      // fwd dilated conv
+  L.pk_c = take((size_t)pad16(d->Cc) * pad128(d->Cd));             // fwd cond proj
+  L.pk_o = take((size_t)pad16(Ch) * pad128(d->Cr + d->Cs));        // fwd res|skip
+  L.pk_gz_r = take((size_t)pad16(d->Cr) * pad128(Ch));             // bwd gz from g_res
+  L.pk_gz_s = take((size_t)pad16(d->Cs) * pad128(Ch));             // bwd gz from g_skip
+  L.pk_bd = take((size_t)d->K * pad16(d->Cd) * pad128(d->Cr));     // bwd-data dilated conv
+  L.pk_bc = take((size_t)pad16(d->Cd) * pad128(d->Cc));            // bwd-data cond proj
+  int cins[MAXSEG];
+  for (int j = 0; j < d->K; ++j) cins[j] = d->Cr;
+  cins[d->K] = d->Cc;
+  L.p_h = plan_wgrad(d->Cd, d->B, d->T, cins, d->K + 1);
+  int cz[1] = {Ch};
+  L.p_r = plan_wgrad(d->Cr, d->B, d->T, cz, 1);
+  L.p_s = plan_wgrad(d->Cs, d->B, d->T, cz, 1);
+  size_t sl = L.p_h.slab_floats + L.p_h.bslab_floats;
+  size_t s2 = L.p_r.slab_floats + L.p_r.bslab_floats;
+  size_t s3 = L.p_s.slab_floats + L.p_s.bslab_floats;
+  if (s2 > sl) sl = s2;
+  if (s3 > sl) sl = s3;
+  L.slabs = take(sl);
+  L.total = o;
+  return L;
+}
+
+static int check_rb(const vqvae_resblock_desc* d) {
+  VQ_REQUIRE(d, "resblock: null desc");
+  VQ_REQUIRE(d->B > 0 && d->T > 0 && d->Cr > 0 && d->Cd > 0 && d->Cs > 0 && d->Cc > 0, "resblock: bad dims");
+  VQ_REQUIRE(d->Cd % 64 == 0, "resblock: dilated_channels/2 must be a multiple of 32 (got Cd=%d)", d->Cd);
+  VQ_REQUIRE(d->K >= 1 && d->K + 1 <= MAXSEG, "resblock: filter_size %d unsupported", d->K);
+  VQ_REQUIRE(d->dil >= 1, "resblock: bad dilation");
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
+  if (!d || d->Cd <= 0) return 0;
+  return rb_layout(d).total * sizeof(float) + 256;
+}
+
+extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                  const float* x, const float* cond, float* res, float* skip,
+                                  int skip_accumulate, float* gates, float* z, void* ws,
+                                  size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(p && x && cond && skip && gates && z && ws, "resblock_fwd: null pointer");
+  VQ_REQUIRE(p->Wd && p->Wc && p->Ws && (res == nullptr || p->Wr), "resblock_fwd: null weight");
+  hipStream_t st = (hipStream_t)s;
+  RbLayout L = rb_layout(d);
+  if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  float* w = (float*)ws;
+  const int Ch = d->Cd / 2, T = d->T;
+  const int ldd = pad128(d->Cd);
+  const int Mo = (res ? d->Cr : 0) + d->Cs;
+  const int ldo = pad128(Mo);
+
+  PackArgs pa; pa.njob = 0;
+  pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p->Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
+  pa.job[pa.njob++] = pack_fwd_job(w + L.pk_c, p->Wc, d->Cd, d->Cc, 1, Ch, ldd, 0, ldd);
+  if (res) {
+    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Wr, d->Cr, Ch, 1, 0, ldo, 0, d->Cr);
+    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Ws, d->Cs, Ch, 1, 0, ldo, d->Cr, ldo - d->Cr);
+  } else {
+    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Ws, d->Cs, Ch, 1, 0, ldo, 0, ldo);
+  }
+  VQ_REQUIRE(!res || d->Cr % 4 == 0, "resblock: residual_channels must be a multiple of 4");
+  if (int e = launch_pack(pa, st)) return e;
+
+  // K1: h = dilconv(x) + cond_proj(c) + biases -> gate
+  {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.nseg = d->K + 1;
+    const int rp = pad16(d->Cr);
+    for (int j = 0; j < d->K; ++j) {
+      Seg& sg = g.seg[j];
+      sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
+      sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
+      sg.w = w + L.pk_d + (size_t)j * rp * ldd; sg.ldw = ldd;
+    }
+    Seg& sc = g.seg[d->K];
+    sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
+    sc.tmul = 1; sc.toff = 0; sc.tdiv = 1; sc.w = w + L.pk_c; sc.ldw = ldd;
+    g.M = d->Cd; g.Tout = T; g.B = d->B;
+    g.out[0].y = gates; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].bias = p->bd; g.out[0].bias2 = p->bc;
+    g.out[0].rows = d->Cd;
+    g.out[1].y = z; g.out[1].y_bstride = (long)Ch * T;
+    if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
+  }
+  // K2: [res; skip] = [Wr; Ws] z (+ x) (+= skip)
+  {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.nseg = 1;
+    Seg& sg = g.seg[0];
+    sg.x = z; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + L.pk_o; sg.ldw = ldo;
+    g.M = Mo; g.Tout = T; g.B = d->B;
+    int o = 0;
+    if (res) {
+      g.out[0].y = res; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
+      g.out[0].add = x; g.out[0].add_bstride = (long)d->Cr * T; g.out[0].bias = p->br;
+      o = 1;
+    }
+    g.out[o].y = skip; g.out[o].y_bstride = (long)d->Cs * T; g.out[o].rows = d->Cs;
+    g.out[o].bias = p->bs; g.out[o].accumulate = skip_accumulate;
+    if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st)) return e;
+  }
+  return 0;
+}
+
+extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                  const float* x, const float* cond, const float* gates,
+                                  const float* z, const float* g_res, const float* g_skip,
+                                  float* gx, float* gcond, int gcond_accumulate,
+                                  const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
+                                  size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(p && x && cond && gates && z && g_skip && ws && gr, "resblock_bwd: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  RbLayout L = rb_layout(d);
+  if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  float* w = (float*)ws;
+  const int Ch = d->Cd / 2, T = d->T;
+  float* gh = w + L.gh;
+  const int ldz = pad128(Ch), ldr = pad128(d->Cr), ldc = pad128(d->Cc);
+
+  PackArgs pa; pa.njob = 0;
+  if (g_res) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_r, p->Wr, d->Cr, Ch, 1, ldz);
+  pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_s, p->Ws, d->Cs, Ch, 1, ldz);
+  if (gx) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bd, p->Wd, d->Cd, d->Cr, d->K, ldr);
+  if (gcond) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bc, p->Wc, d->Cd, d->Cc, 1, ldc);
+  if (int e = launch_pack(pa, st)) return e;
+
+  // K3: gz = Wr^T g_res + Ws^T g_skip ; gh = gate'(gz)
+  {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    int n = 0;
+    if (g_res) {
+      Seg& sg = g.seg[n++];
+      sg.x = g_res; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
+      sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + L.pk_gz_r; sg.ldw = ldz;
+    }
+    Seg& ss = g.seg[n++];
+    ss.x = g_skip; ss.x_bstride = (long)d->Cs * T; ss.x_cstride = T; ss.cin = d->Cs; ss.Tin = T;
+    ss.tmul = 1; ss.toff = 0; ss.tdiv = 1; ss.w = w + L.pk_gz_s; ss.ldw = ldz;
+    g.nseg = n;
+    g.M = Ch; g.Tout = T; g.B = d->B;
+    g.out[0].y = gh; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].rows = Ch;
+    g.out[0].add = gates; g.out[0].add_bstride = (long)d->Cd * T;
+    if (int e = launch_gemm<EPI_GATE_BWD>(g, VQVAE_PROF_RESBLOCK_BWD_GZ, st)) return e;
+  }
+  // K4: gx = g_res + sum_j Wd_j^T gh[t + (K-1-j) dil]
+  if (gx) {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.nseg = d->K;
+    const int rp = pad16(d->Cd);
+    for (int j = 0; j < d->K; ++j) {
+      Seg& sg = g.seg[j];
+      sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
+      sg.tmul = 1; sg.toff = (d->K - 1 - j) * d->dil; sg.tdiv = 1;
+      sg.w = w + L.pk_bd + (size_t)j * rp * ldr; sg.ldw = ldr;
+    }
+    g.M = d->Cr; g.Tout = T; g.B = d->B;
+    g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
+    g.out[0].add = g_res; g.out[0].add_bstride = (long)d->Cr * T;
+    if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GX, st)) return e;
+  }
+  // K5: gcond (+)= Wc^T gh
+  if (gcond) {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.nseg = 1;
+    Seg& sg = g.seg[0];
+    sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + L.pk_bc; sg.ldw = ldc;
+    g.M = d->Cc; g.Tout = T; g.B = d->B;
+    g.out[0].y = gcond; g.out[0].y_bstride = (long)d->Cc * T; g.out[0].rows = d->Cc;
+    g.out[0].accumulate = gcond_accumulate;
+    if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GC, st)) return e;
+  }
+  // K6a: gWd, gWc, gbd, gbc from gh
+  if (gr->gWd || gr->gWc || gr->gbd || gr->gbc) {
+    WgradArgs wa; memset(&wa, 0, sizeof(wa));
+    wa.gy = gh; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
+    wa.nseg = d->K + 1;
+    for (int j = 0; j < d->K; ++j) {
+      WSeg& sg = wa.seg[j];
+      sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
+      sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
+      sg.gw = gr->gWd ? gr->gWd + j : nullptr; sg.gw_co_stride = (long)d->Cr * d->K; sg.gw_ci_stride = d->K;
+    }
+    WSeg& sc = wa.seg[d->K];
+    sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
+    sc.tmul = 1; sc.toff = 0; sc.tdiv = 1;
+    sc.gw = gr->gWc; sc.gw_co_stride = d->Cc; sc.gw_ci_stride = 1;
+    wa.gb = gr->gbd; wa.gb2 = gr->gbc; wa.accumulate = grads_accumulate;
+    if (int e = launch_wgrad(wa, L.p_h, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
+  }
+  // K6b / K6c: gWr, gbr from g_res ; gWs, gbs from g_skip
+  for (int which = 0; which < 2; ++which) {
+    const float* gy = which ? g_skip : g_res;
+    float* gW = which ? gr->gWs : gr->gWr;
+    float* gb = which ? gr->gbs : gr->gbr;
+    const int M = which ? d->Cs : d->Cr;
+    if (!gy || (!gW && !gb)) continue;
+    WgradArgs wa; memset(&wa, 0, sizeof(wa));
+    wa.gy = gy; wa.gy_bstride = (long)M * T; wa.M = M; wa.Tout = T; wa.B = d->B;
+    wa.nseg = 1;
+    WSeg& sg = wa.seg[0];
+    sg.x = z; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
+    sg.gw = gW; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
+    wa.gb = gb; wa.accumulate = grads_accumulate;
+    if (int e = launch_wgrad(wa, which ? L.p_s : L.p_r, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
+  }
+  return 0;
+}

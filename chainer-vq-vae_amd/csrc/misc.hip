@@ -1,0 +1,323 @@
+// misc.hip -- HBM-bound kernels of the path: element-wise Variable arithmetic,
+// reductions, align-corners up-sampling, speaker-embedding broadcast, fused
+// softmax cross-entropy, Adam and EMA over flat arenas.  All are grid-stride,
+// coalesced along the contiguous time axis; fp32 ops that the NumPy path rounds
+// individually use the _rn intrinsics so hipcc cannot contract them into FMAs.
+#include "common.h"
+
+namespace vq {
+
+static inline int grid_for(size_t n, int block = 256, int cap = 2048) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ void ew_kernel(int op, size_t n, const float* __restrict__ a, const float* __restrict__ b,
+                          float* __restrict__ out, float alpha, float beta) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    switch (op) {
+      case VQVAE_EW_ADD: v = __fadd_rn(a[i], b[i]); break;
+      case VQVAE_EW_SUB: v = __fsub_rn(a[i], b[i]); break;
+      case VQVAE_EW_MUL: v = __fmul_rn(a[i], b[i]); break;
+      case VQVAE_EW_AXPBY: v = __fadd_rn(__fmul_rn(alpha, a[i]), __fmul_rn(beta, b[i])); break;
+      case VQVAE_EW_SCALE: v = __fmul_rn(alpha, a[i]); break;
+      case VQVAE_EW_SQUARE: v = __fmul_rn(a[i], a[i]); break;
+      case VQVAE_EW_RELU: v = fmaxf(a[i], 0.f); break;
+      case VQVAE_EW_RELU_BWD: v = b[i] > 0.f ? a[i] : 0.f; break;
+      case VQVAE_EW_FILL: v = alpha; break;
+      case VQVAE_EW_MUL_SCALAR_DEV: v = __fmul_rn(__fmul_rn(a[i], b[0]), alpha); break;
+      default: v = 0.f;
+    }
+    out[i] = v;
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ x, size_t n, float* partial) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) acc += x[i];
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ partial, int np, float scale, float* out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+// ---- up-sampling ---------------------------------------------------------
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, int B, int C, int Tin, int Tout,
+                                    const int32_t* __restrict__ v0, const int32_t* __restrict__ v1,
+                                    const float* __restrict__ w0, const float* __restrict__ w1,
+                                    float* __restrict__ y, long y_bstride) {
+  const long total = (long)B * C * Tout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Tout);
+    const long r = i / Tout;
+    const int c = (int)(r % C);
+    const long b = r / C;
+    const float* xr = x + (b * C + c) * (long)Tin;
+    y[b * y_bstride + (long)c * Tout + t] =
+        __fadd_rn(__fmul_rn(w0[t], xr[v0[t]]), __fmul_rn(w1[t], xr[v1[t]]));
+  }
+}
+
+__global__ void upsample_bwd_kernel(const float* __restrict__ gy, long gy_bstride, int B, int C,
+                                    int Tin, int Tout, const float* __restrict__ w0,
+                                    const float* __restrict__ w1, const int32_t* __restrict__ lo0,
+                                    const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
+                                    const int32_t* __restrict__ hi1, float* __restrict__ gx) {
+  const long total = (long)B * C * Tin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % Tin);
+    const long r = i / Tin;
+    const int c = (int)(r % C);
+    const long b = r / C;
+    const float* g = gy + b * gy_bstride + (long)c * Tout;
+    double acc = 0.0;     // numpy.bincount(weights=...) accumulates in float64
+    for (int t = lo0[v]; t < hi0[v]; ++t) acc += (double)__fmul_rn(g[t], w0[t]);
+    for (int t = lo1[v]; t < hi1[v]; ++t) acc += (double)__fmul_rn(g[t], w1[t]);
+    gx[i] = (float)acc;
+  }
+}
+
+// ---- speaker embedding broadcast -----------------------------------------
+__global__ void embed_bcast_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ ids,
+                                       int B, int G, int T, float* __restrict__ y, long y_bstride) {
+  const long total = (long)B * G * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int c = (int)(r % G);
+    const long b = r / G;
+    y[b * y_bstride + (long)c * T + t] = E[(long)ids[b] * G + c];
+  }
+}
+
+// one wavefront per (b,c) row: rowsum[b*G+c] = sum_t gy[b,c,t]
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ gy, long gy_bstride,
+                                                     int B, int G, int T, float* __restrict__ rs) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * G) return;
+  const int b = row / G, c = row % G;
+  const float* g = gy + (long)b * gy_bstride + (long)c * T;
+  float acc = 0.f;
+  for (int t = threadIdx.x & 63; t < T; t += 64) acc += g[t];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) rs[row] = acc;
+}
+
+__global__ void embed_scatter_kernel(const float* __restrict__ rs, const int32_t* __restrict__ ids,
+                                     int B, int G, int n_id, float* __restrict__ gE, int accumulate) {
+  const long total = (long)n_id * G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % G);
+    const int sid = (int)(i / G);
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+      if (ids[b] == sid) acc += rs[(long)b * G + c];
+    gE[i] = accumulate ? gE[i] + acc : acc;
+  }
+}
+
+// ---- softmax cross entropy -------------------------------------------------
+// thread per (b,t); channel stride T keeps every load coalesced along t.
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ y,
+                                                       const int32_t* __restrict__ tg, int B, int q,
+                                                       int T, float* __restrict__ lse,
+                                                       float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const long N = (long)B * T;
+  float lacc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+       i += (long)gridDim.x * blockDim.x) {
+    const long b = i / T;
+    const int t = (int)(i % T);
+    const float* yp = y + b * (long)q * T + t;
+    float m = -INFINITY;
+    for (int c = 0; c < q; ++c) m = fmaxf(m, yp[(long)c * T]);
+    float ssum = 0.f;
+    for (int c = 0; c < q; ++c) ssum += expf(yp[(long)c * T] - m);
+    const float l = logf(ssum) + m;
+    lse[i] = l;
+    lacc += l - yp[(long)tg[i] * T];
+  }
+  const float tot = block_sum_256(lacc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void xent_bwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ tg,
+                                const float* __restrict__ lse, const float* __restrict__ gloss,
+                                int B, int q, int T, float scale, float* __restrict__ gy) {
+  const long total = (long)B * q * T;
+  const float gs = (gloss ? gloss[0] : 1.f) * scale;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int c = (int)(r % q);
+    const long b = r / q;
+    const long pos = b * T + t;
+    float p = expf(y[i] - lse[pos]);
+    if (tg[pos] == c) p -= 1.f;
+    gy[i] = p * gs;
+  }
+}
+
+// ---- Adam / EMA ------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr, float c1, float c2, float eps) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = __fadd_rn(m[i], __fmul_rn(c1, __fsub_rn(gi, m[i])));
+    const float vi = __fadd_rn(v[i], __fmul_rn(c2, __fsub_rn(__fmul_rn(gi, gi), v[i])));
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(lr, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ tgt, size_t n, float d,
+                           float om) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    ema[i] = __fadd_rn(__fmul_rn(d, tgt[i]), __fmul_rn(om, ema[i]));
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" {
+
+int vqvae_elementwise(int op, size_t n, const float* a, const float* b, float* out, float alpha,
+                      float beta, vqvae_stream_t s) {
+  VQ_REQUIRE(out, "elementwise: null out");
+  VQ_REQUIRE(op >= 0 && op <= VQVAE_EW_MUL_SCALAR_DEV, "elementwise: bad op %d", op);
+  if (!n) return 0;
+  hipLaunchKernelGGL(ew_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, op, n, a, b, out, alpha, beta);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws, size_t ws_bytes,
+              vqvae_stream_t s) {
+  VQ_REQUIRE(x && out && ws, "sum: null pointer");
+  if (ws_bytes < 4096 * 4) { set_error("sum: workspace too small"); return VQVAE_E_WORKSPACE; }
+  const int np = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(sum_stage1, dim3(np), dim3(256), 0, (hipStream_t)s, x, n, (float*)ws);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, scale, out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_upsample_linear_fwd(const float* x, int B, int C, int Tin, int Tout, const int32_t* v0,
+                              const int32_t* v1, const float* w0, const float* w1, float* y,
+                              long y_bstride, vqvae_stream_t s) {
+  VQ_REQUIRE(x && v0 && v1 && w0 && w1 && y, "upsample_fwd: null pointer");
+  const size_t n = (size_t)B * C * Tout;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, B, C, Tin, Tout, v0, v1, w0, w1, y, y_bstride);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, int Tin, int Tout,
+                              const float* w0, const float* w1, const int32_t* lo0,
+                              const int32_t* hi0, const int32_t* lo1, const int32_t* hi1, float* gx,
+                              vqvae_stream_t s) {
+  VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd: null pointer");
+  const size_t n = (size_t)B * C * Tin;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_embed_broadcast_fwd(const float* E, const int32_t* ids, int B, int G, int T, float* y,
+                              long y_bstride, vqvae_stream_t s) {
+  VQ_REQUIRE(E && ids && y, "embed_fwd: null pointer");
+  const size_t n = (size_t)B * G * T;
+  hipLaunchKernelGGL(embed_bcast_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, E, ids, B, G, T, y, y_bstride);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_embed_broadcast_bwd(const float* gy, long gy_bstride, const int32_t* ids, int B, int G,
+                              int T, int n_id, float* gE, int accumulate, void* ws, size_t ws_bytes,
+                              vqvae_stream_t s) {
+  VQ_REQUIRE(gy && ids && gE && ws, "embed_bwd: null pointer");
+  if (ws_bytes < (size_t)B * G * 4) { set_error("embed_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipLaunchKernelGGL(rowsum_kernel, dim3(cdiv(B * G, 4)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, G, T, (float*)ws);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid_for((size_t)n_id * G)), dim3(256), 0, (hipStream_t)s, (const float*)ws, ids, B, G, n_id, gE, accumulate);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t vqvae_softmax_xent_workspace_bytes(int B, int q, int T) { (void)B; (void)q; (void)T; return 4096 * 4; }
+
+int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T, float* lse,
+                           float* loss, void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(y && t && lse && loss && ws, "softmax_xent_fwd: null pointer");
+  if (ws_bytes < 4096 * 4) { set_error("softmax_xent_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  const size_t N = (size_t)B * T;
+  const int np = grid_for(N, 256, 1024);
+  hipLaunchKernelGGL(xent_fwd_kernel, dim3(np), dim3(256), 0, (hipStream_t)s, y, t, B, q, T, lse, (float*)ws);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, (float)(1.0 / (double)N), loss);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse, const float* gloss,
+                           int B, int q, int T, float* gy, vqvae_stream_t s) {
+  VQ_REQUIRE(y && t && lse && gy, "softmax_xent_bwd: null pointer");
+  const size_t n = (size_t)B * q * T;
+  hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, y, t, lse, gloss, B, q, T, (float)(1.0 / ((double)B * T)), gy);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr_t,
+                    double beta1, double beta2, double eps, vqvae_stream_t s) {
+  VQ_REQUIRE(p && g && m && v, "adam_step: null pointer");
+  if (!n) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n,
+                     (float)lr_t, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_ema_step(float* ema, const float* target, size_t n, double decay, vqvae_stream_t s) {
+  VQ_REQUIRE(ema && target, "ema_step: null pointer");
+  if (!n) return 0;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, ema, target, n,
+                     (float)decay, (float)(1.0 - decay));
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

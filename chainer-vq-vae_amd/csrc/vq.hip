@@ -1,0 +1,295 @@
+// vq.hip -- the vector quantiser: nearest-codebook lookup (StraightThrough.forward,
+// utils.py:176-211) and its codebook gradient (utils.py:213-231).
+//
+// The reference's index is argmin_j of an fp32 distance evaluated as
+//     acc = 0; for c in 0..d-1: acc = acc + (z[c]-W[j][c])**2      (each op rounded)
+// with numpy.argmin's first-minimum rule.  Evaluating that form for all N*k
+// pairs is 3 non-fusable VALU ops per term; instead:
+//   1. vq_mfma_kernel  -- dist'(j,n) = |w_j|^2 - 2 <w_j, z_n> on the fp32 matrix
+//      cores (v_mfma_f32_32x32x2_f32: codes x latents tiles), per-lane running
+//      (min, argmin, runner-up) and a cross-half wavefront reduce.  A row is
+//      CERTAIN when runner-up - min exceeds a rigorous rounding band; otherwise it is
+//      queued for
+//   2. vq_exact_kernel -- all k codes re-evaluated in the reference's operation
+//      order (contraction off), ties to the lowest index.  Typically 1-3 % of rows.
+// The band: both forms are within (2d+3)*u*2S of the real-number distance, with
+// u = 2^-24 and S = |z|^2 + max_j |w_j|^2, so any code that can be the reference
+// argmin has dist' <= min dist' + 8(d+2)uS; we use 12(d+4)uS.
+#include "common.h"
+
+namespace vq {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__global__ void vq_wnorm_kernel(const float* __restrict__ W, int k, int d, float* wn, int* wmax_bits) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  float s = 0.f;
+  for (int c = 0; c < d; ++c) { const float w = W[(long)j * d + c]; s = fmaf(w, w, s); }
+  wn[j] = s;
+  atomicMax(wmax_bits, __float_as_int(s));   // s >= 0: int order == float order
+}
+
+// block: NW wavefronts, each owning 32 latent columns; Zs[d][32*NW], Ws[32][d+1]
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void vq_mfma_kernel(
+    const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ wn,
+    const int* __restrict__ wmax_bits, int B, int d, int T, int k, int dpad,
+    int32_t* __restrict__ idx, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+  extern __shared__ float smem[];
+  constexpr int NC = 32 * NW;
+  float* Zs = smem;                       // [dpad][NC]
+  float* Ws = smem + (size_t)dpad * NC;   // [32][dpad+1]
+  const int WPITCH = dpad + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long N = (long)B * T;
+  const long n0 = (long)blockIdx.x * NC;
+
+  // stage the latent columns (coalesced along t), zero padded in c and n
+  for (int e = tid; e < dpad * NC; e += 64 * NW) {
+    const int c = e / NC, col = e % NC;
+    const long n = n0 + col;
+    float v = 0.f;
+    if (c < d && n < N) { const long bb = n / T, t = n % T; v = z[(bb * d + c) * T + t]; }
+    Zs[c * NC + col] = v;
+  }
+
+  float m1 = INFINITY, m2 = INFINITY;
+  int i1 = 0x7fffffff;
+  const int ntile = (k + 31) / 32;
+  for (int jt = 0; jt < ntile; ++jt) {
+    __syncthreads();    // previous tile consumed (and Zs staged, first time)
+    for (int e = tid; e < 32 * dpad; e += 64 * NW) {
+      const int r = e / dpad, c = e % dpad;
+      const int j = jt * 32 + r;
+      Ws[r * WPITCH + c] = (j < k && c < d) ? W[(long)j * d + c] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* wrow = Ws + li * WPITCH + lk;
+    const float* zcol = Zs + lk * NC + wave * 32 + li;
+#pragma unroll 8
+    for (int kk = 0; kk < dpad / 2; ++kk) {
+      const float av = wrow[2 * kk];
+      const float bv = zcol[(2 * kk) * NC];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (j < k) {
+        const float v = fmaf(-2.f, acc[r], wn[j]);
+        if (v < m1) { m2 = m1; m1 = v; i1 = j; }
+        else if (v < m2) { m2 = v; }
+      }
+    }
+  }
+  // merge the two half-waves (same column, disjoint code rows)
+  {
+    const float om1 = __shfl_xor(m1, 32, 64);
+    const float om2 = __shfl_xor(m2, 32, 64);
+    const int oi1 = __shfl_xor(i1, 32, 64);
+    if (om1 < m1 || (om1 == m1 && oi1 < i1)) {
+      m2 = fminf(m1, om2); m1 = om1; i1 = oi1;
+    } else {
+      m2 = fminf(m2, om1);
+    }
+  }
+  const long n = n0 + wave * 32 + li;
+  if (lk == 0 && n < N) {
+    float zn = 0.f;
+    for (int c = 0; c < d; ++c) { const float v = Zs[c * NC + wave * 32 + li]; zn = fmaf(v, v, zn); }
+    const float wmax = __int_as_float(*wmax_bits);
+    const float band = 12.f * (float)(d + 4) * 5.9604645e-8f * (zn + wmax);
+    idx[n] = i1;
+    if (!(m2 - m1 > band)) {           // also catches NaN
+      const int slot = atomicAdd(nflag, 1);
+      flagged[slot] = (int32_t)n;
+    }
+  }
+}
+
+// exact evaluation in the reference's order for the queued rows (list != null) or
+// for every row (list == null).  One 256-thread block per row.
+__global__ __launch_bounds__(256) void vq_exact_kernel(
+    const float* __restrict__ z, const float* __restrict__ W, int B, int d, int T, int k,
+    const int32_t* __restrict__ list, const int32_t* __restrict__ nlist, int32_t* __restrict__ idx) {
+  extern __shared__ float smem[];
+  float* zs = smem;                         // [d]
+  float* rv = smem + d;                     // [256]
+  int* ri = (int*)(rv + 256);               // [256]
+  const long N = (long)B * T;
+  const long count = list ? (long)(*nlist) : N;
+  for (long q = blockIdx.x; q < count; q += gridDim.x) {
+    const long n = list ? (long)list[q] : q;
+    const long bb = n / T, t = n % T;
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) zs[c] = z[(bb * d + c) * T + t];
+    __syncthreads();
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < k; j += 256) {
+      const float* wr = W + (long)j * d;
+      float acc = 0.f;
+      for (int c = 0; c < d; ++c) {
+        const float df = __fsub_rn(zs[c], wr[c]);
+        acc = __fadd_rn(acc, __fmul_rn(df, df));
+      }
+      // j ascends per thread, so strict '<' keeps this thread's first minimum
+      if (acc < best || bi == 0x7fffffff) { best = acc; bi = j; }
+    }
+    rv[threadIdx.x] = best;
+    ri[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+      if (threadIdx.x < s) {
+        const float ov = rv[threadIdx.x + s];
+        const int oi = ri[threadIdx.x + s];
+        const float mv = rv[threadIdx.x];
+        const int mi = ri[threadIdx.x];
+        // numpy.argmin: first minimum; NaN never occurs for finite inputs
+        if (oi != 0x7fffffff && (mi == 0x7fffffff || ov < mv || (ov == mv && oi < mi))) {
+          rv[threadIdx.x] = ov; ri[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) idx[n] = ri[0];
+  }
+}
+
+__global__ void vq_gather_kernel(const float* __restrict__ W, const int32_t* __restrict__ idx,
+                                 int B, int d, int T, float* __restrict__ e) {
+  const long total = (long)B * d * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int c = (int)(r % d);
+    const long bb = r / d;
+    e[i] = W[(long)idx[bb * T + t] * d + c];
+  }
+}
+
+__global__ void vq_scatter64_kernel(const int32_t* __restrict__ idx, const float* __restrict__ gy,
+                                    int B, int d, int T, double* g64) {
+  const long total = (long)B * d * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int c = (int)(r % d);
+    const long bb = r / d;
+    atomicAdd(&g64[(long)idx[bb * T + t] * d + c], (double)gy[i]);
+  }
+}
+
+__global__ void vq_cast64_kernel(const double* __restrict__ g64, long n, float* gW, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float v = (float)g64[i];
+    gW[i] = accumulate ? __fadd_rn(gW[i], v) : v;
+  }
+}
+
+static int vq_cols_per_block(int dpad) {
+  // LDS: dpad*NC + 32*(dpad+1) floats <= ~150 KB
+  for (int nw = 4; nw >= 1; nw >>= 1) {
+    size_t bytes = ((size_t)dpad * 32 * nw + 32 * (size_t)(dpad + 1)) * 4;
+    if (bytes <= 150 * 1024) return nw;
+  }
+  return 0;
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" size_t vqvae_vq_workspace_bytes(int B, int d, int T, int k) {
+  const size_t N = (size_t)B * T;
+  size_t fwd = align_up((size_t)k * 4, 256) + 256 /*wmax+nflag*/ + align_up(N * 4, 256);
+  size_t bwd = align_up((size_t)k * d * 8, 256);
+  return (fwd > bwd ? fwd : bwd) + 256;
+}
+
+extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d, int T, int k,
+                                    int mode, int32_t* idx, float* e, int32_t* n_rechecked,
+                                    void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(z && W && idx && ws, "vq_nearest_fwd: null pointer");
+  VQ_REQUIRE(B > 0 && d > 0 && T > 0 && k > 0, "vq_nearest_fwd: bad dims");
+  if (ws_bytes < vqvae_vq_workspace_bytes(B, d, T, k)) { set_error("vq_nearest_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  const long N = (long)B * T;
+  char* wp = (char*)ws;
+  float* wn = (float*)wp; wp += align_up((size_t)k * 4, 256);
+  int* wmax_bits = (int*)wp;
+  int32_t* nflag = (int32_t*)(wp + 64); wp += 256;
+  int32_t* flagged = (int32_t*)wp;
+  ProfScope ps(VQVAE_PROF_VQ_NEAREST, st);
+  if (mode == 0) {
+    const int dpad = (d + 1) / 2 * 2;
+    const int nw = vq_cols_per_block(dpad);
+    VQ_REQUIRE(nw > 0, "vq_nearest_fwd: d=%d too large for the LDS-staged MFMA path (max ~1000)", d);
+    VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
+    hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
+    VQ_LAUNCH_CHECK();
+    const int NC = 32 * nw;
+    const size_t lds = ((size_t)dpad * NC + 32 * (size_t)(dpad + 1)) * 4;
+    const unsigned grid = (unsigned)((N + NC - 1) / NC);
+    if (nw == 4) {
+      VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(vq_mfma_kernel<4>, dim3(grid), dim3(256), lds, st, z, W, wn, wmax_bits, B, d, T, k, dpad, idx, flagged, nflag);
+    } else if (nw == 2) {
+      VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(vq_mfma_kernel<2>, dim3(grid), dim3(128), lds, st, z, W, wn, wmax_bits, B, d, T, k, dpad, idx, flagged, nflag);
+    } else {
+      VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(vq_mfma_kernel<1>, dim3(grid), dim3(64), lds, st, z, W, wn, wmax_bits, B, d, T, k, dpad, idx, flagged, nflag);
+    }
+    VQ_LAUNCH_CHECK();
+    const size_t lds2 = ((size_t)d + 512) * 4;
+    unsigned g2 = (unsigned)(N < 4096 ? N : 4096);
+    hipLaunchKernelGGL(vq_exact_kernel, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, flagged, nflag, idx);
+    VQ_LAUNCH_CHECK();
+    if (n_rechecked) VQ_CHECK_HIP(hipMemcpyAsync(n_rechecked, nflag, 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    const size_t lds2 = ((size_t)d + 512) * 4;
+    unsigned g2 = (unsigned)(N < 65535 ? N : 65535);
+    hipLaunchKernelGGL(vq_exact_kernel, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, idx);
+    VQ_LAUNCH_CHECK();
+    if (n_rechecked) VQ_CHECK_HIP(hipMemsetAsync(n_rechecked, 0, 4, st));
+  }
+  if (e) {
+    const long total = (long)B * d * T;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(vq_gather_kernel, dim3(nb), dim3(256), 0, st, W, idx, B, d, T, e);
+    VQ_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d, int T, int k,
+                               float* gW, int accumulate, void* ws, size_t ws_bytes,
+                               vqvae_stream_t s) {
+  VQ_REQUIRE(idx && gy && gW && ws, "vq_grad_w: null pointer");
+  if (ws_bytes < (size_t)k * d * 8) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  double* g64 = (double*)ws;
+  VQ_CHECK_HIP(hipMemsetAsync(g64, 0, (size_t)k * d * 8, st));
+  const long total = (long)B * d * T;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(vq_scatter64_kernel, dim3(nb), dim3(256), 0, st, idx, gy, B, d, T, g64);
+  VQ_LAUNCH_CHECK();
+  const long n = (long)k * d;
+  int nb2 = (int)((n + 255) / 256);
+  if (nb2 > 4096) nb2 = 4096;
+  hipLaunchKernelGGL(vq_cast64_kernel, dim3(nb2), dim3(256), 0, st, g64, n, gW, accumulate);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}

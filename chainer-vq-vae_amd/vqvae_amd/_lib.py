@@ -1,0 +1,136 @@
+"""ctypes binding of libvqvae_hip.so (include/vqvae_hip.h).
+
+There is no CPU fallback: if the shared library is missing, importing anything
+that needs it raises, and every compute entry point requires a gfx950 device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libvqvae_hip.so')
+
+c_void_p, c_int, c_long, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+c_float, c_double, c_char_p = C.c_float, C.c_double, C.c_char_p
+P = c_void_p                      # every device pointer crosses as an integer address
+
+
+class Conv1dDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in
+                ('B', 'Cin', 'Tin', 'Cout', 'Tout', 'K', 'stride', 'pad', 'dil', 'relu')]
+
+
+class ResblockDesc(C.Structure):
+    _fields_ = [(n, c_int) for n in ('B', 'T', 'Cr', 'Cd', 'Cs', 'Cc', 'K', 'dil')]
+
+
+class ResblockParams(C.Structure):
+    _fields_ = [(n, P) for n in ('Wd', 'bd', 'Wc', 'bc', 'Wr', 'br', 'Ws', 'bs')]
+
+
+class ResblockGrads(C.Structure):
+    _fields_ = [(n, P) for n in ('gWd', 'gbd', 'gWc', 'gbc', 'gWr', 'gbr', 'gWs', 'gbs')]
+
+
+# name -> (restype, argtypes); this table IS the list of symbols the header declares
+PROTOTYPES = {
+    'vqvae_last_error_string': (c_char_p, []),
+    'vqvae_abi_version': (c_int, []),
+    'vqvae_device_count': (c_int, [C.POINTER(c_int)]),
+    'vqvae_set_device': (c_int, [c_int]),
+    'vqvae_device_info': (c_int, [c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_size_t)]),
+    'vqvae_malloc': (c_int, [C.POINTER(c_void_p), c_size_t]),
+    'vqvae_free': (c_int, [P]),
+    'vqvae_memcpy_h2d': (c_int, [P, c_void_p, c_size_t, P]),
+    'vqvae_memcpy_d2h': (c_int, [c_void_p, P, c_size_t, P]),
+    'vqvae_memcpy_d2d': (c_int, [P, P, c_size_t, P]),
+    'vqvae_memset': (c_int, [P, c_int, c_size_t, P]),
+    'vqvae_stream_create': (c_int, [C.POINTER(c_void_p)]),
+    'vqvae_stream_destroy': (c_int, [P]),
+    'vqvae_stream_synchronize': (c_int, [P]),
+    'vqvae_device_synchronize': (c_int, []),
+    'vqvae_event_create': (c_int, [C.POINTER(c_void_p)]),
+    'vqvae_event_destroy': (c_int, [P]),
+    'vqvae_event_record': (c_int, [P, P]),
+    'vqvae_event_synchronize': (c_int, [P]),
+    'vqvae_event_elapsed_ms': (c_int, [C.POINTER(c_float), P, P]),
+    'vqvae_prof_enable': (c_int, [c_int]),
+    'vqvae_prof_reset': (c_int, []),
+    'vqvae_prof_read': (c_int, [c_int, C.POINTER(c_double), C.POINTER(c_int)]),
+    'vqvae_conv1d_workspace_bytes': (c_size_t, [C.POINTER(Conv1dDesc)]),
+    'vqvae_conv1d_fwd': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, P]),
+    'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),
+    'vqvae_conv1d_bwd_weight': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P]),
+    'vqvae_resblock_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc)]),
+    'vqvae_resblock_fwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
+                                   c_int, P, P, P, c_size_t, P]),
+    'vqvae_resblock_bwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
+                                   P, P, P, P, c_int, C.POINTER(ResblockGrads), c_int, P,
+                                   c_size_t, P]),
+    'vqvae_vq_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'vqvae_vq_nearest_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P,
+                                     c_size_t, P]),
+    'vqvae_vq_grad_w': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
+    'vqvae_upsample_linear_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_long, P]),
+    'vqvae_upsample_linear_bwd': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
+                                          P, P]),
+    'vqvae_embed_broadcast_fwd': (c_int, [P, P, c_int, c_int, c_int, P, c_long, P]),
+    'vqvae_embed_broadcast_bwd': (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, P, c_int, P,
+                                          c_size_t, P]),
+    'vqvae_softmax_xent_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vqvae_softmax_xent_fwd': (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    'vqvae_softmax_xent_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
+    'vqvae_elementwise': (c_int, [c_int, c_size_t, P, P, P, c_float, c_float, P]),
+    'vqvae_sum': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
+    'vqvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, P]),
+    'vqvae_ema_step': (c_int, [P, P, c_size_t, c_double, P]),
+    'vqvae_comm_unique_id': (c_int, [c_char_p]),
+    'vqvae_comm_init': (c_int, [C.POINTER(c_void_p), c_int, c_int, c_char_p]),
+    'vqvae_comm_allreduce_sum_f32': (c_int, [P, P, c_size_t, P]),
+    'vqvae_comm_allreduce_max_f32': (c_int, [P, P, c_size_t, P]),
+    'vqvae_comm_destroy': (c_int, [P]),
+}
+
+# elementwise op codes / profiler tags (mirror the header)
+EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
+    EW_MUL_SCALAR_DEV = range(10)
+PROF_RESBLOCK_GATE, PROF_RESBLOCK_OUT, PROF_RESBLOCK_BWD_GZ, PROF_RESBLOCK_BWD_GX, \
+    PROF_RESBLOCK_BWD_GC, PROF_RESBLOCK_WGRAD, PROF_CONV_FWD, PROF_CONV_BWD_DATA, \
+    PROF_CONV_WGRAD, PROF_VQ_NEAREST = range(1, 11)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libvqvae_hip.so (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libvqvae_hip.so not found at %s -- build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().vqvae_last_error_string()
+        raise HipError('%s failed (code %d): %s' % (what or 'libvqvae_hip call', rc,
+                                                    msg.decode() if msg else ''))
+
+
+def call(name, *args):
+    """Calls an int-returning entry point and raises HipError on failure."""
+    check(getattr(load(), name)(*args), name)

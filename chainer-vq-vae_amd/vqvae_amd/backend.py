@@ -1,0 +1,253 @@
+"""Device arrays, the caching allocator and the per-process stream.
+
+This is the plumbing Chainer gets from CuPy (ndarray + memory pool + streams);
+here it sits directly on the C ABI (vqvae_malloc / vqvae_memcpy_* /
+vqvae_stream_*).  One process drives one GPU on one stream; every kernel of the
+library is enqueued on ``stream()``.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+_state = {'stream': None, 'device': None, 'pool': {}, 'live_bytes': 0, 'pool_bytes': 0,
+          'ws': None}
+
+
+def init(device=0):
+    """Selects the GPU and creates the process stream (idempotent)."""
+    if _state['stream'] is not None:
+        if device != _state['device']:
+            raise RuntimeError('backend already initialised on device %d' % _state['device'])
+        return
+    lib = _lib.load()
+    n = C.c_int(0)
+    rc = lib.vqvae_device_count(C.byref(n))
+    if rc != 0 or n.value < 1:
+        raise RuntimeError(
+            'no HIP device visible (%s): this framework has no CPU compute path'
+            % lib.vqvae_last_error_string().decode())
+    _lib.call('vqvae_set_device', device)
+    s = C.c_void_p()
+    _lib.call('vqvae_stream_create', C.byref(s))
+    _state['stream'] = s
+    _state['device'] = device
+
+
+def available():
+    """True when the library loads and at least one GPU is visible."""
+    try:
+        lib = _lib.load()
+    except (ImportError, OSError):
+        return False
+    n = C.c_int(0)
+    return lib.vqvae_device_count(C.byref(n)) == 0 and n.value > 0
+
+
+def stream():
+    if _state['stream'] is None:
+        init(0)
+    return _state['stream']
+
+
+def synchronize():
+    _lib.call('vqvae_stream_synchronize', stream())
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    ncu = C.c_int(0)
+    mem = C.c_size_t(0)
+    stream()
+    _lib.call('vqvae_device_info', name, 256, C.byref(ncu), C.byref(mem))
+    return {'name': name.value.decode(), 'n_cu': ncu.value, 'total_mem': mem.value}
+
+
+# --------------------------------------------------------------------------- #
+# caching allocator: exact-size free lists (a training step repeats its sizes)
+# --------------------------------------------------------------------------- #
+def _round(nbytes):
+    return max(256, (nbytes + 255) // 256 * 256)
+
+
+class _Block(object):
+    __slots__ = ('ptr', 'nbytes', '__weakref__')
+
+    def __init__(self, nbytes):
+        nbytes = _round(nbytes)
+        free = _state['pool'].get(nbytes)
+        if free:
+            self.ptr = free.pop()
+            _state['pool_bytes'] -= nbytes
+        else:
+            stream()
+            p = C.c_void_p()
+            _lib.call('vqvae_malloc', C.byref(p), nbytes)
+            self.ptr = p.value
+        self.nbytes = nbytes
+        _state['live_bytes'] += nbytes
+
+    def __del__(self):
+        try:
+            _state['pool'].setdefault(self.nbytes, []).append(self.ptr)
+            _state['pool_bytes'] += self.nbytes
+            _state['live_bytes'] -= self.nbytes
+        except Exception:      # interpreter shutdown
+            pass
+
+
+def free_all_blocks():
+    """Returns every cached (unused) block to the driver."""
+    for nbytes, ptrs in _state['pool'].items():
+        for p in ptrs:
+            _lib.call('vqvae_free', p)
+    _state['pool'].clear()
+    _state['pool_bytes'] = 0
+
+
+def memory_stats():
+    return {'live_bytes': _state['live_bytes'], 'cached_bytes': _state['pool_bytes']}
+
+
+class DeviceArray(object):
+    """A contiguous device buffer with NumPy-like metadata (the ``xp.ndarray``
+    of this backend).  Views share the owning block."""
+    __slots__ = ('ptr', 'shape', 'dtype', '_block', '__weakref__')
+
+    def __init__(self, shape, dtype=np.float32, _block=None, _ptr=None):
+        if isinstance(shape, int):
+            shape = (shape,)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        if _block is None:
+            _block = _Block(self.nbytes)
+            _ptr = _block.ptr
+        self._block = _block
+        self.ptr = _ptr
+
+    # ---- metadata ----
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return 'DeviceArray(shape=%s, dtype=%s, ptr=0x%x)' % (self.shape, self.dtype, self.ptr)
+
+    # ---- views ----
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            i = shape.index(-1)
+            known = 1
+            for j, s in enumerate(shape):
+                if j != i:
+                    known *= s
+            shape[i] = self.size // known
+        n = 1
+        for s in shape:
+            n *= s
+        if n != self.size:
+            raise ValueError('cannot reshape %s into %s' % (self.shape, tuple(shape)))
+        return DeviceArray(tuple(shape), self.dtype, _block=self._block, _ptr=self.ptr)
+
+    def flat_view(self, offset, size, shape=None):
+        """View of ``size`` elements starting ``offset`` elements in."""
+        if offset < 0 or offset + size > self.size:
+            raise ValueError('flat_view out of range')
+        return DeviceArray(shape if shape is not None else (size,), self.dtype,
+                           _block=self._block, _ptr=self.ptr + offset * self.dtype.itemsize)
+
+    # ---- transfers ----
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError('size mismatch in DeviceArray.set: %s vs %s' % (host.shape, self.shape))
+        _lib.call('vqvae_memcpy_h2d', self.ptr, host.ctypes.data, self.nbytes, stream())
+        return self
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        _lib.call('vqvae_memcpy_d2h', out.ctypes.data, self.ptr, self.nbytes, stream())
+        return out
+
+    def copy(self):
+        out = DeviceArray(self.shape, self.dtype)
+        _lib.call('vqvae_memcpy_d2d', out.ptr, self.ptr, self.nbytes, stream())
+        return out
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError('size mismatch in copy_from')
+        _lib.call('vqvae_memcpy_d2d', self.ptr, other.ptr, self.nbytes, stream())
+        return self
+
+    def fill_zero(self):
+        _lib.call('vqvae_memset', self.ptr, 0, self.nbytes, stream())
+        return self
+
+    def __float__(self):
+        if self.size != 1:
+            raise TypeError('only size-1 arrays convert to float')
+        return float(self.get().reshape(()))
+
+
+def to_device(host, dtype=None):
+    host = np.asarray(host)
+    if dtype is None:
+        dtype = host.dtype
+    return DeviceArray(host.shape, dtype).set(host)
+
+
+def empty(shape, dtype=np.float32):
+    return DeviceArray(shape, dtype)
+
+
+def zeros(shape, dtype=np.float32):
+    return DeviceArray(shape, dtype).fill_zero()
+
+
+def is_device(x):
+    return isinstance(x, DeviceArray)
+
+
+def require_device(*arrays):
+    """The NumPy/device mix guard of utils.py:183-186, plus: NumPy inputs are not
+    computable here at all (no CPU path)."""
+    for a in arrays:
+        if not isinstance(a, DeviceArray):
+            if isinstance(a, np.ndarray):
+                raise ValueError(
+                    'numpy and device arrays must not be used together / host arrays cannot '
+                    'be computed on: call to_gpu() first (type: %s)' % type(a))
+            raise TypeError('expected a DeviceArray, got %s' % type(a))
+
+
+# --------------------------------------------------------------------------- #
+# one growing scratch buffer shared by all entry points (single stream => the
+# kernels that use it are ordered)
+# --------------------------------------------------------------------------- #
+def workspace(nbytes):
+    ws = _state['ws']
+    if ws is None or ws.nbytes < nbytes:
+        _state['ws'] = None
+        ws = DeviceArray((int(nbytes * 1.25) // 4 + 64,), np.float32)
+        _state['ws'] = ws
+    return ws

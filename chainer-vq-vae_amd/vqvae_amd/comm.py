@@ -1,0 +1,137 @@
+"""Data-parallel communicators.
+
+``RcclCommunicator`` -- one process per GPU, gradients exchanged by one in-place
+RCCL all-reduce(sum) of the flat gradient arena over xGMI (C ABI
+vqvae_comm_*).  Replaces Link.addgrads + Link.copyparams of the reference's
+single-process multi-GPU updater (updaters.py:71-77).
+
+Rendezvous: rank 0 creates the ncclUniqueId and publishes it through a file
+keyed by the launcher's (MASTER_PORT, parent pid); the launcher
+(`python -m torch.distributed.run`) only supplies RANK/WORLD_SIZE/MASTER_* --
+torch itself is never imported in a GPU process (it bundles its own HIP runtime).
+
+``GlooHostCommunicator`` -- the same interface over torch.distributed/gloo on
+host NumPy buffers; used by the world_size-2 CPU tests of the shard/sum/lr
+logic, never on the GPU path.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+
+def shard(batch, rank, size):
+    """The reference's strided split ``batch[i::n]`` (updaters.py:37-38)."""
+    return batch[rank::size]
+
+
+def scaled_alpha(lr, size):
+    """train.py:101: Adam(params.lr / len(args.gpus)) -- gradients are SUMMED
+    over replicas (updaters.py:72), the step size is divided instead."""
+    return lr / size
+
+
+class SingleCommunicator(object):
+    rank, size = 0, 1
+
+    def allreduce_grad(self, flat):
+        return flat
+
+    def barrier(self):
+        pass
+
+    def max_scalar(self, v):
+        return v
+
+
+def _rendezvous_path():
+    port = os.environ.get('MASTER_PORT', '0')
+    run = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+    restart = os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    return '/tmp/vqvae_rccl_uid_%s_%s_%s_%d' % (port, run, restart, os.getppid())
+
+
+class RcclCommunicator(object):
+    def __init__(self, rank=None, size=None, device=None, timeout=300.0):
+        from . import _lib, backend
+        self.rank = int(os.environ.get('RANK', 0)) if rank is None else rank
+        self.size = int(os.environ.get('WORLD_SIZE', 1)) if size is None else size
+        local = int(os.environ.get('LOCAL_RANK', self.rank)) if device is None else device
+        backend.init(local)
+        self._lib, self._backend = _lib, backend
+        path = _rendezvous_path()
+        idbuf = C.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.call('vqvae_comm_unique_id', idbuf)
+            tmp = path + '.tmp'
+            with open(tmp, 'wb') as f:
+                f.write(idbuf.raw)
+            os.rename(tmp, path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout:
+                    raise RuntimeError('RCCL rendezvous timed out waiting for %s' % path)
+                time.sleep(0.05)
+            with open(path, 'rb') as f:
+                raw = f.read()
+            idbuf = C.create_string_buffer(raw, 128)
+        comm = C.c_void_p()
+        _lib.call('vqvae_comm_init', C.byref(comm), self.size, self.rank, idbuf)
+        self._comm = comm
+        self._scalar = backend.zeros((1,), np.float32)
+        self.barrier()
+        if self.rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    def allreduce_grad(self, flat):
+        """In-place sum over ranks of a flat fp32 DeviceArray."""
+        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, flat.ptr, flat.size,
+                       self._backend.stream())
+        return flat
+
+    def barrier(self):
+        self._scalar.fill_zero()
+        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, self._scalar.ptr, 1,
+                       self._backend.stream())
+        self._backend.synchronize()
+
+    def max_scalar(self, v):
+        self._scalar.set(np.array([v], np.float32))
+        self._lib.call('vqvae_comm_allreduce_max_f32', self._comm, self._scalar.ptr, 1,
+                       self._backend.stream())
+        return float(self._scalar.get()[0])
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.call('vqvae_comm_destroy', self._comm)
+            self._comm = None
+
+
+class GlooHostCommunicator(object):
+    """torch.distributed/gloo on host buffers -- CPU tests only."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+
+    def allreduce_grad(self, flat):
+        import torch
+        t = torch.from_numpy(flat)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return flat
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def max_scalar(self, v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])

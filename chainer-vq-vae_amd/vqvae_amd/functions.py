@@ -1,0 +1,385 @@
+"""FunctionNodes of the hot path (the ``chainer.functions`` subset the reference
+uses), each marshalling device pointers + dims into one C-ABI call.
+
+Reference call sites: F.relu net.py:20-24,49-53 / modules.py:155,158;
+F.resize_images + EmbedID + F.concat net.py:54-63; F.mean net.py:90-91;
+softmax_cross_entropy train.py:95; Variable arithmetic net.py:90-92.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, backend
+from .backend import DeviceArray
+from .core import FunctionNode, Variable, as_variable, type_expect
+
+_S = backend.stream
+
+
+def _p(a):
+    return None if a is None else a.ptr
+
+
+# --------------------------------------------------------------------------- #
+# raw element-wise helpers (no graph)
+# --------------------------------------------------------------------------- #
+def _ew(op, a, b=None, out=None, alpha=0.0, beta=0.0, like=None):
+    ref = a if a is not None else like
+    if out is None:
+        out = DeviceArray(ref.shape, np.float32)
+    _lib.call('vqvae_elementwise', op, out.size, _p(a), _p(b), out.ptr, alpha, beta, _S())
+    return out
+
+
+def raw_add(a, b, out=None):
+    if a.size != b.size:
+        raise ValueError('shape mismatch in add: %s vs %s' % (a.shape, b.shape))
+    return _ew(_lib.EW_ADD, a, b, out)
+
+
+def full_like(a, value):
+    return _ew(_lib.EW_FILL, None, None, None, alpha=float(value), like=a)
+
+
+def raw_sum(x, scale=1.0):
+    out = DeviceArray((), np.float32)
+    ws = backend.workspace(4096 * 4)
+    _lib.call('vqvae_sum', x.ptr, x.size, float(scale), out.ptr, ws.ptr, ws.nbytes, _S())
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Variable arithmetic
+# --------------------------------------------------------------------------- #
+class Add(FunctionNode):
+    def forward(self, inputs):
+        a, b = inputs
+        backend.require_device(a, b)
+        return raw_add(a, b),
+
+    def backward(self, indexes, gys):
+        g = gys[0].data
+        return g, g
+
+
+class Sub(FunctionNode):
+    def forward(self, inputs):
+        a, b = inputs
+        backend.require_device(a, b)
+        if a.size != b.size:
+            raise ValueError('shape mismatch in sub')
+        return _ew(_lib.EW_SUB, a, b),
+
+    def backward(self, indexes, gys):
+        g = gys[0].data
+        return g, _ew(_lib.EW_SCALE, g, alpha=-1.0)
+
+
+class Mul(FunctionNode):
+    def forward(self, inputs):
+        a, b = inputs
+        backend.require_device(a, b)
+        self.retain_inputs((0, 1))
+        if b.size == 1 and a.size != 1:
+            return _ew(_lib.EW_MUL_SCALAR_DEV, a, b, alpha=1.0),
+        if a.size != b.size:
+            raise ValueError('shape mismatch in mul')
+        return _ew(_lib.EW_MUL, a, b),
+
+    def backward(self, indexes, gys):
+        a, b = (v.data for v in self.get_retained_inputs())
+        g = gys[0].data
+        if b.size == 1 and a.size != 1:
+            ga = _ew(_lib.EW_MUL_SCALAR_DEV, g, b, alpha=1.0)
+            gb = raw_sum(_ew(_lib.EW_MUL, g, a))
+            return ga, gb
+        return _ew(_lib.EW_MUL, g, b), _ew(_lib.EW_MUL, g, a)
+
+
+class MulScalar(FunctionNode):
+    def __init__(self, c):
+        self.c = float(c)
+
+    def forward(self, inputs):
+        backend.require_device(inputs[0])
+        return _ew(_lib.EW_SCALE, inputs[0], alpha=self.c),
+
+    def backward(self, indexes, gys):
+        return _ew(_lib.EW_SCALE, gys[0].data, alpha=self.c),
+
+
+class Square(FunctionNode):
+    def forward(self, inputs):
+        backend.require_device(inputs[0])
+        self.retain_inputs((0,))
+        return _ew(_lib.EW_SQUARE, inputs[0]),
+
+    def backward(self, indexes, gys):
+        x = self.get_retained_inputs()[0].data
+        t = _ew(_lib.EW_MUL, gys[0].data, x)
+        return _ew(_lib.EW_SCALE, t, alpha=2.0, out=t),
+
+
+class Mean(FunctionNode):
+    """F.mean over all elements (net.py:90-91)."""
+
+    def forward(self, inputs):
+        x = inputs[0]
+        backend.require_device(x)
+        self._shape = x.shape
+        self._n = x.size
+        return raw_sum(x, 1.0 / x.size),
+
+    def backward(self, indexes, gys):
+        like = DeviceArray(self._shape, np.float32)
+        ones = _ew(_lib.EW_FILL, None, out=like, alpha=1.0 / self._n)
+        return _ew(_lib.EW_MUL_SCALAR_DEV, ones, gys[0].data, out=ones, alpha=1.0),
+
+
+class Reshape(FunctionNode):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def forward(self, inputs):
+        self._in_shape = inputs[0].shape
+        return inputs[0].reshape(self.shape),
+
+    def backward(self, indexes, gys):
+        return gys[0].data.reshape(self._in_shape),
+
+
+class ReLU(FunctionNode):
+    def forward(self, inputs):
+        backend.require_device(inputs[0])
+        y = _ew(_lib.EW_RELU, inputs[0])
+        self._y = y
+        return y,
+
+    def backward(self, indexes, gys):
+        return _ew(_lib.EW_RELU_BWD, gys[0].data, self._y),
+
+
+def add(a, b):
+    if np.isscalar(b):
+        raise NotImplementedError('Variable + scalar is not on the hot path')
+    return Add().apply((a, b))[0]
+
+
+def sub(a, b):
+    return Sub().apply((a, b))[0]
+
+
+def mul(a, b):
+    if np.isscalar(b):
+        return MulScalar(b).apply((a,))[0]
+    if np.isscalar(a):
+        return MulScalar(a).apply((b,))[0]
+    return Mul().apply((a, b))[0]
+
+
+def square(a):
+    return Square().apply((a,))[0]
+
+
+def mean(a):
+    return Mean().apply((a,))[0]
+
+
+def reshape(a, shape):
+    return Reshape(shape).apply((a,))[0]
+
+
+def relu(a):
+    return ReLU().apply((a,))[0]
+
+
+# --------------------------------------------------------------------------- #
+# convolution_2d / dilated_convolution_2d with ksize=(K,1)
+# --------------------------------------------------------------------------- #
+def _conv_desc(B, Cin, Tin, Cout, Tout, K, stride, pad, dil, relu):
+    return _lib.Conv1dDesc(B, Cin, Tin, Cout, Tout, K, stride, pad, dil, 1 if relu else 0)
+
+
+class Conv1dFunction(FunctionNode):
+    """y = conv(x, W, b)[..., :out_len] (+ fused ReLU).  x:(B,Cin,T,1), W:(Cout,Cin,K,1).
+    Replaces chainer.functions.convolution_2d / dilated_convolution_2d behind
+    L.Convolution2D / L.DilatedConvolution2D (net.py:12-17,34-43; modules.py:13-22,
+    127-141)."""
+
+    def __init__(self, stride=1, pad=0, dilate=1, out_len=None, relu=False):
+        self.stride, self.pad, self.dil = int(stride), int(pad), int(dilate)
+        self.out_len = out_len
+        self.relu = relu
+
+    def check_type_forward(self, in_vars):
+        x, W = in_vars[0], in_vars[1]
+        type_expect((x.ndim in (3, 4), 'conv: x must be (B,C,T[,1]), got %s' % (x.shape,)),
+                    (W.ndim in (3, 4), 'conv: W must be (Cout,Cin,K[,1])'),
+                    (x.shape[1] == W.shape[1],
+                     'conv: channel mismatch x %s vs W %s' % (x.shape, W.shape)))
+
+    def forward(self, inputs):
+        x, W = inputs[0], inputs[1]
+        b = inputs[2] if len(inputs) > 2 else None
+        backend.require_device(x, W)
+        B, Cin, Tin = x.shape[:3]
+        Cout, _, K = W.shape[:3]
+        nat = (Tin + 2 * self.pad - self.dil * (K - 1) - 1) // self.stride + 1
+        Tout = nat if self.out_len is None else min(self.out_len, nat)
+        self.desc = _conv_desc(B, Cin, Tin, Cout, Tout, K, self.stride, self.pad, self.dil, self.relu)
+        y = DeviceArray((B, Cout, Tout, 1), np.float32)
+        wsb = _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.desc))
+        ws = backend.workspace(wsb)
+        _lib.call('vqvae_conv1d_fwd', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
+                  ws.nbytes, _S())
+        self.retain_inputs((0, 1))
+        self._y = y if self.relu else None
+        self._has_b = b is not None
+        self._x_shape = x.shape
+        return y,
+
+    def backward(self, indexes, gys):
+        x, W = (v.data for v in self.get_retained_inputs())
+        gy = gys[0].data
+        if self.relu:
+            gy = _ew(_lib.EW_RELU_BWD, gy, self._y)
+        wsb = _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.desc))
+        ws = backend.workspace(wsb)
+        gx = None
+        if 0 in indexes:
+            gx = DeviceArray(self._x_shape, np.float32)
+            _lib.call('vqvae_conv1d_bwd_data', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
+                      ws.ptr, ws.nbytes, _S())
+        gW = gb = None
+        if 1 in indexes:
+            gW = DeviceArray(W.shape, np.float32)
+            if self._has_b:
+                gb = DeviceArray((self.desc.Cout,), np.float32)
+            _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.desc), x.ptr, gy.ptr, gW.ptr,
+                      _p(gb), 0, ws.ptr, ws.nbytes, _S())
+        return (gx, gW, gb) if self._has_b else (gx, gW)
+
+
+def convolution_1d(x, W, b=None, stride=1, pad=0, dilate=1, out_len=None, relu=False):
+    args = (x, W) if b is None else (x, W, b)
+    return Conv1dFunction(stride, pad, dilate, out_len, relu).apply(args)[0]
+
+
+# --------------------------------------------------------------------------- #
+# condition assembly = F.resize_images(local) ++ resize_images(EmbedID(ids)) ++ F.concat
+# (net.py:54-63) written straight into the (B, Cl+G, T, 1) tensor
+# --------------------------------------------------------------------------- #
+_resize_cache = {}
+
+
+def resize_tables(H, outH):
+    """Chainer's resize_images sampling along one axis, computed on the host in
+    float64 and cast like Chainer does: v = linspace(0, H-1, outH); v0 =
+    floor(v).clip(0, H-2); v1 = v0+1; weights (v1-v), (v-v0) as float32.  Also
+    the inverse ranges the backward kernel needs."""
+    key = (H, outH)
+    if key in _resize_cache:
+        return _resize_cache[key]
+    if H == 1:
+        v0 = np.zeros(outH, np.int32)
+        v1 = np.zeros(outH, np.int32)
+        w0 = np.zeros(outH, np.float32)
+        w1 = np.ones(outH, np.float32)
+    else:
+        v = np.linspace(0, H - 1, num=outH)
+        v0 = np.floor(v).astype(np.int32).clip(0, H - 2)
+        v1 = v0 + 1
+        w0 = (v1 - v).astype(np.float32)
+        w1 = (v - v0).astype(np.float32)
+    pos = np.arange(H)
+    lo0 = np.searchsorted(v0, pos, 'left').astype(np.int32)
+    hi0 = np.searchsorted(v0, pos, 'right').astype(np.int32)
+    lo1 = np.searchsorted(v1, pos, 'left').astype(np.int32)
+    hi1 = np.searchsorted(v1, pos, 'right').astype(np.int32)
+    if H == 1:           # weight-0 taps contribute nothing
+        lo0[:] = 0
+        hi0[:] = 0
+    tabs = {k: backend.to_device(a) for k, a in
+            dict(v0=v0, v1=v1, w0=w0, w1=w1, lo0=lo0, hi0=hi0, lo1=lo1, hi1=hi1).items()}
+    _resize_cache[key] = tabs
+    return tabs
+
+
+class ConditionAssemble(FunctionNode):
+    def __init__(self, upscale):
+        self.upscale = int(upscale)
+
+    def forward(self, inputs):
+        local, E, ids = inputs
+        backend.require_device(local, E, ids)
+        B, Cl, Tl = local.shape[:3]
+        n_id, G = E.shape
+        T = self.upscale * Tl
+        out = DeviceArray((B, Cl + G, T, 1), np.float32)
+        bs = (Cl + G) * T
+        tb = resize_tables(Tl, T)
+        _lib.call('vqvae_upsample_linear_fwd', local.ptr, B, Cl, Tl, T, tb['v0'].ptr, tb['v1'].ptr,
+                  tb['w0'].ptr, tb['w1'].ptr, out.ptr, bs, _S())
+        _lib.call('vqvae_embed_broadcast_fwd', E.ptr, ids.ptr, B, G, T, out.ptr + Cl * T * 4, bs, _S())
+        self._dims = (B, Cl, Tl, G, T, n_id)
+        self._ids = ids
+        self._local_shape = local.shape
+        return out,
+
+    def backward(self, indexes, gys):
+        B, Cl, Tl, G, T, n_id = self._dims
+        g = gys[0].data
+        bs = (Cl + G) * T
+        tb = resize_tables(Tl, T)
+        gl = DeviceArray(self._local_shape, np.float32)
+        _lib.call('vqvae_upsample_linear_bwd', g.ptr, bs, B, Cl, Tl, T, tb['w0'].ptr, tb['w1'].ptr,
+                  tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr, gl.ptr, _S())
+        gE = DeviceArray((n_id, G), np.float32)
+        ws = backend.workspace(B * G * 4)
+        _lib.call('vqvae_embed_broadcast_bwd', g.ptr + Cl * T * 4, bs, self._ids.ptr, B, G, T, n_id,
+                  gE.ptr, 0, ws.ptr, ws.nbytes, _S())
+        return gl, gE, None
+
+
+def condition_assemble(local, E, ids, upscale):
+    ids = as_variable(ids)
+    ids.requires_grad = False
+    return ConditionAssemble(upscale).apply((local, E, ids))[0]
+
+
+# --------------------------------------------------------------------------- #
+# softmax cross entropy (train.py:95)
+# --------------------------------------------------------------------------- #
+class SoftmaxCrossEntropy(FunctionNode):
+    def check_type_forward(self, in_vars):
+        y, t = in_vars
+        type_expect((y.ndim in (3, 4), 'softmax_cross_entropy: y must be (B,q,T[,1])'),
+                    (t.dtype == np.int32, 'softmax_cross_entropy: t must be int32'),
+                    (y.shape[0] == t.shape[0] and y.shape[2] == t.shape[1],
+                     'softmax_cross_entropy: shape mismatch %s vs %s' % (y.shape, t.shape)))
+
+    def forward(self, inputs):
+        y, t = inputs
+        backend.require_device(y, t)
+        B, q, T = y.shape[:3]
+        lse = DeviceArray((B, T), np.float32)
+        loss = DeviceArray((), np.float32)
+        ws = backend.workspace(4096 * 4)
+        _lib.call('vqvae_softmax_xent_fwd', y.ptr, t.ptr, B, q, T, lse.ptr, loss.ptr, ws.ptr,
+                  ws.nbytes, _S())
+        self._saved = (y, t, lse)
+        return loss,
+
+    def backward(self, indexes, gys):
+        y, t, lse = self._saved
+        B, q, T = y.shape[:3]
+        gy = DeviceArray(y.shape, np.float32)
+        _lib.call('vqvae_softmax_xent_bwd', y.ptr, t.ptr, lse.ptr, gys[0].data.ptr, B, q, T, gy.ptr,
+                  _S())
+        return gy, None
+
+
+def softmax_cross_entropy(y, t):
+    t = as_variable(t)
+    t.requires_grad = False
+    return SoftmaxCrossEntropy().apply((y, t))[0]

@@ -1,0 +1,247 @@
+"""WaveNet decoder -- mirrors the reference's WaveNet/modules.py class for class
+(ResidualBlock modules.py:7-74, ResidualNet 77-110, WaveNet 113-160) with the
+same constructor and call signatures.  The per-block graph of ~10 Chainer
+functions (dilated conv, crop, 1x1 conv, add, split, tanh, sigmoid, mul, two
+1x1 convs, add) is one fused FunctionNode backed by vqvae_resblock_fwd/bwd.
+
+Training path only: the queue-based incremental generation
+(modules.py:58-74, 98-110, 232-255) is out of scope.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, backend, functions as F, links as L
+from .backend import DeviceArray
+from .core import Chain, ChainList, FunctionNode, type_expect
+
+_S = backend.stream
+
+
+def _p(a):
+    return None if a is None else a.ptr
+
+
+def _rb_desc(x, cond, Wd, Ws, dilation):
+    B, Cr, T = x.shape[:3]
+    Cd, _, K = Wd.shape[:3]
+    return _lib.ResblockDesc(B, T, Cr, Cd, Ws.shape[0], cond.shape[1], K, dilation)
+
+
+def _rb_workspace(desc):
+    return backend.workspace(_lib.load().vqvae_resblock_workspace_bytes(C.byref(desc)))
+
+
+class ResidualBlockFunction(FunctionNode):
+    """(x, condition, Wd, bd, Wc, bc, Wr, br, Ws, bs) -> (residual, skip);
+    modules.py:30-56 with dropout_zero_rate == 0."""
+
+    def __init__(self, dilation):
+        self.dilation = int(dilation)
+
+    def check_type_forward(self, v):
+        x, c = v[0], v[1]
+        type_expect((x.ndim == 4 and c.ndim == 4, 'ResidualBlock: x, condition must be (B,C,T,1)'),
+                    (x.shape[2] == c.shape[2] and x.shape[0] == c.shape[0],
+                     'ResidualBlock: x %s and condition %s disagree' % (x.shape, c.shape)),
+                    (v[2].shape[1] == x.shape[1], 'ResidualBlock: conv in-channels mismatch'),
+                    (v[4].shape[1] == c.shape[1], 'ResidualBlock: condition_dim mismatch'))
+
+    def forward(self, inputs):
+        backend.require_device(*inputs)
+        x, cond, Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs
+        d = _rb_desc(x, cond, Wd, Ws, self.dilation)
+        self.desc = d
+        prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+        res = DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
+        skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
+        self.gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
+        self.z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
+        ws = _rb_workspace(d)
+        _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), x.ptr, cond.ptr, res.ptr, skip.ptr,
+                  0, self.gates.ptr, self.z.ptr, ws.ptr, ws.nbytes, _S())
+        self.retain_inputs(tuple(range(10)))
+        return res, skip
+
+    def backward(self, indexes, gys):
+        ins = [v.data for v in self.get_retained_inputs()]
+        x, cond, Wd, bd, Wc, bc, Wr, br, Ws, bs = ins
+        d = self.desc
+        g_res = None if gys[0] is None else gys[0].data
+        g_skip = None if gys[1] is None else gys[1].data
+        if g_skip is None:                      # skip unused: treat as zeros
+            g_skip = backend.zeros((d.B, d.Cs, d.T, 1))
+        prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+        gx = DeviceArray(x.shape, np.float32) if 0 in indexes else None
+        gc = DeviceArray(cond.shape, np.float32) if 1 in indexes else None
+        gp = [DeviceArray(a.shape, np.float32) for a in ins[2:]]
+        if g_res is None:                       # residual output unused (last block)
+            gp[4] = gp[5] = None
+        grd = _lib.ResblockGrads(*[_p(a) for a in gp])
+        ws = _rb_workspace(d)
+        _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), x.ptr, cond.ptr, self.gates.ptr,
+                  self.z.ptr, _p(g_res), g_skip.ptr, _p(gx), _p(gc), 0, C.byref(grd), 0, ws.ptr,
+                  ws.nbytes, _S())
+        return tuple([gx, gc] + gp)
+
+
+class ResidualStackFunction(FunctionNode):
+    """All blocks of a ResidualNet in one node (modules.py:89-96): the skip sum is
+    accumulated in place by each block's epilogue instead of 19 extra full-tensor
+    adds, the last block skips its unused residual branch, and the condition
+    gradient accumulates in place across blocks.
+    inputs: (x, condition, then 8 params per block) -> skip_connections."""
+
+    def __init__(self, dilations):
+        self.dilations = [int(d) for d in dilations]
+
+    def forward(self, inputs):
+        backend.require_device(*inputs)
+        x, cond = inputs[0], inputs[1]
+        nb = len(self.dilations)
+        assert len(inputs) == 2 + 8 * nb
+        self.descs, self.saved = [], []
+        skip = None
+        h = x
+        for i, dil in enumerate(self.dilations):
+            Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs[2 + 8 * i: 10 + 8 * i]
+            d = _rb_desc(h, cond, Wd, Ws, dil)
+            prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+            last = (i == nb - 1)
+            res = None if last else DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
+            if skip is None:
+                skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
+            gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
+            z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
+            ws = _rb_workspace(d)
+            _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, _p(res),
+                      skip.ptr, 0 if i == 0 else 1, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
+            self.descs.append(d)
+            self.saved.append((h, gates, z))
+            h = res
+        self.retain_inputs(tuple(range(len(inputs))))
+        return skip,
+
+    def backward(self, indexes, gys):
+        ins = [v.data for v in self.get_retained_inputs()]
+        cond = ins[1]
+        g_skip = gys[0].data
+        nb = len(self.dilations)
+        gcond = DeviceArray(cond.shape, np.float32) if 1 in indexes else None
+        grads = [None] * len(ins)
+        g_res = None
+        first_gc = True
+        for i in range(nb - 1, -1, -1):
+            Wd, bd, Wc, bc, Wr, br, Ws, bs = ins[2 + 8 * i: 10 + 8 * i]
+            d = self.descs[i]
+            h, gates, z = self.saved[i]
+            prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+            need_gx = (i > 0) or (0 in indexes)
+            gx = DeviceArray(h.shape, np.float32) if need_gx else None
+            gp = [DeviceArray(a.shape, np.float32) for a in (Wd, bd, Wc, bc, Wr, br, Ws, bs)]
+            if g_res is None:
+                gp[4] = gp[5] = None
+            grd = _lib.ResblockGrads(*[_p(a) for a in gp])
+            ws = _rb_workspace(d)
+            _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, gates.ptr,
+                      z.ptr, _p(g_res), g_skip.ptr, _p(gx), _p(gcond), 0 if first_gc else 1,
+                      C.byref(grd), 0, ws.ptr, ws.nbytes, _S())
+            first_gc = False
+            grads[2 + 8 * i: 10 + 8 * i] = gp
+            g_res = gx
+            self.saved[i] = None            # free activations as we go
+        grads[0] = g_res if 0 in indexes else None
+        grads[1] = gcond
+        return tuple(grads)
+
+
+class ResidualBlock(Chain):
+    """modules.py:7-56."""
+
+    def __init__(self, filter_size, dilation, residual_channels, dilated_channels, skip_channels,
+                 condition_dim, dropout_zero_rate):
+        super(ResidualBlock, self).__init__()
+        with self.init_scope():
+            self.conv = L.DilatedConvolution2D(
+                residual_channels, dilated_channels, ksize=(filter_size, 1),
+                pad=(dilation * (filter_size - 1), 0), dilate=(dilation, 1))
+            self.condition_proj = L.Convolution2D(condition_dim, dilated_channels, 1)
+            self.res = L.Convolution2D(dilated_channels // 2, residual_channels, 1)
+            self.skip = L.Convolution2D(dilated_channels // 2, skip_channels, 1)
+        self.filter_size = filter_size
+        self.dilation = dilation
+        self.residual_channels = residual_channels
+        self.condition_dim = condition_dim
+        self.dropout_zero_rate = dropout_zero_rate
+        if dropout_zero_rate:
+            raise NotImplementedError(
+                'dropout_zero_rate > 0 (modules.py:34-35) is outside the hot-path scope: '
+                'every BASELINE config trains with 0 (params.py:42)')
+
+    def param_list(self):
+        return [self.conv.W, self.conv.b, self.condition_proj.W, self.condition_proj.b,
+                self.res.W, self.res.b, self.skip.W, self.skip.b]
+
+    def __call__(self, x, condition):
+        residual, skip_connection = ResidualBlockFunction(self.dilation).apply(
+            [x, condition] + self.param_list())
+        return residual, skip_connection
+
+
+class ResidualNet(ChainList):
+    """modules.py:77-96."""
+
+    def __init__(self, n_loop, n_layer, filter_size, residual_channels, dilated_channels,
+                 skip_channels, condition_dim, dropout_zero_rate):
+        super(ResidualNet, self).__init__()
+        dilations = [2 ** i for i in range(n_layer)] * n_loop
+        for dilation in dilations:
+            self.add_link(ResidualBlock(
+                filter_size, dilation, residual_channels, dilated_channels, skip_channels,
+                condition_dim, dropout_zero_rate))
+
+    def __call__(self, x, condition):
+        blocks = list(self.children())
+        args = [x, condition]
+        for b in blocks:
+            args += b.param_list()
+        return ResidualStackFunction([b.dilation for b in blocks]).apply(args)[0]
+
+
+class WaveNet(Chain):
+    """modules.py:113-160."""
+
+    def __init__(self, n_loop, n_layer, filter_size, input_dim, residual_channels,
+                 dilated_channels, skip_channels,
+                 # arguments for output
+                 quantize, use_logistic, n_mixture, log_scale_min,
+                 # arguments for conditioning
+                 condition_dim,
+                 # arguments for dropout
+                 dropout_zero_rate):
+        super(WaveNet, self).__init__()
+        with self.init_scope():
+            self.embed = L.Convolution2D(input_dim, residual_channels, (2, 1), pad=(1, 0))
+            self.resnet = ResidualNet(
+                n_loop, n_layer, filter_size, residual_channels, dilated_channels, skip_channels,
+                condition_dim, dropout_zero_rate)
+            self.proj1 = L.Convolution2D(skip_channels, skip_channels, 1)
+            output_dim = n_mixture if use_logistic else quantize
+            self.proj2 = L.Convolution2D(skip_channels, output_dim, 1)
+        self.input_dim = input_dim
+        self.quantize = quantize
+        self.skip_channels = skip_channels
+        self.log_scale_min = log_scale_min
+
+    def __call__(self, x, condition, generating=False):
+        if generating:
+            raise NotImplementedError('incremental generation is out of the hot-path scope')
+        length = x.shape[2]
+        # causal conv: pad 1 then crop to `length` (modules.py:151-152), fused as out_len
+        x = self.embed(x, out_len=length)
+        # residual & skip connections (modules.py:155)
+        z = F.relu(self.resnet(x, condition))
+        # output (modules.py:158-159); the ReLU after proj1 is fused into its epilogue
+        z = self.proj1(z, relu=True)
+        y = self.proj2(z)
+        return y

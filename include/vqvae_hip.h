@@ -1,0 +1,242 @@
+/*
+ * vqvae_hip.h -- C ABI of libvqvae_hip.so: the MI355X (gfx950) drop-in for the
+ * arithmetic of dhgrs/chainer-VQ-VAE's training hot path.
+ *
+ * The reference has no FFI of its own: it is pure Python and every multiply-add
+ * runs inside Chainer 4.0.0b3 -> NumPy / CuPy+cuDNN.  The entry points below are
+ * therefore what a Chainer-shaped `FunctionNode.forward/backward` for this path
+ * binds (ctypes).  Each entry cites the reference call site
+ * it replaces (file:line under the reference repo).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every pointer is a raw DEVICE pointer unless
+ *    marked "host"; the library never allocates or frees caller tensors.
+ *  - tensors are fp32, Chainer NCHW with W==1, i.e. (B, C, T[,1]) with T
+ *    contiguous (net.py:12, modules.py:13-16, utils.py:85-110); labels int32.
+ *  - every call is asynchronous on the given stream (hipStream_t as void*),
+ *    re-entrant, and returns 0 on success, a positive hipError_t, or a negative
+ *    VQVAE_E_* code; vqvae_last_error_string() describes the last failure of the
+ *    calling thread.
+ *  - scratch memory is passed in by the caller (ws, ws_bytes); the matching
+ *    *_workspace_bytes() query gives the required size.
+ */
+#ifndef VQVAE_HIP_H_
+#define VQVAE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQVAE_E_INVALID   (-1)   /* bad argument (shape/alignment/null)            */
+#define VQVAE_E_WORKSPACE (-2)   /* workspace too small                            */
+#define VQVAE_E_NOLIB     (-3)   /* librccl could not be loaded                    */
+#define VQVAE_E_COMM      (-4)   /* RCCL returned an error                         */
+
+typedef void* vqvae_stream_t;
+
+const char* vqvae_last_error_string(void);
+int vqvae_abi_version(void);
+
+/* ---- device / memory / stream plumbing (replaces CuPy's allocator + streams,
+ *      reached in the reference through model.to_gpu()/converter, updaters.py:8) */
+int vqvae_device_count(int* n);
+int vqvae_set_device(int dev);
+int vqvae_device_info(char* name, int name_cap, int* n_cu, size_t* total_mem);
+int vqvae_malloc(void** p, size_t bytes);
+int vqvae_free(void* p);
+int vqvae_memcpy_h2d(void* dst, const void* host_src, size_t bytes, vqvae_stream_t s);
+int vqvae_memcpy_d2h(void* host_dst, const void* src, size_t bytes, vqvae_stream_t s);
+int vqvae_memcpy_d2d(void* dst, const void* src, size_t bytes, vqvae_stream_t s);
+int vqvae_memset(void* p, int byte_value, size_t bytes, vqvae_stream_t s);
+int vqvae_stream_create(vqvae_stream_t* s);
+int vqvae_stream_destroy(vqvae_stream_t s);
+int vqvae_stream_synchronize(vqvae_stream_t s);
+int vqvae_device_synchronize(void);
+int vqvae_event_create(void** ev);
+int vqvae_event_destroy(void* ev);
+int vqvae_event_record(void* ev, vqvae_stream_t s);
+int vqvae_event_synchronize(void* ev);
+int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
+
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline).
+ *      tag = one of VQVAE_PROF_*; enable, run, then read (synchronises). */
+#define VQVAE_PROF_NONE            0
+#define VQVAE_PROF_RESBLOCK_GATE   1   /* dilated conv + cond proj + gate (fwd)       */
+#define VQVAE_PROF_RESBLOCK_OUT    2   /* res/skip 1x1 (fwd)                          */
+#define VQVAE_PROF_RESBLOCK_BWD_GZ 3   /* bwd: gz + gate derivative                   */
+#define VQVAE_PROF_RESBLOCK_BWD_GX 4   /* bwd-data of the dilated conv                */
+#define VQVAE_PROF_RESBLOCK_BWD_GC 5   /* bwd-data of the condition projection        */
+#define VQVAE_PROF_RESBLOCK_WGRAD  6   /* bwd-weight kernels of the block             */
+#define VQVAE_PROF_CONV_FWD        7
+#define VQVAE_PROF_CONV_BWD_DATA   8
+#define VQVAE_PROF_CONV_WGRAD      9
+#define VQVAE_PROF_VQ_NEAREST     10
+#define VQVAE_PROF_NTAGS          16
+int vqvae_prof_enable(int on);
+int vqvae_prof_reset(void);
+int vqvae_prof_read(int tag, double* total_ms, int* launches);
+
+/* ---- generic 1-D convolution == chainer L.Convolution2D / L.DilatedConvolution2D
+ *      with ksize=(K,1), stride=(s,1), pad=(p,0), dilate=(d,1)
+ *      (net.py:12-17 encoder, net.py:34-43 condition embed, modules.py:17-22,
+ *      127-141 1x1 / embed / proj convs).  W is Chainer's (Cout,Cin,K,1), b (Cout).
+ *      Tout may be smaller than the natural output length: the tail is cropped
+ *      (modules.py:41 `h[:, :, :length]`, modules.py:152).                       */
+typedef struct {
+  int B, Cin, Tin, Cout, Tout, K, stride, pad, dil;
+  int relu;                 /* fuse F.relu on the output (net.py:20-24, 49-53)   */
+} vqvae_conv1d_desc;
+
+size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d);
+int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                     const float* b, float* y, void* ws, size_t ws_bytes, vqvae_stream_t s);
+/* gx (B,Cin,Tin) (+)= conv^T(gy) */
+int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const float* gy,
+                          float* gx, int accumulate, void* ws, size_t ws_bytes,
+                          vqvae_stream_t s);
+/* gW (Cout,Cin,K) and gb (Cout) (+)= ...; gb may be NULL */
+int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                            float* gW, float* gb, int accumulate, void* ws,
+                            size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- WaveNet ResidualBlock (WaveNet/modules.py:30-56), dropout_zero_rate == 0:
+ *      h = dilconv(x)[:, :, :T] + condition_proj(c); z = tanh(h_a)*sigmoid(h_b);
+ *      residual = res(z) + x; skip = skip(z).                                    */
+typedef struct {
+  int B, T;
+  int Cr;      /* residual_channels                                              */
+  int Cd;      /* dilated_channels (gate halves Cd/2; Cd/2 % 32 == 0)            */
+  int Cs;      /* skip_channels                                                  */
+  int Cc;      /* condition_dim                                                  */
+  int K;       /* filter_size                                                    */
+  int dil;     /* dilation                                                       */
+} vqvae_resblock_desc;
+
+typedef struct {            /* parameters, Chainer layouts (modules.py:13-22)     */
+  const float *Wd, *bd;     /* conv            (Cd, Cr, K, 1), (Cd)               */
+  const float *Wc, *bc;     /* condition_proj  (Cd, Cc, 1, 1), (Cd)               */
+  const float *Wr, *br;     /* res             (Cr, Cd/2, 1, 1), (Cr)             */
+  const float *Ws, *bs;     /* skip            (Cs, Cd/2, 1, 1), (Cs)             */
+} vqvae_resblock_params;
+
+typedef struct {            /* gradients, same layouts; any pair may be NULL      */
+  float *gWd, *gbd, *gWc, *gbc, *gWr, *gbr, *gWs, *gbs;
+} vqvae_resblock_grads;
+
+size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d);
+/* res may be NULL (last block: residual unused, modules.py:89-96).  skip is
+ * overwritten, or accumulated into when skip_accumulate != 0 (modules.py:92-95).
+ * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd. */
+int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                       const float* x, const float* cond, float* res, float* skip,
+                       int skip_accumulate, float* gates, float* z, void* ws,
+                       size_t ws_bytes, vqvae_stream_t s);
+/* g_res may be NULL; gx may be NULL; gcond (B,Cc,T) is accumulated into when
+ * gcond_accumulate != 0; parameter grads are accumulated when grads_accumulate. */
+int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                       const float* x, const float* cond, const float* gates,
+                       const float* z, const float* g_res, const float* g_skip,
+                       float* gx, float* gcond, int gcond_accumulate,
+                       const vqvae_resblock_grads* g, int grads_accumulate, void* ws,
+                       size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- vector quantiser: StraightThrough.forward / backward (utils.py:176-231).
+ *      z (B,d,T) [T contiguous], W (k,d).  idx (B,T) int32 is bit-exact with
+ *      numpy.argmin(numpy.sum((xs-W)**2, axis=2), axis=1): first minimum wins,
+ *      distances evaluated in the reference's fp32 operation order
+ *      (sequential over d, sub/mul/add individually rounded).
+ *      mode 0: MFMA pairwise distances + wavefront argmin + exact re-check of every
+ *      row whose runner-up is inside the rounding band; mode 1: exact evaluation
+ *      of all k codes for every row (test cross-check).  e (B,d,T) = W[idx] may be
+ *      NULL.  n_rechecked (device int32, may be NULL) receives the number of rows
+ *      that took the exact re-check path.                                        */
+size_t vqvae_vq_workspace_bytes(int B, int d, int T, int k);
+int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d, int T, int k,
+                         int mode, int32_t* idx, float* e, int32_t* n_rechecked,
+                         void* ws, size_t ws_bytes, vqvae_stream_t s);
+/* gW (k,d) (+)= onehot(idx)^T . gy, accumulated in float64 then rounded
+ * (utils.py:227-228).  gy (B,d,T).                                               */
+int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d, int T, int k,
+                    float* gW, int accumulate, void* ws, size_t ws_bytes,
+                    vqvae_stream_t s);
+
+/* ---- F.resize_images along T, align-corners (net.py:54-55): tables computed by
+ *      the host in float64 exactly as Chainer does (v0/v1 int32[Tout], w0/w1 fp32[Tout]);
+ *      y[b,c,i] = w0[i]*x[b,c,v0[i]] + w1[i]*x[b,c,v1[i]].  y has batch stride
+ *      y_bstride elements (writes a channel slice of the concat, net.py:63).
+ *      bwd uses host tables of contributing output ranges per input position
+ *      (lo0/hi0: outputs with v0==v; lo1/hi1: outputs with v0+1==v).            */
+int vqvae_upsample_linear_fwd(const float* x, int B, int C, int Tin, int Tout,
+                              const int32_t* v0, const int32_t* v1, const float* w0,
+                              const float* w1,
+                              float* y, long y_bstride, vqvae_stream_t s);
+int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, int Tin,
+                              int Tout, const float* w0, const float* w1,
+                              const int32_t* lo0, const int32_t* hi0,
+                              const int32_t* lo1, const int32_t* hi1,
+                              float* gx, vqvae_stream_t s);
+
+/* ---- L.EmbedID + broadcast along T (net.py:57-61): y[b,c,t] = E[id[b],c]      */
+int vqvae_embed_broadcast_fwd(const float* E, const int32_t* ids, int B, int G, int T,
+                              float* y, long y_bstride, vqvae_stream_t s);
+/* gE (n_id,G) (+)= scatter of sum_t gy[b,c,t]; ws >= B*G floats                  */
+int vqvae_embed_broadcast_bwd(const float* gy, long gy_bstride, const int32_t* ids,
+                              int B, int G, int T, int n_id, float* gE, int accumulate,
+                              void* ws, size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- chainer.functions.softmax_cross_entropy (train.py:95, net.py:89):
+ *      y (B,q,T), t (B,T) int32; loss = -mean_{b,t} log softmax(y)[t].
+ *      fwd writes lse (B,T) and the scalar loss; bwd writes
+ *      gy = (softmax - onehot) * (*gloss) / (B*T)   (gloss: device scalar or NULL=1) */
+size_t vqvae_softmax_xent_workspace_bytes(int B, int q, int T);
+int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T,
+                           float* lse, float* loss, void* ws, size_t ws_bytes,
+                           vqvae_stream_t s);
+int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse,
+                           const float* gloss, int B, int q, int T, float* gy,
+                           vqvae_stream_t s);
+
+/* ---- element-wise helpers behind Variable arithmetic (net.py:90-92) and F.relu */
+#define VQVAE_EW_ADD       0   /* out = a + b                  */
+#define VQVAE_EW_SUB       1   /* out = a - b                  */
+#define VQVAE_EW_MUL       2   /* out = a * b                  */
+#define VQVAE_EW_AXPBY     3   /* out = alpha*a + beta*b       */
+#define VQVAE_EW_SCALE     4   /* out = alpha*a                */
+#define VQVAE_EW_SQUARE    5   /* out = a*a                    */
+#define VQVAE_EW_RELU      6   /* out = max(a,0)               */
+#define VQVAE_EW_RELU_BWD  7   /* out = a * (b > 0)   (a=gy,b=y) */
+#define VQVAE_EW_FILL      8   /* out = alpha                  */
+#define VQVAE_EW_MUL_SCALAR_DEV 9 /* out = a * b[0] * alpha    */
+int vqvae_elementwise(int op, size_t n, const float* a, const float* b, float* out,
+                      float alpha, float beta, vqvae_stream_t s);
+/* out[0] = scale * sum(x[0..n)) (deterministic two-stage); ws >= 4096 floats     */
+int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws,
+              size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- chainer.optimizers.Adam update rule (train.py:101-102) over a flat arena:
+ *      m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m/(sqrt(v)+eps)
+ *      with lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the host in double;
+ *      scalars are rounded to fp32 exactly where NumPy would (weak Python scalars). */
+int vqvae_adam_step(float* p, const float* g, float* m, float* v, size_t n,
+                    double lr_t, double beta1, double beta2, double eps, vqvae_stream_t s);
+/* ExponentialMovingAverage (utils.py:151-155): ema = decay*target + (1-decay)*ema */
+int vqvae_ema_step(float* ema, const float* target, size_t n, double decay,
+                   vqvae_stream_t s);
+
+/* ---- data-parallel gradient exchange: replaces Link.addgrads (sum to main,
+ *      updaters.py:71-72) + Link.copyparams (updaters.py:76-77) by one RCCL
+ *      all-reduce(sum) of the flat gradient arena on every rank.                */
+#define VQVAE_COMM_ID_BYTES 128
+int vqvae_comm_unique_id(char id[VQVAE_COMM_ID_BYTES]);          /* host buffer     */
+int vqvae_comm_init(void** comm, int nranks, int rank, const char id[VQVAE_COMM_ID_BYTES]);
+int vqvae_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, vqvae_stream_t s);
+int vqvae_comm_allreduce_max_f32(void* comm, float* buf, size_t n, vqvae_stream_t s);
+int vqvae_comm_destroy(void* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQVAE_HIP_H_ */

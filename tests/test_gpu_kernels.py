@@ -1,0 +1,312 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the NumPy
+oracle on the same seeded inputs.  Tolerance: 1e-4 fp32 (north_star) for
+float outputs, bit-exact for indices."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import vqvae_oracle as O
+from helpers import assert_close, assert_close_scaled, to4
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _dev(gpu, a):
+    return gpu.to_device(np.ascontiguousarray(a))
+
+
+CONV_CASES = [
+    # B, Cin, Tin, Cout, K, stride, pad, dil, crop
+    (2, 1, 513, 32, 4, 2, 1, 1, None),       # encoder conv1 (net.py:12)
+    (2, 32, 256, 32, 4, 2, 1, 1, None),      # encoder conv2..6
+    (3, 64, 120, 64, 3, 1, 4, 4, None),      # condition embed, "same" dilated (net.py:38-39)
+    (2, 64, 120, 64, 3, 1, 16, 16, None),
+    (2, 96, 300, 80, 2, 1, 8, 8, 300),       # causal dilated + crop (modules.py:13-16,41)
+    (2, 256, 384, 64, 2, 1, 1, 1, 384),      # embed conv (modules.py:127-128,152)
+    (2, 48, 200, 30, 1, 1, 0, 1, None),      # 1x1, ragged channels (proj2 -> 30)
+    (1, 192, 130, 256, 1, 1, 0, 1, None),    # condition_proj
+    (2, 40, 77, 50, 3, 2, 2, 3, None),       # everything odd
+    (1, 16, 7, 20, 4, 2, 1, 1, None),        # tiny T
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv1d_fwd_bwd(gpu, case, relu):
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Tin, Cout, K, stride, pad, dil, crop = case
+    rs = np.random.RandomState(hash(case) % 2**31)
+    x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    y_ref = O.conv1d_fwd(x, W, b, stride, pad, dil)
+    if crop is not None:
+        y_ref = y_ref[:, :, :crop]
+    if relu:
+        y_ref = O.relu(y_ref)
+    gy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    gyr = gy * (y_ref > 0) if relu else gy
+    if crop is not None:
+        nat = O.conv_out_len(Tin, K, stride, pad, dil)
+        gfull = np.zeros((B, Cout, nat), np.float32)
+        gfull[:, :, :crop] = gyr
+    else:
+        gfull = gyr
+    gx_ref, gW_ref, gb_ref = O.conv1d_bwd(x, W, gfull, stride, pad, dil)
+
+    vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+    y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil, out_len=crop, relu=relu)
+    assert y.shape == y_ref.shape + (1,)
+    assert_close(y.data.get(), y_ref, 1e-4, 'y')
+    y.grad = _dev(gpu, to4(gy))
+    y.backward()
+    assert_close_scaled(vx.grad.get(), gx_ref, 1e-4, 'gx')
+    assert_close_scaled(vW.grad.get(), gW_ref, 1e-4, 'gW')
+    assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'gb')
+
+
+def test_conv_impulse_tap_order(gpu):
+    """Known-answer: an impulse reads the taps back; pins W[...,0] <-> x[t-dil]
+    and the zero fill for t < dil (modules.py:16, 41)."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    T, dil = 64, 4
+    x = np.zeros((1, 1, T), np.float32)
+    x[0, 0, 10] = 1.0
+    W = np.array([[[2.0, 3.0]]], np.float32)       # (1,1,2): tap0 = 2, tap1 = 3
+    y = F.convolution_1d(Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), None,
+                         pad=dil, dilate=dil, out_len=T).data.get().reshape(T)
+    want = np.zeros(T, np.float32)
+    want[10] = 3.0           # tap1 multiplies x[t]
+    want[10 + dil] = 2.0     # tap0 multiplies x[t - dil]
+    np.testing.assert_array_equal(y, want)
+
+
+RB_CASES = [
+    # B, T, Cr, Cd, Cs, Cc, K, dil
+    (2, 256, 64, 64, 64, 48, 2, 1),
+    (2, 256, 64, 64, 32, 48, 2, 2),
+    (1, 300, 96, 128, 80, 40, 2, 8),        # ragged T, mixed channels
+    (2, 384, 256, 256, 256, 192, 2, 512),   # real channel counts, dilation > T
+    (1, 200, 64, 64, 64, 16, 3, 4),         # filter_size 3
+]
+
+
+def _rb_params(rs, Cr, Cd, Cs, Cc, K):
+    def conv(co, ci, k):
+        return ((rs.standard_normal((co, ci, k)) / np.sqrt(ci * k)).astype(np.float32),
+                (0.1 * rs.standard_normal(co)).astype(np.float32))
+    return {'conv': conv(Cd, Cr, K), 'condition_proj': conv(Cd, Cc, 1),
+            'res': conv(Cr, Cd // 2, 1), 'skip': conv(Cs, Cd // 2, 1)}
+
+
+@pytest.mark.parametrize('case', RB_CASES)
+def test_resblock_fwd_bwd(gpu, case):
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualBlockFunction
+    B, T, Cr, Cd, Cs, Cc, K, dil = case
+    rs = np.random.RandomState(sum(case))
+    p = _rb_params(rs, Cr, Cd, Cs, Cc, K)
+    x = rs.standard_normal((B, Cr, T)).astype(np.float32)
+    c = rs.standard_normal((B, Cc, T)).astype(np.float32)
+    res_ref, skip_ref, cache = O.resblock_fwd(p, x, c, dil)
+    g_res = rs.standard_normal(res_ref.shape).astype(np.float32)
+    g_skip = rs.standard_normal(skip_ref.shape).astype(np.float32)
+    gx_ref, gc_ref, gr = O.resblock_bwd(p, cache, c, dil, g_res, g_skip)
+
+    order = ['conv', 'condition_proj', 'res', 'skip']
+    vs = [Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(c)))]
+    for n in order:
+        vs.append(Variable(_dev(gpu, to4(p[n][0]))))
+        vs.append(Variable(_dev(gpu, p[n][1])))
+    res, skip = ResidualBlockFunction(dil).apply(vs)
+    assert_close(res.data.get(), res_ref, 1e-4, 'res')
+    assert_close(skip.data.get(), skip_ref, 1e-4, 'skip')
+    # backward through both outputs: seed grads by hand
+    from vqvae_amd import functions as F
+    loss_like = None
+    fn = res.creator
+    gouts = fn.backward(tuple(range(10)), (Variable(_dev(gpu, to4(g_res))), Variable(_dev(gpu, to4(g_skip)))))
+    assert_close_scaled(gouts[0].get(), gx_ref, 1e-4, 'gx')
+    assert_close_scaled(gouts[1].get(), gc_ref, 1e-4, 'gcond')
+    for i, n in enumerate(order):
+        assert_close_scaled(gouts[2 + 2 * i].get(), gr[n][0], 1e-4, 'gW ' + n)
+        assert_close_scaled(gouts[3 + 2 * i].get(), gr[n][1], 1e-4, 'gb ' + n)
+    # last-block form: residual output unused
+    gouts = fn.backward(tuple(range(10)), (None, Variable(_dev(gpu, to4(g_skip)))))
+    gx2, gc2, gr2 = O.resblock_bwd(p, cache, c, dil, None, g_skip)
+    assert_close_scaled(gouts[0].get(), gx2, 1e-4, 'gx (no g_res)')
+    assert gouts[6] is None and gouts[7] is None
+    assert_close_scaled(gouts[8].get(), gr2['skip'][0], 1e-4, 'gWs (no g_res)')
+
+
+# ---------------------------------------------------------------------------
+# vector quantiser: golden vectors from the reference's own code, both modes
+# ---------------------------------------------------------------------------
+def _run_vq(gpu, z, W, gy, mode):
+    from vqvae_amd.core import Variable
+    from vqvae_amd.utils import StraightThrough
+    st = StraightThrough()
+    st.mode = mode
+    vz, vW = Variable(_dev(gpu, z)), Variable(_dev(gpu, W))
+    (e,) = st.apply((vz, vW))
+    idx = st.indexes.get()
+    gx, gW = st.backward((0, 1), (Variable(_dev(gpu, gy)),))
+    return e.data.get(), idx, gx, gW.data.get(), int(st.n_rechecked.get()[0])
+
+
+@pytest.mark.parametrize('name', ['vq_train', 'vq_3d', 'vq_ties'])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_vq_golden(gpu, name, mode):
+    g = np.load(os.path.join(GOLD, name + '.npz'))
+    e, idx, gx, gW, nre = _run_vq(gpu, g['z'], g['W'], g['gy'], mode)
+    np.testing.assert_array_equal(idx, g['idx'])          # bit-exact indices
+    np.testing.assert_array_equal(e, g['e'])              # gather is exact
+    np.testing.assert_array_equal(gW, g['gW'])            # fp64-accumulated, rounded once
+    if name == 'vq_ties' and mode == 0:
+        assert nre > 0                                    # ties must take the exact path
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_vq_golden_stress(gpu, mode):
+    from golden.make_golden import stress_inputs
+    g = np.load(os.path.join(GOLD, 'vq_stress.npz'))
+    B, d, T, k = [int(v) for v in g['shape']]
+    z, W = stress_inputs(int(g['seed_z']), int(g['seed_w']), B, d, T, k)
+    gy = np.random.RandomState(int(g['seed_gy'])).standard_normal((B, d, T, 1)).astype(np.float32)
+    e, idx, gx, gW, nre = _run_vq(gpu, z, W, gy, mode)
+    np.testing.assert_array_equal(idx, g['idx'])
+    assert abs(e.astype(np.float64).sum() - float(g['e_sum'])) < 1e-6 * max(1, abs(float(g['e_sum'])))
+    np.testing.assert_array_equal(gW[g['gW_rows']], g['gW_vals'])
+    rest = np.ones(k, bool)
+    rest[g['gW_rows']] = False
+    assert not gW[rest].any()
+
+
+def test_vq_mfma_vs_exact_large(gpu):
+    """Size-independent property at the C4 scale the oracle cannot reach in
+    seconds: the MFMA + re-check path must equal the all-exact path row for row."""
+    from golden.make_golden import stress_inputs
+    B, d, T, k = 64, 128, 120, 8192
+    z, W = stress_inputs(5, 6, B, d, T, k)
+    gy = np.zeros((B, d, T, 1), np.float32)
+    _, idx0, _, _, nre = _run_vq(gpu, z, W, gy, 0)
+    _, idx1, _, _, _ = _run_vq(gpu, z, W, gy, 1)
+    np.testing.assert_array_equal(idx0, idx1)
+    assert 0 < nre < 0.2 * B * T
+    # spot-check 128 rows against the reference-order NumPy restatement
+    _, idx_ref = O.vq_forward_chunked(z[:1], W, 1)
+    np.testing.assert_array_equal(idx0[:1], idx_ref)
+
+
+def test_vq_type_check(gpu):
+    from vqvae_amd.core import InvalidType, Variable
+    from vqvae_amd.utils import StraightThrough
+    z = _dev(gpu, np.zeros((2, 8, 5, 1), np.float32))
+    W = _dev(gpu, np.zeros((4, 7), np.float32))
+    with pytest.raises(InvalidType):
+        StraightThrough().apply((Variable(z), Variable(W)))
+    with pytest.raises(ValueError):       # the numpy/device mix guard, utils.py:183-186
+        StraightThrough().apply((Variable(z), Variable(np.zeros((4, 8), np.float32))))
+
+
+# ---------------------------------------------------------------------------
+# condition assembly, losses, optimiser
+# ---------------------------------------------------------------------------
+def test_condition_assemble(gpu):
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(3)
+    B, Cl, Tl, G, n_id, up = 3, 24, 15, 10, 6, 64
+    loc = rs.standard_normal((B, Cl, Tl)).astype(np.float32)
+    E = rs.standard_normal((n_id, G)).astype(np.float32)
+    ids = np.array([4, 1, 4], np.int32)
+    T = up * Tl
+    up_ref = O.upsample_fwd(loc, T)
+    cond_ref = np.concatenate([up_ref, np.broadcast_to(E[ids][:, :, None], (B, G, T))], 1)
+    vl, vE = Variable(_dev(gpu, to4(loc))), Variable(_dev(gpu, E))
+    cond = F.condition_assemble(vl, vE, _dev(gpu, ids), up)
+    np.testing.assert_array_equal(cond.data.get().reshape(cond_ref.shape), cond_ref)
+    g = rs.standard_normal(cond_ref.shape).astype(np.float32)
+    cond.grad = _dev(gpu, to4(g))
+    cond.backward()
+    gl_ref = O.upsample_bwd(np.ascontiguousarray(g[:, :Cl]), Tl)
+    gE_ref = np.zeros_like(E)
+    np.add.at(gE_ref, ids, g[:, Cl:].sum(axis=2))
+    assert_close_scaled(vl.grad.get(), gl_ref, 1e-5, 'g local')
+    assert_close_scaled(vE.grad.get(), gE_ref, 1e-5, 'g embed')
+
+
+def test_upsample_constant_known_answer(gpu):
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    loc = np.full((1, 2, 9), 3.5, np.float32)
+    E = np.zeros((1, 1), np.float32)
+    cond = F.condition_assemble(Variable(_dev(gpu, to4(loc))), Variable(_dev(gpu, E)),
+                                _dev(gpu, np.zeros(1, np.int32)), 64).data.get()
+    np.testing.assert_allclose(cond[0, :2], 3.5, rtol=1e-6)
+
+
+def test_softmax_xent(gpu):
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(5)
+    B, q, T = 2, 256, 300
+    y = (3 * rs.standard_normal((B, q, T))).astype(np.float32)
+    t = rs.randint(0, q, (B, T)).astype(np.int32)
+    loss_ref, logp = O.softmax_xent_fwd(y, t)
+    gy_ref = O.softmax_xent_bwd(logp, t)
+    vy = Variable(_dev(gpu, to4(y)))
+    loss = F.softmax_cross_entropy(vy, _dev(gpu, to4(t).reshape(B, T, 1)))
+    assert_close(loss.data.get(), loss_ref, 1e-5, 'loss')
+    loss.backward()
+    assert_close_scaled(vy.grad.get(), gy_ref, 1e-4, 'gy')
+    # known answer: uniform logits -> ln q (loss1.png starts at ~5.5 = ln 256)
+    vy = Variable(_dev(gpu, np.zeros((B, q, T, 1), np.float32)))
+    loss = F.softmax_cross_entropy(vy, _dev(gpu, t.reshape(B, T, 1)))
+    assert abs(float(loss.data.get()) - np.log(256.0)) < 1e-5
+
+
+def test_adam_and_ema_bitexact(gpu):
+    import vqvae_amd._lib as L
+    rs = np.random.RandomState(9)
+    n = 100003
+    p = rs.standard_normal(n).astype(np.float32)
+    g = rs.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dg, dm, dv = [_dev(gpu, a) for a in (p, g, m, v)]
+    for t in range(1, 4):
+        O.adam_update(p, g, m, v, t, 2e-4)
+        fix1, fix2 = 1 - 0.9 ** t, 1 - 0.999 ** t
+        L.call('vqvae_adam_step', dp.ptr, dg.ptr, dm.ptr, dv.ptr, n, 2e-4 * np.sqrt(fix2) / fix1,
+               0.9, 0.999, 1e-8, gpu.stream())
+    np.testing.assert_array_equal(dm.get(), m)
+    np.testing.assert_array_equal(dv.get(), v)
+    assert_close(dp.get(), p, 1e-7, 'adam p')
+    # closed form of the first step from zero state: dp = -alpha * g / (|g| + eps/sqrt(1-b2))
+    e = rs.standard_normal(n).astype(np.float32)
+    tt = rs.standard_normal(n).astype(np.float32)
+    de, dt = _dev(gpu, e), _dev(gpu, tt)
+    O.ema_update(e, tt, 0.9999)
+    L.call('vqvae_ema_step', de.ptr, dt.ptr, n, 0.9999, gpu.stream())
+    np.testing.assert_array_equal(de.get(), e)
+
+
+def test_variable_arithmetic(gpu):
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(1)
+    a = rs.standard_normal((2, 8, 30, 1)).astype(np.float32)
+    b = rs.standard_normal((2, 8, 30, 1)).astype(np.float32)
+    va, vb = Variable(_dev(gpu, a)), Variable(_dev(gpu, b))
+    loss = 0.25 * F.mean((va - Variable(vb.data)) ** 2)      # net.py:91
+    want = np.float32(0.25) * np.mean((a - b) ** 2, dtype=np.float32)
+    assert_close(loss.data.get(), want, 1e-6, 'loss3 form')
+    loss.backward()
+    assert vb.grad is None
+    assert_close_scaled(va.grad.get(), 0.25 * 2 * (a - b) / a.size, 1e-5, 'grad')
