@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- audio samples/s of the VQ-VAE training hot path on MI355X.
+
+One "step" = one VQVAE updater iteration over one synthetic minibatch: VAE
+forward (encoder -> VQ -> condition embed -> WaveNet -> softmax-CE), the
+three-loss backward of updaters.py:13-19, the EMA blend (utils.py:146-155), the
+RCCL gradient all-reduce when N > 1, and the Adam update.  Nothing is skipped in
+the timed region.  Inputs are resident in HBM before the timed region starts.
+
+Workload (N=1): BASELINE.json configs[1] -- batch 16, length 7680, mu-law q=256,
+d=64, k=512, n_loop=2, n_layer=10, residual=dilated=skip=256, condition 64+128,
+fp32.  N>1: weak scaling, 16 samples per GPU (configs[2]), one process per GPU
+launched by `python -m torch.distributed.run` (only RANK/WORLD_SIZE/MASTER_* are
+used; torch is not imported: it bundles its own HIP runtime).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     -- the dominant kernel (ResidualBlock forward: dilated conv +
+                  condition projection + gate, MFMA fp32), algorithmic FLOPs per
+                  launch / average launch time measured with HIP events on the
+                  launch stream during the timed steps.
+  cpu_baseline -- the NumPy oracle (a port of the Chainer-CPU algorithm) timed on
+                  this box's host cores on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'chainer-vq-vae_amd'))
+
+import numpy as np  # noqa: E402
+
+CFG = dict(d=64, k=512, n_loop=2, n_layer=10, filter_size=2, input_dim=256, quantize=256,
+           residual=256, dilated=256, skip=256, local_dim=64, global_dim=128, n_speaker=109,
+           length=7680, beta=0.25, lr=2e-4, ema_mu=0.9999, batch_per_gpu=16)
+PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def synth_examples(B, cfg, seed):
+    """Preprocess's output contract (utils.py:99-110) on synthetic audio:
+    (raw (1,L+1,1) f32, one_hot[:, :-1] (q,L,1) f32, speaker () i32, quantized[1:] (L,1) i32)."""
+    from vqvae_amd.utils import MuLaw
+    rs = np.random.RandomState(seed)
+    L = cfg['length'] + 1
+    n = np.arange(L) / 16000.0
+    mu = MuLaw(cfg['quantize'])
+    ex = []
+    eye = np.identity(cfg['quantize'], dtype=np.float32)
+    for _ in range(B):
+        f = rs.uniform(80, 4000, 3)
+        ph = rs.uniform(0, 2 * np.pi, 3)
+        a = rs.uniform(0.2, 1.0, 3)
+        raw = sum(a[i] * np.sin(2 * np.pi * f[i] * n + ph[i]) for i in range(3))
+        raw = raw + 0.05 * rs.standard_normal(L)
+        raw = (raw / np.abs(raw).max()).astype(np.float32)
+        q = mu.transform(raw)
+        one_hot = np.expand_dims(eye[q].T, 2)
+        ex.append((raw[None, :, None], one_hot[:, :-1], np.array(rs.randint(0, cfg['n_speaker']), np.int32),
+                   np.expand_dims(q, 1)[1:]))
+    return ex
+
+
+class ResidentIterator(object):
+    """Yields this rank's shard as device-resident arrays (already concatenated):
+    the timed region starts with inputs in HBM."""
+
+    class _Shard(object):
+        def __init__(self, arrays):
+            self.arrays = arrays
+
+        def __getitem__(self, sl):       # batch[rank::n] -- this IS the rank's shard
+            return self
+
+    def __init__(self, shards):
+        self.shards = [self._Shard(s) for s in shards]
+        self.i = 0
+
+    def next(self):
+        s = self.shards[self.i % len(self.shards)]
+        self.i += 1
+        return s
+
+
+def resident_converter(batch, device):
+    return batch.arrays
+
+
+def build(cfg, n_gpus):
+    import vqvae_amd as V
+    from vqvae_amd import functions as F
+    from vqvae_amd.optimizers import Adam
+    V.core.seed_initializers(0)
+    encoder = V.Encoder(cfg['d'])
+    wavenet = V.WaveNet(cfg['n_loop'], cfg['n_layer'], cfg['filter_size'], cfg['input_dim'],
+                        cfg['residual'], cfg['dilated'], cfg['skip'], cfg['quantize'], False, 30,
+                        -40, cfg['local_dim'] + cfg['global_dim'], 0)
+    cond = V.ConditionEmbed(cfg['n_speaker'], cfg['global_dim'], cfg['local_dim'])
+    decoder = V.ExponentialMovingAverage(wavenet, cfg['ema_mu'])       # train.py:87-90
+    model = V.VAE(encoder, decoder, cond, cfg['d'], cfg['k'], cfg['beta'], F.softmax_cross_entropy)
+    return model, Adam(cfg['lr'] / n_gpus)                              # train.py:101
+
+
+def cpu_baseline(cfg):
+    """Times the NumPy oracle (port of the Chainer-CPU algorithm) at the
+    reference's CPU-runnable shape (configs[0]: batch 1, length 7680)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import vqvae_oracle as O
+    rs = np.random.RandomState(0)
+    P = O.make_params(rs, d=cfg['d'], k=cfg['k'], n_loop=cfg['n_loop'], n_layer=cfg['n_layer'],
+                      residual=cfg['residual'], dilated=cfg['dilated'], skip=cfg['skip'],
+                      local_dim=cfg['local_dim'], global_dim=cfg['global_dim'],
+                      n_speaker=cfg['n_speaker'])
+    batch = O.synth_batch(1, length=cfg['length'], n_speaker=cfg['n_speaker'], seed=71)
+    state = {}
+    O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])        # warm-up
+    times = []
+    t_all = time.time()
+    while len(times) < 3 or (time.time() - t_all < 12 and len(times) < 8):
+        t0 = time.time()
+        O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full training steps (fwd + 3-loss bwd + Adam) at batch 1, length %d, '
+                      'median %.2f s/step, NumPy+BLAS threads = all %d visible cores'
+                      % (len(times), cfg['length'], med, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch', type=int, default=CFG['batch_per_gpu'])
+    args = ap.parse_args()
+    cfg = dict(CFG)
+    cfg['batch_per_gpu'] = args.batch
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d '
+                             'bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    n = world
+
+    import vqvae_amd as V
+    from vqvae_amd import _lib, backend
+    from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
+    backend.init(local)
+    comm = RcclCommunicator(rank, n, local) if n > 1 else SingleCommunicator()
+
+    model, opt = build(cfg, n)
+    model.to_gpu(local)
+    opt.setup(model)
+
+    B = cfg['batch_per_gpu']
+    shards = []
+    for s in range(2):                      # two distinct resident minibatches, alternated
+        ex = synth_examples(B, cfg, seed=71 + 1000 * rank + s)
+        shards.append(V.concat_examples(ex, device=local))
+    it = ResidentIterator(shards)
+    upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local)
+
+    for _ in range(args.warmup):
+        upd.update()
+    backend.synchronize()
+
+    tag = _lib.PROF_RESBLOCK_GATE
+    lib = _lib.load()
+    lib.vqvae_prof_reset()
+    lib.vqvae_prof_enable(1 << tag)
+    comm.barrier()
+    backend.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        upd.update()
+    backend.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    lib.vqvae_prof_enable(0)
+    dt = comm.max_scalar(dt)
+
+    import ctypes as C
+    tot = C.c_double(0)
+    cnt = C.c_int(0)
+    _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
+    losses = [float(l.data.get()) for l in upd.last_losses]
+
+    if rank == 0:
+        T = cfg['length']
+        samples = n * B * T * args.steps
+        value = samples / dt
+        # algorithmic FLOPs of one launch of the fused dilated-conv + condition-proj + gate kernel
+        cdim = cfg['local_dim'] + cfg['global_dim']
+        flop = 2.0 * B * T * cfg['dilated'] * (cfg['filter_size'] * cfg['residual'] + cdim)
+        avg_ms = tot.value / max(cnt.value, 1)
+        ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
+        out = {
+            'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
+            'value': value, 'unit': 'samples/s', 'n_gpus': n, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic', 'samples_per_sec_per_gpu': value / n,
+            'config': {'workload': 'BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
+                                   'd=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256, '
+                                   'cond 64+128, EMA 0.9999, Adam lr=2e-4/N' % (1 if n == 1 else 2, B),
+                       'global_batch': n * B, 'length': T,
+                       'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
+            'losses_last_step': losses,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: '
+                         'dilated conv k=2 + condition 1x1 + tanh*sigmoid gate)',
+                         'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
+                         'traffic': None, 'launches': cnt.value, 'avg_launch_ms': avg_ms,
+                         'flop_per_launch': flop},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if n > 1:
+        comm.barrier()
+        comm.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 
 // ---- profiler: pairs of events per tagged launch, read back on demand -------
 struct ProfPair { hipEvent_t a, b; int tag; };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;   // bit t enables tag t
 static std::vector<ProfPair> g_prof_pairs;
 static std::vector<hipEvent_t> g_prof_free;
 static hipEvent_t g_prof_open[VQVAE_PROF_NTAGS];
@@ -35,7 +35,7 @@ static hipEvent_t prof_get_event() {
 }
 
 void prof_begin(int tag, hipStream_t s) {
-  if (!g_prof_on || tag <= 0 || tag >= VQVAE_PROF_NTAGS) return;
+  if (tag <= 0 || tag >= VQVAE_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t e = prof_get_event();
   if (!e) return;
@@ -44,7 +44,7 @@ void prof_begin(int tag, hipStream_t s) {
 }
 
 void prof_end(int tag, hipStream_t s) {
-  if (!g_prof_on || tag <= 0 || tag >= VQVAE_PROF_NTAGS) return;
+  if (tag <= 0 || tag >= VQVAE_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_open[tag]) return;
   hipEvent_t e = prof_get_event();
@@ -137,7 +137,7 @@ int vqvae_event_elapsed_ms(float* ms, void* a, void* b) {
   return 0;
 }
 
-int vqvae_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+int vqvae_prof_enable(int tag_mask) { g_prof_mask = (unsigned)tag_mask; return 0; }
 
 int vqvae_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -62,7 +62,8 @@ int vqvae_event_synchronize(void* ev);
 int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline).
- *      tag = one of VQVAE_PROF_*; enable, run, then read (synchronises). */
+ *      tag = one of VQVAE_PROF_*; enable(bitmask: bit t = tag t, -1 = all), run, then
+ *      read (synchronises the device). */
 #define VQVAE_PROF_NONE            0
 #define VQVAE_PROF_RESBLOCK_GATE   1   /* dilated conv + cond proj + gate (fwd)       */
 #define VQVAE_PROF_RESBLOCK_OUT    2   /* res/skip 1x1 (fwd)                          */
@@ -75,7 +76,7 @@ int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
 #define VQVAE_PROF_CONV_WGRAD      9
 #define VQVAE_PROF_VQ_NEAREST     10
 #define VQVAE_PROF_NTAGS          16
-int vqvae_prof_enable(int on);
+int vqvae_prof_enable(int tag_mask);
 int vqvae_prof_reset(void);
 int vqvae_prof_read(int tag, double* total_ms, int* launches);
 

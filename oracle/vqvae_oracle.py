@@ -88,7 +88,7 @@ def conv1d_fwd(x, W, b, stride=1, pad=0, dil=1):
     y = np.zeros((B, Co, Lo), dtype=x.dtype)
     for j in range(K):
         xs = xp[:, :, j * dil: j * dil + (Lo - 1) * stride + 1: stride]
-        y += np.matmul(W[:, :, j], xs)
+        y += np.matmul(np.ascontiguousarray(W[:, :, j]), xs)       # BLAS sgemm per batch item
     if b is not None:
         y += b[None, :, None]
     return y
@@ -106,9 +106,9 @@ def conv1d_bwd(x, W, gy, stride=1, pad=0, dil=1, need_gx=True):
         sl = slice(j * dil, j * dil + (Lo - 1) * stride + 1, stride)
         xs = xp[:, :, sl]
         # gW[o,c,j] = sum_{b,t} gy[b,o,t] xs[b,c,t]
-        gW[:, :, j] = np.einsum('bot,bct->oc', gy, xs, optimize=True)
+        gW[:, :, j] = np.tensordot(gy, xs, axes=((0, 2), (0, 2)))
         if need_gx:
-            gxp[:, :, sl] += np.matmul(W[:, :, j].T, gy)
+            gxp[:, :, sl] += np.matmul(np.ascontiguousarray(W[:, :, j].T), gy)
     gb = gy.sum(axis=(0, 2))
     gx = gxp[:, :, pad: pad + L] if need_gx else None
     return gx, gW, gb
