@@ -28,7 +28,8 @@ namespace vq {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
-constexpr int MAXSEG = 4;
+constexpr int MAXSEG = 24;   // a whole ResidualNet's blocks can feed one contraction
+constexpr int MAXTAPS = 4;
 
 struct Seg {
   const float* x;      // activations, channel 0 of this segment
@@ -187,29 +188,61 @@ __global__ __launch_bounds__(NT) void conv_gemm_kernel(const GemmArgs a) {
   // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int T = a.Tout;
   if (EPI == EPI_LINEAR) {
+    // All loads of a 32x32 sub-tile (bias, residual, old value) are issued before its
+    // first store, so they overlap instead of serialising behind may-alias stores.
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+      const int mb = m0 + wm * 64 + mi * 32;
+      // the host guarantees out[0].rows % 32 == 0 when two ranges exist: wave-uniform
+      const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+      const OutR& od = a.out[o];
+      const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
+      const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
+      float bias[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= a.M) continue;
-        const int o = (m < a.out[0].rows) ? 0 : 1;
-        const OutR& od = a.out[o];
-        const int mr = o ? m - a.out[0].rows : m;
-        const float bias = od.bias ? od.bias[mr] : 0.f;
+        const int mr = mrb + (r & 3) + 8 * (r >> 2);
+        bias[r] = (od.bias && mr < rows_left) ? od.bias[mr] : 0.f;
+      }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int t = t0 + wn * 64 + ni * 32 + li;
-          if (t >= T) continue;
-          float v = acc[mi][ni][r] + bias;
-          const long off = (long)mr * T + t;
-          if (od.add) v += od.add[(long)b * od.add_bstride + off];
-          float* yp = od.y + (long)b * od.y_bstride + off;
-          if (od.accumulate) v += *yp;
-          if (od.relu) v = fmaxf(v, 0.f);
-          *yp = v;
+      for (int ni = 0; ni < 2; ++ni) {
+        const int t = t0 + wn * 64 + ni * 32 + li;
+        const bool tok = t < T;
+        float addv[16], oldv[16];
+        const long boff = (long)mrb * T + t;
+        if (od.add) {
+          const float* ap = od.add + (long)b * od.add_bstride + boff;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            addv[r] = (tok && mrb + dr < rows_left) ? ap[(long)dr * T] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) addv[r] = 0.f;
+        }
+        float* yp = od.y + (long)b * od.y_bstride + boff;
+        if (od.accumulate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            oldv[r] = (tok && mrb + dr < rows_left) ? yp[(long)dr * T] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (tok && mrb + dr < rows_left) {
+            float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
+            if (od.relu) v = fmaxf(v, 0.f);
+            yp[(long)dr * T] = v;
+          }
         }
       }
+    }
   } else if (EPI == EPI_GATE) {
     // packed rows: each 64-row wave tile = 32 tanh rows (mi=0) + the matching 32
     // sigmoid rows (mi=1) of channel group g.
@@ -273,7 +306,7 @@ struct PackJob {
   int Rpad, ldw, m_off;
   int mspan;             // columns of dst this job owns (multiple of 4, zero filled)
 };
-struct PackArgs { PackJob job[8]; int njob; };
+struct PackArgs { PackJob job[MAXSEG]; int njob; };
 
 __global__ void pack_kernel(const PackArgs pa) {
   const PackJob& j = pa.job[blockIdx.y];
@@ -316,6 +349,7 @@ struct WgradArgs {
   float* slabs;              // [nsplit][ntile_m][ntile_n][128][128]
   float* bslabs;             // [nsplit][ntile_m*128]
   float* gb; float* gb2;     // bias grad destinations (nullable)
+  float* gbl[MAXSEG]; int ngbl;   // further copies of the bias grad (shared gy, many layers)
   int accumulate;
 };
 
@@ -421,40 +455,61 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
-  // one thread per (row, global column)
+// block = (64 columns) x (4 split groups): each thread sums every 4th split with
+// 4 independent accumulators, then the 4 groups combine through LDS in fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
+  __shared__ float red[4][64];
   const long ncol = (long)a.ntile_n * BN;
   const long total = (long)a.ntile_m * BM * ncol;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int colg = (int)(i % ncol);
-    const int row = (int)(i / ncol);
-    if (row >= a.M) continue;
-    const int ntg = colg / BN, col = colg % BN;
-    int s = 0;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long sstride = (long)a.ntile_m * a.ntile_n * (BM * BN);
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long i = base + tx;
+    bool ok = i < total;
+    int colg = 0, row = 0, s = 0, ci = 0;
+    const float* p = a.slabs;
+    if (ok) {
+      colg = (int)(i % ncol);
+      row = (int)(i / ncol);
+      const int ntg = colg / BN, col = colg % BN;
 #pragma unroll
-    for (int k = 1; k < MAXSEG; ++k)
-      if (k < a.nseg && ntg >= a.seg[k].tile0) s = k;
-    const WSeg& sg = a.seg[s];
-    const int ci = (ntg - sg.tile0) * BN + col;
-    if (ci >= sg.cin || sg.gw == nullptr) continue;
-    const int mt = row / BM, r = row % BM;
-    const float* p = a.slabs + ((long)mt * a.ntile_n + ntg) * (BM * BN) + r * BN + col;
-    const long sstride = (long)a.ntile_m * a.ntile_n * (BM * BN);
-    float v = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) v += p[sp * sstride];
-    float* dst = sg.gw + (long)row * sg.gw_co_stride + (long)ci * sg.gw_ci_stride;
-    if (a.accumulate) v += *dst;
-    *dst = v;
+      for (int k = 1; k < MAXSEG; ++k)
+        if (k < a.nseg && ntg >= a.seg[k].tile0) s = k;
+      ci = (ntg - a.seg[s].tile0) * BN + col;
+      ok = row < a.M && ci < a.seg[s].cin && a.seg[s].gw != nullptr;
+      const int mt = row / BM, r = row % BM;
+      p = a.slabs + ((long)mt * a.ntile_n + ntg) * (BM * BN) + r * BN + col;
+    }
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (ok) {
+      int sp = ty;
+      for (; sp + 12 < nsplit; sp += 16) {
+        v0 += p[(long)sp * sstride];
+        v1 += p[(long)(sp + 4) * sstride];
+        v2 += p[(long)(sp + 8) * sstride];
+        v3 += p[(long)(sp + 12) * sstride];
+      }
+      for (; sp < nsplit; sp += 4) v0 += p[(long)sp * sstride];
+    }
+    __syncthreads();
+    red[ty][tx] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (ty == 0 && ok) {
+      float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+      const WSeg& sg = a.seg[s];
+      float* dst = sg.gw + (long)row * sg.gw_co_stride + (long)ci * sg.gw_ci_stride;
+      if (a.accumulate) v += *dst;
+      *dst = v;
+    }
   }
-  if (a.bslabs) {
-    const long totb = a.M;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totb;
-         i += (long)gridDim.x * blockDim.x) {
+  if (a.bslabs && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < a.M; i += 256) {
       float v = 0.f;
       for (int sp = 0; sp < nsplit; ++sp) v += a.bslabs[(long)sp * a.ntile_m * BM + i];
       if (a.gb) { a.gb[i] = a.accumulate ? a.gb[i] + v : v; }
       if (a.gb2) { a.gb2[i] = a.accumulate ? a.gb2[i] + v : v; }
+      for (int l = 0; l < a.ngbl; ++l)
+        if (a.gbl[l]) a.gbl[l][i] = a.accumulate ? a.gbl[l][i] + v : v;
     }
   }
 }
@@ -475,6 +530,9 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   g.ntile_m = cdiv(g.M, BM);
   g.ntile_n = cdiv(g.Tout, BN);
   for (int i = 0; i < g.nseg; ++i) g.seg[i].vec = seg_vec_ok(g.seg[i]) ? 1 : 0;
+  if (EPI == EPI_LINEAR && g.out[1].y != nullptr)
+    VQ_REQUIRE(g.out[0].rows % 32 == 0, "conv_gemm: first output range must be a multiple of 32 rows");
+  if (EPI == EPI_LINEAR && g.out[1].y == nullptr) g.out[0].rows = g.M;
   const long nblk = (long)g.ntile_m * g.ntile_n * g.B;
   if (nblk <= 0) return 0;
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
@@ -541,15 +599,15 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
 static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream_t st) {
   w.ntile_m = p.ntile_m; w.ntile_n = p.ntile_n; w.tchunk = p.tchunk; w.nsplit_t = p.nsplit_t;
   w.slabs = ws;
-  w.bslabs = (w.gb || w.gb2) ? ws + p.slab_floats : nullptr;
+  w.bslabs = (w.gb || w.gb2 || w.ngbl > 0) ? ws + p.slab_floats : nullptr;
   int t0 = 0;
   for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
   ProfScope ps(tag, st);
   hipLaunchKernelGGL(wgrad_kernel, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
   const long total = (long)p.ntile_m * BM * p.ntile_n * BN;
-  int nb = (int)((total + 255) / 256);
-  if (nb > 2048) nb = 2048;
+  int nb = (int)((total + 63) / 64);
+  if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, w, p.nsplit);
   VQ_LAUNCH_CHECK();
   return 0;
@@ -565,7 +623,7 @@ using namespace vq;
 static int check_conv_desc(const vqvae_conv1d_desc* d) {
   VQ_REQUIRE(d, "conv1d: null desc");
   VQ_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->Tin > 0 && d->Tout > 0, "conv1d: bad dims");
-  VQ_REQUIRE(d->K >= 1 && d->K <= MAXSEG, "conv1d: K=%d unsupported (1..%d)", d->K, MAXSEG);
+  VQ_REQUIRE(d->K >= 1 && d->K <= MAXTAPS, "conv1d: K=%d unsupported (1..%d)", d->K, MAXTAPS);
   VQ_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, "conv1d: bad stride/dil/pad");
   const int nat = (d->Tin + 2 * d->pad - d->dil * (d->K - 1) - 1) / d->stride + 1;
   VQ_REQUIRE(d->Tout <= nat, "conv1d: Tout=%d exceeds natural output length %d", d->Tout, nat);
@@ -580,9 +638,9 @@ static size_t conv_pack_floats(const vqvae_conv1d_desc* d) {
 
 extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
   if (!d) return 0;
-  int cins[MAXSEG];
-  for (int i = 0; i < d->K && i < MAXSEG; ++i) cins[i] = d->Cin;
-  WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K < MAXSEG ? d->K : MAXSEG);
+  int cins[MAXTAPS];
+  for (int i = 0; i < d->K && i < MAXTAPS; ++i) cins[i] = d->Cin;
+  WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K < MAXTAPS ? d->K : MAXTAPS);
   size_t wg = (p.slab_floats + p.bslab_floats) * sizeof(float);
   size_t pk = conv_pack_floats(d) * sizeof(float);
   return align_up(wg > pk ? wg : pk, 256) + 256;
@@ -707,7 +765,7 @@ static int check_rb(const vqvae_resblock_desc* d) {
   VQ_REQUIRE(d, "resblock: null desc");
   VQ_REQUIRE(d->B > 0 && d->T > 0 && d->Cr > 0 && d->Cd > 0 && d->Cs > 0 && d->Cc > 0, "resblock: bad dims");
   VQ_REQUIRE(d->Cd % 64 == 0, "resblock: dilated_channels/2 must be a multiple of 32 (got Cd=%d)", d->Cd);
-  VQ_REQUIRE(d->K >= 1 && d->K + 1 <= MAXSEG, "resblock: filter_size %d unsupported", d->K);
+  VQ_REQUIRE(d->K >= 1 && d->K <= MAXTAPS, "resblock: filter_size %d unsupported", d->K);
   VQ_REQUIRE(d->dil >= 1, "resblock: bad dilation");
   return 0;
 }
@@ -723,27 +781,29 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
                                   int skip_accumulate, float* gates, float* z, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
-  VQ_REQUIRE(p && x && cond && skip && gates && z && ws, "resblock_fwd: null pointer");
-  VQ_REQUIRE(p->Wd && p->Wc && p->Ws && (res == nullptr || p->Wr), "resblock_fwd: null weight");
+  VQ_REQUIRE(p && x && cond && gates && z && ws, "resblock_fwd: null pointer");
+  VQ_REQUIRE(p->Wd && p->Wc && (skip == nullptr || p->Ws) && (res == nullptr || p->Wr), "resblock_fwd: null weight");
   hipStream_t st = (hipStream_t)s;
   RbLayout L = rb_layout(d);
   if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* w = (float*)ws;
   const int Ch = d->Cd / 2, T = d->T;
   const int ldd = pad128(d->Cd);
-  const int Mo = (res ? d->Cr : 0) + d->Cs;
-  const int ldo = pad128(Mo);
+  const int Mo = (res ? d->Cr : 0) + (skip ? d->Cs : 0);
+  const int ldo = pad128(Mo > 0 ? Mo : 1);
 
   PackArgs pa; pa.njob = 0;
   pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p->Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
   pa.job[pa.njob++] = pack_fwd_job(w + L.pk_c, p->Wc, d->Cd, d->Cc, 1, Ch, ldd, 0, ldd);
-  if (res) {
+  if (res && skip) {
+    VQ_REQUIRE(d->Cr % 32 == 0, "resblock: residual_channels must be a multiple of 32 when res and skip share a launch");
     pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Wr, d->Cr, Ch, 1, 0, ldo, 0, d->Cr);
     pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Ws, d->Cs, Ch, 1, 0, ldo, d->Cr, ldo - d->Cr);
-  } else {
+  } else if (res) {
+    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Wr, d->Cr, Ch, 1, 0, ldo, 0, ldo);
+  } else if (skip) {
     pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Ws, d->Cs, Ch, 1, 0, ldo, 0, ldo);
   }
-  VQ_REQUIRE(!res || d->Cr % 4 == 0, "resblock: residual_channels must be a multiple of 4");
   if (int e = launch_pack(pa, st)) return e;
 
   // K1: h = dilconv(x) + cond_proj(c) + biases -> gate
@@ -767,7 +827,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
     if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
   }
   // K2: [res; skip] = [Wr; Ws] z (+ x) (+= skip)
-  {
+  if (Mo > 0) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.nseg = 1;
     Seg& sg = g.seg[0];
@@ -780,8 +840,10 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
       g.out[0].add = x; g.out[0].add_bstride = (long)d->Cr * T; g.out[0].bias = p->br;
       o = 1;
     }
-    g.out[o].y = skip; g.out[o].y_bstride = (long)d->Cs * T; g.out[o].rows = d->Cs;
-    g.out[o].bias = p->bs; g.out[o].accumulate = skip_accumulate;
+    if (skip) {
+      g.out[o].y = skip; g.out[o].y_bstride = (long)d->Cs * T; g.out[o].rows = d->Cs;
+      g.out[o].bias = p->bs; g.out[o].accumulate = skip_accumulate;
+    }
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st)) return e;
   }
   return 0;
@@ -790,7 +852,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
 extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                                   const float* x, const float* cond, const float* gates,
                                   const float* z, const float* g_res, const float* g_skip,
-                                  float* gx, float* gcond, int gcond_accumulate,
+                                  float* gx, float* gcond, int gcond_accumulate, float* gh_out,
                                   const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
@@ -800,7 +862,7 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
   if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* w = (float*)ws;
   const int Ch = d->Cd / 2, T = d->T;
-  float* gh = w + L.gh;
+  float* gh = gh_out ? gh_out : w + L.gh;
   const int ldz = pad128(Ch), ldr = pad128(d->Cr), ldc = pad128(d->Cc);
 
   PackArgs pa; pa.njob = 0;
@@ -892,4 +954,128 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
     if (int e = launch_wgrad(wa, which ? L.p_s : L.p_r, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
   }
   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: ResidualNet-level contractions (WaveNet/modules.py:89-96).
+//
+// skip_connections = sum_l skip_l(z_l) is ONE GEMM over K = nblocks * Cd/2
+// (the z_l of all blocks are kept in HBM for backward anyway), instead of
+// nblocks read-modify-write passes over the (B,Cs,T) accumulator; likewise the
+// condition gradient sum_l Wc_l^T gh_l is one GEMM over K = nblocks * Cd, and
+// the skip-weight gradients share one launch (g_skip is their common operand).
+// ---------------------------------------------------------------------------
+struct PtrList { const float* p[MAXSEG]; };
+__global__ void bias_sum_list_kernel(const PtrList bl, int nb, int n, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int l = 0; l < nb; ++l) v += bl.p[l][i];
+  out[i] = v;
+}
+
+extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks) {
+  if (!d || nblocks < 1 || nblocks > MAXSEG) return 0;
+  const int Ch = d->Cd / 2;
+  size_t skip_pk = (size_t)nblocks * pad16(Ch) * pad128(d->Cs) + pad128(d->Cs);
+  size_t gc_pk = (size_t)nblocks * pad16(d->Cd) * pad128(d->Cc);
+  int cz[MAXSEG];
+  for (int i = 0; i < nblocks; ++i) cz[i] = Ch;
+  WgradPlan p = plan_wgrad(d->Cs, d->B, d->T, cz, nblocks);
+  size_t wg = p.slab_floats + p.bslab_floats;
+  size_t m = skip_pk > gc_pk ? skip_pk : gc_pk;
+  if (wg > m) m = wg;
+  return m * sizeof(float) + 1024;
+}
+
+extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
+                                       const float* const* Ws, const float* const* bs,
+                                       const float* const* z, float* skip, void* ws,
+                                       size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_fwd: 1..%d blocks", MAXSEG);
+  VQ_REQUIRE(Ws && bs && z && skip && ws, "resstack_skip_fwd: null pointer");
+  if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_skip_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  const int Ch = d->Cd / 2, T = d->T;
+  const int ld = pad128(d->Cs), rp = pad16(Ch);
+  float* w = (float*)ws;
+  float* bsum = w + (size_t)nblocks * rp * ld;
+  PackArgs pa; pa.njob = 0;
+  PtrList bl;
+  for (int l = 0; l < nblocks; ++l) {
+    pa.job[pa.njob++] = pack_fwd_job(w + (size_t)l * rp * ld, Ws[l], d->Cs, Ch, 1, 0, ld, 0, ld);
+    bl.p[l] = bs[l];
+  }
+  if (int e = launch_pack(pa, st)) return e;
+  hipLaunchKernelGGL(bias_sum_list_kernel, dim3(cdiv(d->Cs, 256)), dim3(256), 0, st, bl, nblocks, d->Cs, bsum);
+  VQ_LAUNCH_CHECK();
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.nseg = nblocks;
+  for (int l = 0; l < nblocks; ++l) {
+    Seg& sg = g.seg[l];
+    sg.x = z[l]; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + (size_t)l * rp * ld; sg.ldw = ld;
+  }
+  g.M = d->Cs; g.Tout = T; g.B = d->B;
+  g.out[0].y = skip; g.out[0].y_bstride = (long)d->Cs * T; g.out[0].rows = d->Cs;
+  g.out[0].bias = bsum;
+  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st);
+}
+
+extern "C" int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
+                                        const float* const* Wc, const float* const* gh,
+                                        float* gcond, int accumulate, void* ws, size_t ws_bytes,
+                                        vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_gcond_bwd: 1..%d blocks", MAXSEG);
+  VQ_REQUIRE(Wc && gh && gcond && ws, "resstack_gcond_bwd: null pointer");
+  if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_gcond_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  const int T = d->T;
+  const int ld = pad128(d->Cc), rp = pad16(d->Cd);
+  float* w = (float*)ws;
+  PackArgs pa; pa.njob = 0;
+  for (int l = 0; l < nblocks; ++l)
+    pa.job[pa.njob++] = pack_bwd_job(w + (size_t)l * rp * ld, Wc[l], d->Cd, d->Cc, 1, ld);
+  if (int e = launch_pack(pa, st)) return e;
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.nseg = nblocks;
+  for (int l = 0; l < nblocks; ++l) {
+    Seg& sg = g.seg[l];
+    sg.x = gh[l]; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + (size_t)l * rp * ld; sg.ldw = ld;
+  }
+  g.M = d->Cc; g.Tout = T; g.B = d->B;
+  g.out[0].y = gcond; g.out[0].y_bstride = (long)d->Cc * T; g.out[0].rows = d->Cc;
+  g.out[0].accumulate = accumulate;
+  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GC, st);
+}
+
+extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nblocks,
+                                         const float* g_skip, const float* const* z,
+                                         float* const* gWs, float* const* gbs, int accumulate,
+                                         void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_wgrad: 1..%d blocks", MAXSEG);
+  VQ_REQUIRE(g_skip && z && gWs && ws, "resstack_skip_wgrad: null pointer");
+  if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_skip_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  const int Ch = d->Cd / 2, T = d->T;
+  int cz[MAXSEG];
+  for (int i = 0; i < nblocks; ++i) cz[i] = Ch;
+  WgradPlan p = plan_wgrad(d->Cs, d->B, T, cz, nblocks);
+  WgradArgs wa; memset(&wa, 0, sizeof(wa));
+  wa.gy = g_skip; wa.gy_bstride = (long)d->Cs * T; wa.M = d->Cs; wa.Tout = T; wa.B = d->B;
+  wa.nseg = nblocks;
+  for (int l = 0; l < nblocks; ++l) {
+    WSeg& sg = wa.seg[l];
+    sg.x = z[l]; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
+    sg.gw = gWs[l]; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
+    wa.gbl[l] = gbs ? gbs[l] : nullptr;
+  }
+  wa.ngbl = gbs ? nblocks : 0;
+  wa.accumulate = accumulate;
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }

@@ -12,6 +12,12 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libvqvae_hip.so')
 c_void_p, c_int, c_long, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_size_t
 c_float, c_double, c_char_p = C.c_float, C.c_double, C.c_char_p
 P = c_void_p                      # every device pointer crosses as an integer address
+PP = C.POINTER(c_void_p)          # host array of device pointers
+
+
+def ptr_array(arrays):
+    """Host array of device pointers (None -> NULL) for the resstack entry points."""
+    return (c_void_p * len(arrays))(*[None if a is None else a.ptr for a in arrays])
 
 
 class Conv1dDesc(C.Structure):
@@ -64,8 +70,15 @@ PROTOTYPES = {
     'vqvae_resblock_fwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
                                    c_int, P, P, P, c_size_t, P]),
     'vqvae_resblock_bwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
-                                   P, P, P, P, c_int, C.POINTER(ResblockGrads), c_int, P,
+                                   P, P, P, P, c_int, P, C.POINTER(ResblockGrads), c_int, P,
                                    c_size_t, P]),
+    'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
+    'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, P, c_size_t,
+                                        P]),
+    'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
+                                         c_size_t, P]),
+    'vqvae_resstack_skip_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, P, PP, PP, PP, c_int, P,
+                                          c_size_t, P]),
     'vqvae_vq_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'vqvae_vq_nearest_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P,
                                      c_size_t, P]),

@@ -266,9 +266,20 @@ class Parameter(Variable):
             arr = np.ascontiguousarray(init(shape), np.float32)
         self._data = arr
 
+    def grad_buffer(self):
+        """Where a backward kernel may write this parameter's gradient directly
+        (its slot in the flat gradient arena) -- only while no gradient has been
+        accumulated yet; otherwise None and the caller allocates."""
+        if self._grad_slot is not None and self.grad is None:
+            return self._grad_slot
+        return None
+
     def _accumulate_grad(self, gx):
         from . import functions as F
         if self._grad_slot is not None:
+            if gx.ptr == self._grad_slot.ptr:        # written in place by the kernel
+                self.grad = self._grad_slot
+                return
             gx = gx.reshape(self._grad_slot.shape)
             if self.grad is None:
                 self._grad_slot.copy_from(gx)
@@ -395,8 +406,11 @@ class Link(object):
         """Link.cleargrads (updaters.py:14,16).  With a flat gradient arena the
         contiguous run of slots is zeroed by one memset."""
         ps = [p for p in self.params() if p.data is not None]
-        slots = [p for p in ps if p._grad_slot is not None and p.grad is not None]
-        if slots:
+        slots = [p for p in ps if p._grad_slot is not None]
+        dirty = [p for p in slots if p.grad is not None]
+        if dirty:
+            # the slots of one Link sub-tree are one contiguous run of the arena
+            # (namedparams order); zeroing never-written (already zero) slots is harmless
             lo = min(p._grad_slot.ptr for p in slots)
             hi = max(p._grad_slot.ptr + p._grad_slot.nbytes for p in slots)
             tot = sum(p._grad_slot.nbytes for p in slots)
@@ -404,7 +418,7 @@ class Link(object):
             if hi - lo == tot:
                 _lib.call('vqvae_memset', lo, 0, tot, backend.stream())
             else:
-                for p in slots:
+                for p in dirty:
                     p._grad_slot.fill_zero()
         for p in ps:
             p.grad = None

@@ -252,9 +252,13 @@ class Conv1dFunction(FunctionNode):
                       ws.ptr, ws.nbytes, _S())
         gW = gb = None
         if 1 in indexes:
-            gW = DeviceArray(W.shape, np.float32)
+            wv = self.inputs[1]
+            buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
+            gW = buf.reshape(W.shape) if buf is not None else DeviceArray(W.shape, np.float32)
             if self._has_b:
-                gb = DeviceArray((self.desc.Cout,), np.float32)
+                bv = self.inputs[2]
+                buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
+                gb = buf if buf is not None else DeviceArray((self.desc.Cout,), np.float32)
             _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.desc), x.ptr, gy.ptr, gW.ptr,
                       _p(gb), 0, ws.ptr, ws.nbytes, _S())
         return (gx, gW, gb) if self._has_b else (gx, gW)

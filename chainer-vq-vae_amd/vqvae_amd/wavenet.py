@@ -80,17 +80,31 @@ class ResidualBlockFunction(FunctionNode):
         grd = _lib.ResblockGrads(*[_p(a) for a in gp])
         ws = _rb_workspace(d)
         _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), x.ptr, cond.ptr, self.gates.ptr,
-                  self.z.ptr, _p(g_res), g_skip.ptr, _p(gx), _p(gc), 0, C.byref(grd), 0, ws.ptr,
-                  ws.nbytes, _S())
+                  self.z.ptr, _p(g_res), g_skip.ptr, _p(gx), _p(gc), 0, None, C.byref(grd), 0,
+                  ws.ptr, ws.nbytes, _S())
         return tuple([gx, gc] + gp)
 
 
+def _grad_out(var, shape):
+    """Gradient destination for input ``var``: its slot in the flat gradient arena
+    when it is a Parameter that has no gradient yet, else a fresh array."""
+    buf = var.grad_buffer() if hasattr(var, 'grad_buffer') else None
+    if buf is not None and buf.size == int(np.prod(shape)):
+        return buf.reshape(shape)
+    return DeviceArray(shape, np.float32)
+
+
 class ResidualStackFunction(FunctionNode):
-    """All blocks of a ResidualNet in one node (modules.py:89-96): the skip sum is
-    accumulated in place by each block's epilogue instead of 19 extra full-tensor
-    adds, the last block skips its unused residual branch, and the condition
-    gradient accumulates in place across blocks.
-    inputs: (x, condition, then 8 params per block) -> skip_connections."""
+    """All blocks of a ResidualNet in one node (modules.py:89-96).
+    inputs: (x, condition, then 8 params per block) -> skip_connections.
+
+    MI355X-first restructuring (same math, summation order aside):
+      * skip_connections = sum_l skip_l(z_l) is ONE GEMM over K = n_blocks*Cd/2 at the
+        end (vqvae_resstack_skip_fwd) instead of n_blocks read-modify-write passes;
+      * the last block's unused residual branch is not computed;
+      * backward keeps every block's gh in HBM (2.5 GB at B=16 -- 288 GB part) so the
+        condition gradient sum_l Wc_l^T gh_l is ONE GEMM over K = n_blocks*Cd, and all
+        skip-weight gradients share one launch (g_skip is their common operand)."""
 
     def __init__(self, dilations):
         self.dilations = [int(d) for d in dilations]
@@ -101,7 +115,6 @@ class ResidualStackFunction(FunctionNode):
         nb = len(self.dilations)
         assert len(inputs) == 2 + 8 * nb
         self.descs, self.saved = [], []
-        skip = None
         h = x
         for i, dil in enumerate(self.dilations):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs[2 + 8 * i: 10 + 8 * i]
@@ -109,28 +122,34 @@ class ResidualStackFunction(FunctionNode):
             prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
             last = (i == nb - 1)
             res = None if last else DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
-            if skip is None:
-                skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
             gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
             z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
             ws = _rb_workspace(d)
             _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, _p(res),
-                      skip.ptr, 0 if i == 0 else 1, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
+                      None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
             self.descs.append(d)
             self.saved.append((h, gates, z))
             h = res
+        d = self.descs[0]
+        skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
+        ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
+        Ws = _lib.ptr_array([inputs[2 + 8 * i + 6] for i in range(nb)])
+        bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(nb)])
+        zs = _lib.ptr_array([sv[2] for sv in self.saved])
+        _lib.call('vqvae_resstack_skip_fwd', C.byref(d), nb, Ws, bs, zs, skip.ptr, ws.ptr, ws.nbytes,
+                  _S())
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
 
     def backward(self, indexes, gys):
-        ins = [v.data for v in self.get_retained_inputs()]
+        in_vars = self.get_retained_inputs()
+        ins = [v.data for v in in_vars]
         cond = ins[1]
         g_skip = gys[0].data
         nb = len(self.dilations)
-        gcond = DeviceArray(cond.shape, np.float32) if 1 in indexes else None
         grads = [None] * len(ins)
         g_res = None
-        first_gc = True
+        ghs = [None] * nb
         for i in range(nb - 1, -1, -1):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = ins[2 + 8 * i: 10 + 8 * i]
             d = self.descs[i]
@@ -138,20 +157,37 @@ class ResidualStackFunction(FunctionNode):
             prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
             need_gx = (i > 0) or (0 in indexes)
             gx = DeviceArray(h.shape, np.float32) if need_gx else None
-            gp = [DeviceArray(a.shape, np.float32) for a in (Wd, bd, Wc, bc, Wr, br, Ws, bs)]
+            gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(6)]
+            gp += [None, None]                 # skip conv grads: one launch for all blocks below
             if g_res is None:
-                gp[4] = gp[5] = None
+                gp[4] = gp[5] = None           # residual output unused (last block)
             grd = _lib.ResblockGrads(*[_p(a) for a in gp])
+            gh = DeviceArray((d.B, d.Cd, d.T), np.float32)
             ws = _rb_workspace(d)
             _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, gates.ptr,
-                      z.ptr, _p(g_res), g_skip.ptr, _p(gx), _p(gcond), 0 if first_gc else 1,
-                      C.byref(grd), 0, ws.ptr, ws.nbytes, _S())
-            first_gc = False
+                      z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(grd), 0,
+                      ws.ptr, ws.nbytes, _S())
             grads[2 + 8 * i: 10 + 8 * i] = gp
+            ghs[i] = gh
             g_res = gx
-            self.saved[i] = None            # free activations as we go
+        d = self.descs[0]
+        ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
+        if 1 in indexes:
+            gcond = DeviceArray(cond.shape, np.float32)
+            Wc = _lib.ptr_array([ins[2 + 8 * i + 2] for i in range(nb)])
+            _lib.call('vqvae_resstack_gcond_bwd', C.byref(d), nb, Wc, _lib.ptr_array(ghs), gcond.ptr,
+                      0, ws.ptr, ws.nbytes, _S())
+            grads[1] = gcond
+        gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
+        gbs = [_grad_out(in_vars[2 + 8 * i + 7], ins[2 + 8 * i + 7].shape) for i in range(nb)]
+        zs = _lib.ptr_array([sv[2] for sv in self.saved])
+        _lib.call('vqvae_resstack_skip_wgrad', C.byref(d), nb, g_skip.ptr, zs, _lib.ptr_array(gWs),
+                  _lib.ptr_array(gbs), 0, ws.ptr, ws.nbytes, _S())
+        for i in range(nb):
+            grads[2 + 8 * i + 6] = gWs[i]
+            grads[2 + 8 * i + 7] = gbs[i]
+        self.saved = None                      # release activations
         grads[0] = g_res if 0 in indexes else None
-        grads[1] = gcond
         return tuple(grads)
 
 

@@ -129,20 +129,40 @@ typedef struct {            /* gradients, same layouts; any pair may be NULL    
 
 size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d);
 /* res may be NULL (last block: residual unused, modules.py:89-96).  skip is
- * overwritten, or accumulated into when skip_accumulate != 0 (modules.py:92-95).
+ * overwritten, or accumulated into when skip_accumulate != 0 (modules.py:92-95);
+ * skip may be NULL too (ResidualNet computes the skip sum with vqvae_resstack_skip_fwd).
  * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd. */
 int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                        const float* x, const float* cond, float* res, float* skip,
                        int skip_accumulate, float* gates, float* z, void* ws,
                        size_t ws_bytes, vqvae_stream_t s);
-/* g_res may be NULL; gx may be NULL; gcond (B,Cc,T) is accumulated into when
- * gcond_accumulate != 0; parameter grads are accumulated when grads_accumulate. */
+/* g_res may be NULL; gx may be NULL; gcond (B,Cc,T) may be NULL and is accumulated
+ * into when gcond_accumulate != 0; gh_out (B,Cd,T), if not NULL, receives the
+ * gradient w.r.t. the pre-gate activation h (kept by ResidualNet for the stack-level
+ * condition gradient); parameter grads are accumulated when grads_accumulate. */
 int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                        const float* x, const float* cond, const float* gates,
                        const float* z, const float* g_res, const float* g_skip,
-                       float* gx, float* gcond, int gcond_accumulate,
+                       float* gx, float* gcond, int gcond_accumulate, float* gh_out,
                        const vqvae_resblock_grads* g, int grads_accumulate, void* ws,
                        size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- ResidualNet-level contractions (WaveNet/modules.py:89-96): the arguments are
+ *      HOST arrays of nblocks (<= 24) device pointers.
+ *      skip_fwd : skip (B,Cs,T) = sum_l (Ws_l z_l + bs_l)   -- one GEMM, K = nblocks*Cd/2
+ *      gcond_bwd: gcond (B,Cc,T) (+)= sum_l Wc_l^T gh_l     -- one GEMM, K = nblocks*Cd
+ *      skip_wgrad: gWs_l (+)= g_skip z_l^T, gbs_l (+)= rowsum(g_skip) for every l     */
+size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks);
+int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
+                            const float* const* Ws, const float* const* bs,
+                            const float* const* z, float* skip, void* ws, size_t ws_bytes,
+                            vqvae_stream_t s);
+int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
+                             const float* const* Wc, const float* const* gh, float* gcond,
+                             int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
+int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nblocks, const float* g_skip,
+                              const float* const* z, float* const* gWs, float* const* gbs,
+                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
 
 /* ---- vector quantiser: StraightThrough.forward / backward (utils.py:176-231).
  *      z (B,d,T) [T contiguous], W (k,d).  idx (B,T) int32 is bit-exact with
