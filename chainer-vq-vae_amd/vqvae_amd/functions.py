@@ -276,14 +276,12 @@ def convolution_1d(x, W, b=None, stride=1, pad=0, dilate=1, out_len=None, relu=F
 _resize_cache = {}
 
 
-def resize_tables(H, outH):
+def resize_tables_host(H, outH):
     """Chainer's resize_images sampling along one axis, computed on the host in
     float64 and cast like Chainer does: v = linspace(0, H-1, outH); v0 =
     floor(v).clip(0, H-2); v1 = v0+1; weights (v1-v), (v-v0) as float32.  Also
-    the inverse ranges the backward kernel needs."""
-    key = (H, outH)
-    if key in _resize_cache:
-        return _resize_cache[key]
+    the inverse ranges the backward kernel needs: outputs i with v0[i]==p are
+    [lo0[p], hi0[p]); with v1[i]==p are [lo1[p], hi1[p])."""
     if H == 1:
         v0 = np.zeros(outH, np.int32)
         v1 = np.zeros(outH, np.int32)
@@ -303,10 +301,14 @@ def resize_tables(H, outH):
     if H == 1:           # weight-0 taps contribute nothing
         lo0[:] = 0
         hi0[:] = 0
-    tabs = {k: backend.to_device(a) for k, a in
-            dict(v0=v0, v1=v1, w0=w0, w1=w1, lo0=lo0, hi0=hi0, lo1=lo1, hi1=hi1).items()}
-    _resize_cache[key] = tabs
-    return tabs
+    return dict(v0=v0, v1=v1, w0=w0, w1=w1, lo0=lo0, hi0=hi0, lo1=lo1, hi1=hi1)
+
+
+def resize_tables(H, outH):
+    key = (H, outH)
+    if key not in _resize_cache:
+        _resize_cache[key] = {k: backend.to_device(a) for k, a in resize_tables_host(H, outH).items()}
+    return _resize_cache[key]
 
 
 class ConditionAssemble(FunctionNode):

@@ -1,0 +1,197 @@
+"""CPU tests (-m "not gpu") of the host side: the C-ABI library loads and exports
+every symbol include/vqvae_hip.h declares, argument validation, the Chainer-shaped
+Link tree (names, shapes, parameter counts), and that NOTHING computes on the host."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import vqvae_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'vqvae_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(vqvae_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_header_symbol():
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(lib, s), 'libvqvae_hip.so does not export ' + s
+        assert s in _lib.PROTOTYPES, 'no ctypes prototype for ' + s
+    for s in _lib.PROTOTYPES:
+        assert s in syms, 'prototype %s is not declared in include/vqvae_hip.h' % s
+    assert lib.vqvae_abi_version() == 1
+
+
+def test_argument_validation_without_device():
+    """Entry points validate before touching the device and return VQVAE_E_INVALID."""
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    d = _lib.Conv1dDesc(1, 4, 16, 4, 99, 2, 1, 0, 1, 0)           # Tout > natural length
+    assert lib.vqvae_conv1d_fwd(C.byref(d), 8, 8, None, 8, 8, 1 << 20, None) == -1
+    assert b'Tout' in lib.vqvae_last_error_string()
+    d = _lib.Conv1dDesc(1, 4, 16, 4, 15, 9, 1, 0, 1, 0)           # K too large
+    assert lib.vqvae_conv1d_fwd(C.byref(d), 8, 8, None, 8, 8, 1 << 20, None) == -1
+    rb = _lib.ResblockDesc(1, 16, 8, 40, 8, 4, 2, 1)              # Cd/2 not a multiple of 32
+    assert lib.vqvae_resblock_workspace_bytes(C.byref(rb)) > 0
+    assert lib.vqvae_resblock_fwd(C.byref(rb), None, 8, 8, 8, 8, 0, 8, 8, 8, 1 << 30, None) == -1
+    assert lib.vqvae_vq_nearest_fwd(None, None, 1, 1, 1, 1, 0, None, None, None, None, 0, None) == -1
+    with pytest.raises(_lib.HipError):
+        _lib.call('vqvae_sum', None, 4, 1.0, None, None, 0, None)
+
+
+def test_workspace_queries():
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    rb = _lib.ResblockDesc(16, 7680, 256, 256, 256, 192, 2, 512)
+    n = lib.vqvae_resblock_workspace_bytes(C.byref(rb))
+    assert 16 * 256 * 7680 * 4 < n < 2 * 2 ** 30
+    assert lib.vqvae_resstack_workspace_bytes(C.byref(rb), 20) > 0
+    assert lib.vqvae_resstack_workspace_bytes(C.byref(rb), 25) == 0     # > 24 blocks unsupported
+    assert lib.vqvae_vq_workspace_bytes(16, 64, 120, 512) >= 512 * 64 * 8
+
+
+def _c1_model():
+    import vqvae_amd as V
+    from vqvae_amd import functions as F
+    enc = V.Encoder(64)
+    wn = V.WaveNet(2, 10, 2, 256, 256, 256, 256, 256, False, 30, -40, 192, 0)
+    ce = V.ConditionEmbed(109, 128, 64)
+    for i, ci in zip(range(1, 6), [64] * 5):
+        getattr(ce, 'local_embed%d' % i)._initialize_params(ci)
+    return V.VAE(enc, V.ExponentialMovingAverage(wn, 0.9999), ce, 64, 512, 0.25,
+                 F.softmax_cross_entropy), enc, wn, ce
+
+
+def test_link_tree_names_shapes_counts():
+    model, enc, wn, ce = _c1_model()
+    assert enc.count_params() == 82560
+    assert wn.count_params() == 5198592
+    assert ce.count_params() == 75712
+    assert model.vq.W.shape == (512, 64)
+    names = [n for n, _ in model.namedparams()]
+    # generate.py:67-81 key layout: encoder / vq / decoder/{ema,target} / condition_embed
+    assert '/encoder/conv1/W' in names and '/vq/W' in names
+    assert '/decoder/target/resnet/0/conv/W' in names and '/decoder/ema/resnet/19/skip/b' in names
+    assert '/condition_embed/global_embed/W' in names
+    assert names == sorted(names, key=lambda s: [int(p) if p.isdigit() else p for p in s.split('/')])
+    p = dict(model.namedparams())
+    assert p['/encoder/conv1/W'].shape == (64, 1, 4, 1)
+    assert p['/decoder/target/resnet/3/conv/W'].shape == (256, 256, 2, 1)
+    assert p['/decoder/target/resnet/3/condition_proj/W'].shape == (256, 192, 1, 1)
+    assert p['/decoder/target/resnet/3/res/W'].shape == (256, 128, 1, 1)
+    assert p['/decoder/target/embed/W'].shape == (256, 256, 2, 1)
+    assert [b.dilation for b in wn.resnet.children()] == [2 ** i for i in range(10)] * 2
+    # EMA copy starts identical and is flagged as a never-trained shadow
+    assert np.array_equal(p['/decoder/ema/proj1/W'].data, p['/decoder/target/proj1/W'].data)
+    assert p['/decoder/ema/proj1/W']._shadow and not p['/decoder/target/proj1/W']._shadow
+
+
+def test_oracle_and_device_model_name_maps_agree():
+    import helpers as H
+    cfg = dict(H.SMALL)
+    P, model = H.build_model(cfg, seed=0, ema_decay=0.99)
+    named = dict(model.namedparams())
+    for name, arr in O.flatten_params(P):
+        dn = H._dev_name(name, True)
+        assert dn in named, dn
+        assert named[dn].data.reshape(arr.shape).shape == arr.shape
+        np.testing.assert_array_equal(named[dn].data.reshape(arr.shape), arr)
+
+
+def test_no_cpu_compute_path():
+    """Host arrays are storage only: any compute on them must raise, not fall back."""
+    import vqvae_amd as V
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    from vqvae_amd.optimizers import Adam
+    x = Variable(np.zeros((1, 4, 16, 1), np.float32))
+    W = Variable(np.zeros((4, 4, 2, 1), np.float32))
+    with pytest.raises((ValueError, TypeError)):
+        F.convolution_1d(x, W)
+    with pytest.raises((ValueError, TypeError)):
+        F.relu(x)
+    with pytest.raises(ValueError):                      # the mix guard of utils.py:183-186
+        V.StraightThrough().apply((Variable(np.zeros((1, 4, 3, 1), np.float32)),
+                                   Variable(np.zeros((5, 4), np.float32))))
+    with pytest.raises(ValueError):
+        Adam(1e-3).setup(V.Encoder(8))                   # parameters still on the host
+
+
+def test_straight_through_type_check_matches_reference():
+    """check_type_forward conditions of utils.py:162-174."""
+    import vqvae_amd as V
+    from vqvae_amd.core import InvalidType, Variable
+    st = V.StraightThrough()
+    f32 = np.float32
+    with pytest.raises(InvalidType):
+        st.check_type_forward((Variable(np.zeros((2, 4), f32)), Variable(np.zeros((3, 4), f32))))
+    with pytest.raises(InvalidType):
+        st.check_type_forward((Variable(np.zeros((2, 4, 3, 1, 1), f32)), Variable(np.zeros((3, 4), f32))))
+    with pytest.raises(InvalidType):
+        st.check_type_forward((Variable(np.zeros((2, 4, 3), f32)), Variable(np.zeros((3, 5), f32))))
+    with pytest.raises(InvalidType):
+        st.check_type_forward((Variable(np.zeros((2, 4, 3), np.int32)), Variable(np.zeros((3, 4), f32))))
+    st.check_type_forward((Variable(np.zeros((2, 4, 3), f32)), Variable(np.zeros((3, 4), f32))))
+
+
+def test_resize_tables_match_oracle_and_invert():
+    from vqvae_amd.functions import resize_tables_host
+    for H, outH in [(120, 7680), (8, 512), (1, 64), (5, 40)]:
+        t = resize_tables_host(H, outH)
+        v0, v1, w0, w1 = O.resize_tables(H, outH)
+        np.testing.assert_array_equal(t['v0'], v0)
+        np.testing.assert_array_equal(t['v1'], v1)
+        np.testing.assert_array_equal(t['w0'], w0)
+        np.testing.assert_array_equal(t['w1'], w1)
+        for p in range(H):
+            if H > 1:
+                assert (np.flatnonzero(v0 == p) == np.arange(t['lo0'][p], t['hi0'][p])).all()
+            assert (np.flatnonzero(v1 == p) == np.arange(t['lo1'][p], t['hi1'][p])).all()
+
+
+def test_mulaw_product_matches_golden():
+    from vqvae_amd.utils import MuLaw
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'mulaw.npz'))
+    np.testing.assert_array_equal(MuLaw(256).transform(g['x']), g['q'])
+
+
+def test_shard_and_alpha():
+    from vqvae_amd.comm import scaled_alpha, shard
+    batch = list(range(128))
+    parts = [shard(batch, r, 8) for r in range(8)]
+    assert parts[3] == batch[3::8] and sorted(sum(parts, [])) == batch    # updaters.py:37-38
+    assert scaled_alpha(2e-4, 8) == 2e-4 / 8                               # train.py:101
+
+
+def test_link_signatures_match_reference():
+    import inspect
+    import vqvae_amd as V
+    sig = lambda f: list(inspect.signature(f).parameters)[1:]
+    assert sig(V.Encoder.__init__) == ['d']
+    assert sig(V.ConditionEmbed.__init__) == ['n_global_cond', 'global_embed_dim', 'local_embed_dim',
+                                              'upscale_factor']
+    assert sig(V.VAE.__init__) == ['encoder', 'decoder', 'condition_embed', 'd', 'k', 'beta', 'loss_func']
+    assert sig(V.VAE.__call__) == ['x_enc', 'x_dec', 'global_condition', 't']
+    assert sig(V.VQ.__init__) == ['k', 'd', 'initialW']
+    assert sig(V.ResidualBlock.__init__) == ['filter_size', 'dilation', 'residual_channels',
+                                             'dilated_channels', 'skip_channels', 'condition_dim',
+                                             'dropout_zero_rate']
+    assert sig(V.ResidualNet.__init__) == ['n_loop', 'n_layer', 'filter_size', 'residual_channels',
+                                           'dilated_channels', 'skip_channels', 'condition_dim',
+                                           'dropout_zero_rate']
+    assert sig(V.WaveNet.__init__) == ['n_loop', 'n_layer', 'filter_size', 'input_dim',
+                                       'residual_channels', 'dilated_channels', 'skip_channels',
+                                       'quantize', 'use_logistic', 'n_mixture', 'log_scale_min',
+                                       'condition_dim', 'dropout_zero_rate']
+    assert sig(V.WaveNet.__call__) == ['x', 'condition', 'generating']
+    assert sig(V.ExponentialMovingAverage.__init__) == ['target', 'decay']
