@@ -68,7 +68,7 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(NT) void conv_gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
 
@@ -337,7 +337,9 @@ constexpr int WBK = 32, WP = WBK + 1;
 struct WSeg {
   const float* x; long x_bstride; int x_cstride; int cin; int Tin;
   int tmul, toff, tdiv;
+  const float* gy;    // this segment's own output-gradient tensor (nullptr: WgradArgs.gy)
   float* gw; long gw_co_stride, gw_ci_stride;
+  float* gb; float* gb2;   // bias-gradient destinations fed by this segment's gy (nullable)
   int tile0;          // first global n-tile of this segment
 };
 struct WgradArgs {
@@ -347,13 +349,12 @@ struct WgradArgs {
   int ntile_m, ntile_n;      // ntile_n = total over segments
   int tchunk, nsplit_t;
   float* slabs;              // [nsplit][ntile_m][ntile_n][128][128]
-  float* bslabs;             // [nsplit][ntile_m*128]
-  float* gb; float* gb2;     // bias grad destinations (nullable)
-  float* gbl[MAXSEG]; int ngbl;   // further copies of the bias grad (shared gy, many layers)
+  float* bslabs;             // [nsplit][nseg][ntile_m*128]
+  float* gbl[MAXSEG]; int ngbl;   // further copies of segment 0's bias grad (shared gy, many layers)
   int accumulate;
 };
 
-__global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   __shared__ float As[BM][WP];
   __shared__ float Bs[BN][WP];
   const int tile = blockIdx.x;
@@ -387,9 +388,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
 
-  const float* gyb = a.gy + (long)b * a.gy_bstride;
+  const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride;
   const float* xb = sg.x + (long)b * sg.x_bstride;
-  const bool do_bias = (ntg == 0) && (a.bslabs != nullptr);
+  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
 
   float ra[16], rbv[16];
   auto load = [&](int tb) {
@@ -450,26 +451,30 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs a) {
       float v = bsum[i];
 #pragma unroll
       for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
-      if (l_k == 0) a.bslabs[((long)split * a.ntile_m + mt) * BM + l_r + 8 * i] = v;
+      if (l_k == 0) a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + mt) * BM + l_r + 8 * i] = v;
     }
   }
 }
 
-// block = (64 columns) x (4 split groups): each thread sums every 4th split with
+// block = (64 outputs) x (4 split groups): each thread sums every 4th split with
 // 4 independent accumulators, then the 4 groups combine through LDS in fixed order.
+// Outputs [0,total) are weight-gradient entries, [total, total + nseg*Mpad) bias entries.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
   __shared__ float red[4][64];
   const long ncol = (long)a.ntile_n * BN;
   const long total = (long)a.ntile_m * BM * ncol;
+  const long mpad = (long)a.ntile_m * BM;
+  const long total_ext = total + (a.bslabs ? (long)a.nseg * mpad : 0);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long sstride = (long)a.ntile_m * a.ntile_n * (BM * BN);
-  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+  for (long base = (long)blockIdx.x * 64; base < total_ext; base += (long)gridDim.x * 64) {
     const long i = base + tx;
-    bool ok = i < total;
-    int colg = 0, row = 0, s = 0, ci = 0;
+    bool ok = i < total_ext;
+    const bool is_bias = i >= total;
+    int row = 0, s = 0, ci = 0;
     const float* p = a.slabs;
-    if (ok) {
-      colg = (int)(i % ncol);
+    long sstride = (long)a.ntile_m * a.ntile_n * (BM * BN);
+    if (ok && !is_bias) {
+      const int colg = (int)(i % ncol);
       row = (int)(i / ncol);
       const int ntg = colg / BN, col = colg % BN;
 #pragma unroll
@@ -479,6 +484,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
       ok = row < a.M && ci < a.seg[s].cin && a.seg[s].gw != nullptr;
       const int mt = row / BM, r = row % BM;
       p = a.slabs + ((long)mt * a.ntile_n + ntg) * (BM * BN) + r * BN + col;
+    } else if (ok) {
+      const long bi = i - total;
+      s = (int)(bi / mpad);
+      row = (int)(bi % mpad);
+      ok = row < a.M && (a.seg[s].gb || a.seg[s].gb2 || (s == 0 && a.ngbl > 0));
+      p = a.bslabs + (long)s * mpad + row;
+      sstride = (long)a.nseg * mpad;
     }
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (ok) {
@@ -495,21 +507,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     red[ty][tx] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (ty == 0 && ok) {
-      float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+      const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
       const WSeg& sg = a.seg[s];
-      float* dst = sg.gw + (long)row * sg.gw_co_stride + (long)ci * sg.gw_ci_stride;
-      if (a.accumulate) v += *dst;
-      *dst = v;
-    }
-  }
-  if (a.bslabs && blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < a.M; i += 256) {
-      float v = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) v += a.bslabs[(long)sp * a.ntile_m * BM + i];
-      if (a.gb) { a.gb[i] = a.accumulate ? a.gb[i] + v : v; }
-      if (a.gb2) { a.gb2[i] = a.accumulate ? a.gb2[i] + v : v; }
-      for (int l = 0; l < a.ngbl; ++l)
-        if (a.gbl[l]) a.gbl[l][i] = a.accumulate ? a.gbl[l][i] + v : v;
+      if (!is_bias) {
+        float* dst = sg.gw + (long)row * sg.gw_co_stride + (long)ci * sg.gw_ci_stride;
+        *dst = a.accumulate ? *dst + v : v;
+      } else {
+        if (sg.gb) sg.gb[row] = a.accumulate ? sg.gb[row] + v : v;
+        if (sg.gb2) sg.gb2[row] = a.accumulate ? sg.gb2[row] + v : v;
+        if (s == 0)
+          for (int l = 0; l < a.ngbl; ++l)
+            if (a.gbl[l]) a.gbl[l][row] = a.accumulate ? a.gbl[l][row] + v : v;
+      }
     }
   }
 }
@@ -575,16 +584,21 @@ static PackJob pack_bwd_job(float* dst, const float* W, int Cout, int Cin, int K
   return j;
 }
 
-struct WgradPlan { int ntile_m, ntile_n, nsplit_t, tchunk, nsplit; size_t slab_floats, bslab_floats; };
+struct WgradPlan { int ntile_m, ntile_n, nsplit_t, tchunk, nsplit, nseg; size_t slab_floats, bslab_floats; };
 
+// wgrad_kernel runs 2 workgroups per CU (205 VGPR): 512 resident slots on 256 CUs.
+// Choose the split count so that the grid is just under a whole number of rounds.
 static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   WgradPlan p;
+  p.nseg = nseg;
   p.ntile_m = cdiv(M, BM);
   p.ntile_n = 0;
   for (int i = 0; i < nseg; ++i) p.ntile_n += cdiv(cins[i], BN);
-  const long tiles = (long)p.ntile_m * p.ntile_n * B;
-  int want = (int)((1024 + tiles - 1) / tiles);
-  int maxs = Tout / 256;
+  const long tiles = (long)p.ntile_m * p.ntile_n;
+  const long per_t = tiles * B;                 // blocks per time split
+  const long target = per_t >= 256 ? 1024 : 512;
+  int want = (int)(target / per_t);
+  int maxs = Tout / 128;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -592,20 +606,22 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   p.nsplit_t = cdiv(Tout, p.tchunk);
   p.nsplit = p.nsplit_t * B;
   p.slab_floats = (size_t)p.nsplit * p.ntile_m * p.ntile_n * BM * BN;
-  p.bslab_floats = (size_t)p.nsplit * p.ntile_m * BM;
+  p.bslab_floats = (size_t)p.nsplit * nseg * p.ntile_m * BM;
   return p;
 }
 
 static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream_t st) {
   w.ntile_m = p.ntile_m; w.ntile_n = p.ntile_n; w.tchunk = p.tchunk; w.nsplit_t = p.nsplit_t;
   w.slabs = ws;
-  w.bslabs = (w.gb || w.gb2 || w.ngbl > 0) ? ws + p.slab_floats : nullptr;
+  bool any_b = w.ngbl > 0;
+  for (int i = 0; i < w.nseg; ++i) any_b = any_b || w.seg[i].gb || w.seg[i].gb2;
+  w.bslabs = any_b ? ws + p.slab_floats : nullptr;
   int t0 = 0;
   for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
   ProfScope ps(tag, st);
   hipLaunchKernelGGL(wgrad_kernel, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
-  const long total = (long)p.ntile_m * BM * p.ntile_n * BN;
+  const long total = (long)p.ntile_m * BM * p.ntile_n * BN + (long)p.nseg * p.ntile_m * BM;
   int nb = (int)((total + 63) / 64);
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, w, p.nsplit);
@@ -718,7 +734,7 @@ extern "C" int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* 
     sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
     sg.gw = gW + j; sg.gw_co_stride = (long)d->Cin * d->K; sg.gw_ci_stride = d->K;
   }
-  w.gb = gb; w.gb2 = nullptr; w.accumulate = accumulate;
+  w.seg[0].gb = gb; w.accumulate = accumulate;
   return launch_wgrad(w, p, (float*)ws, VQVAE_PROF_CONV_WGRAD, st);
 }
 
@@ -933,7 +949,7 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
     sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
     sc.tmul = 1; sc.toff = 0; sc.tdiv = 1;
     sc.gw = gr->gWc; sc.gw_co_stride = d->Cc; sc.gw_ci_stride = 1;
-    wa.gb = gr->gbd; wa.gb2 = gr->gbc; wa.accumulate = grads_accumulate;
+    wa.seg[0].gb = gr->gbd; wa.seg[0].gb2 = gr->gbc; wa.accumulate = grads_accumulate;
     if (int e = launch_wgrad(wa, L.p_h, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
   }
   // K6b / K6c: gWr, gbr from g_res ; gWs, gbs from g_skip
@@ -950,7 +966,7 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
     sg.x = z; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
     sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
     sg.gw = gW; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
-    wa.gb = gb; wa.accumulate = grads_accumulate;
+    wa.seg[0].gb = gb; wa.accumulate = grads_accumulate;
     if (int e = launch_wgrad(wa, which ? L.p_s : L.p_r, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
   }
   return 0;
@@ -982,7 +998,9 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
   int cz[MAXSEG];
   for (int i = 0; i < nblocks; ++i) cz[i] = Ch;
   WgradPlan p = plan_wgrad(d->Cs, d->B, d->T, cz, nblocks);
+  WgradPlan p2 = plan_wgrad(d->Cr, d->B, d->T, cz, nblocks);
   size_t wg = p.slab_floats + p.bslab_floats;
+  if (p2.slab_floats + p2.bslab_floats > wg) wg = p2.slab_floats + p2.bslab_floats;
   size_t m = skip_pk > gc_pk ? skip_pk : gc_pk;
   if (wg > m) m = wg;
   return m * sizeof(float) + 1024;
@@ -1076,6 +1094,39 @@ extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nbloc
     wa.gbl[l] = gbs ? gbs[l] : nullptr;
   }
   wa.ngbl = gbs ? nblocks : 0;
+  wa.accumulate = accumulate;
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+}
+
+// gWr_l (+)= g_res_l z_l^T, gbr_l (+)= rowsum(g_res_l) for every block whose g_res_l
+// is non-NULL -- one launch, each segment carrying its own output-gradient tensor.
+extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblocks,
+                                        const float* const* g_res, const float* const* z,
+                                        float* const* gWr, float* const* gbr, int accumulate,
+                                        void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_res_wgrad: 1..%d blocks", MAXSEG);
+  VQ_REQUIRE(g_res && z && gWr && ws, "resstack_res_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const int Ch = d->Cd / 2, T = d->T;
+  int cz[MAXSEG];
+  int n = 0;
+  WgradArgs wa; memset(&wa, 0, sizeof(wa));
+  for (int l = 0; l < nblocks; ++l) {
+    if (!g_res[l] || !gWr[l]) continue;
+    WSeg& sg = wa.seg[n];
+    sg.gy = g_res[l];
+    sg.x = z[l]; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
+    sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
+    sg.gw = gWr[l]; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
+    sg.gb = gbr ? gbr[l] : nullptr;
+    cz[n++] = Ch;
+  }
+  if (n == 0) return 0;
+  WgradPlan p = plan_wgrad(d->Cr, d->B, T, cz, n);
+  if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_res_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
+  wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cr * T; wa.M = d->Cr; wa.Tout = T; wa.B = d->B;
+  wa.nseg = n;
   wa.accumulate = accumulate;
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }

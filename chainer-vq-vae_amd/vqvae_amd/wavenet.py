@@ -150,6 +150,7 @@ class ResidualStackFunction(FunctionNode):
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb
+        g_ress = [None] * nb
         for i in range(nb - 1, -1, -1):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = ins[2 + 8 * i: 10 + 8 * i]
             d = self.descs[i]
@@ -157,10 +158,9 @@ class ResidualStackFunction(FunctionNode):
             prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
             need_gx = (i > 0) or (0 in indexes)
             gx = DeviceArray(h.shape, np.float32) if need_gx else None
-            gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(6)]
-            gp += [None, None]                 # skip conv grads: one launch for all blocks below
-            if g_res is None:
-                gp[4] = gp[5] = None           # residual output unused (last block)
+            gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(4)]
+            gp += [None, None, None, None]     # res / skip conv grads: one launch each, below
+            g_ress[i] = g_res                  # None for the last block: residual unused
             grd = _lib.ResblockGrads(*[_p(a) for a in gp])
             gh = DeviceArray((d.B, d.Cd, d.T), np.float32)
             ws = _rb_workspace(d)
@@ -183,7 +183,15 @@ class ResidualStackFunction(FunctionNode):
         zs = _lib.ptr_array([sv[2] for sv in self.saved])
         _lib.call('vqvae_resstack_skip_wgrad', C.byref(d), nb, g_skip.ptr, zs, _lib.ptr_array(gWs),
                   _lib.ptr_array(gbs), 0, ws.ptr, ws.nbytes, _S())
+        gWr = [None if g_ress[i] is None else
+               _grad_out(in_vars[2 + 8 * i + 4], ins[2 + 8 * i + 4].shape) for i in range(nb)]
+        gbr = [None if g_ress[i] is None else
+               _grad_out(in_vars[2 + 8 * i + 5], ins[2 + 8 * i + 5].shape) for i in range(nb)]
+        _lib.call('vqvae_resstack_res_wgrad', C.byref(d), nb, _lib.ptr_array(g_ress), zs,
+                  _lib.ptr_array(gWr), _lib.ptr_array(gbr), 0, ws.ptr, ws.nbytes, _S())
         for i in range(nb):
+            grads[2 + 8 * i + 4] = gWr[i]
+            grads[2 + 8 * i + 5] = gbr[i]
             grads[2 + 8 * i + 6] = gWs[i]
             grads[2 + 8 * i + 7] = gbs[i]
         self.saved = None                      # release activations

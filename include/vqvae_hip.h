@@ -163,6 +163,12 @@ int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
 int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nblocks, const float* g_skip,
                               const float* const* z, float* const* gWs, float* const* gbs,
                               int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
+/*      res_wgrad : gWr_l (+)= g_res_l z_l^T, gbr_l (+)= rowsum(g_res_l) for every l with
+ *      g_res[l] != NULL (the last block has none) -- one launch                      */
+int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblocks,
+                             const float* const* g_res, const float* const* z,
+                             float* const* gWr, float* const* gbr, int accumulate, void* ws,
+                             size_t ws_bytes, vqvae_stream_t s);
 
 /* ---- vector quantiser: StraightThrough.forward / backward (utils.py:176-231).
  *      z (B,d,T) [T contiguous], W (k,d).  idx (B,T) int32 is bit-exact with
