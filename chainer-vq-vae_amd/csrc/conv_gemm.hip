@@ -596,12 +596,21 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   for (int i = 0; i < nseg; ++i) p.ntile_n += cdiv(cins[i], BN);
   const long tiles = (long)p.ntile_m * p.ntile_n;
   const long per_t = tiles * B;                 // blocks per time split
-  const long target = per_t >= 256 ? 1024 : 512;
-  int want = (int)(target / per_t);
   int maxs = Tout / 128;
   if (maxs < 1) maxs = 1;
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
+  if (maxs > 32) maxs = 32;
+  // smallest split count whose grid fills >= 92 % of its last residency round
+  // (and at least one full round); otherwise the best fill found
+  const long slots = 512;
+  int want = 1;
+  double best = -1.0;
+  for (int w = 1; w <= maxs; ++w) {
+    const long blocks = per_t * w;
+    const long rounds = (blocks + slots - 1) / slots;
+    const double eff = (double)blocks / (double)(rounds * slots);
+    if (eff > best + 1e-9) { best = eff; want = w; }
+    if (eff >= 0.92 && blocks >= slots) { want = w; break; }
+  }
   p.tchunk = cdiv(cdiv(Tout, want), WBK) * WBK;
   p.nsplit_t = cdiv(Tout, p.tchunk);
   p.nsplit = p.nsplit_t * B;
