@@ -52,7 +52,13 @@ struct OutR {          // one row range of M
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_GATE_BWD = 2 };
 
+struct Lerp {           // epilogue add of an up-sampled latent-rate tensor (align-corners lerp)
+  const float* P; long p_bstride; int Tl;
+  const int* v0; const float* w0; const float* w1;
+};
+
 struct GemmArgs {
+  Lerp lerp;
   Seg seg[MAXSEG];
   int nseg;
   int M;         // logical rows (packed rows for EPI_GATE)
@@ -261,8 +267,17 @@ __global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
       for (int ni = 0; ni < 2; ++ni) {
         const int t = t0 + wn * 64 + ni * 32 + li;
         if (t >= T) continue;
-        const float ta = tanhf(acc[0][ni][r] + ba);
-        const float sb = sigmoidf_(acc[1][ni][r] + bb);
+        float pa = 0.f, pb = 0.f;
+        if (a.lerp.P) {      // h += upsample(P)[t]: condition projected at latent rate
+          const int v = a.lerp.v0[t];
+          const float w0 = a.lerp.w0[t], w1 = a.lerp.w1[t];
+          const float* pp = a.lerp.P + (long)b * a.lerp.p_bstride + (long)ch * a.lerp.Tl + v;
+          const float* pq = pp + (long)Ch * a.lerp.Tl;
+          pa = w0 * pp[0] + w1 * pp[1];
+          pb = w0 * pq[0] + w1 * pq[1];
+        }
+        const float ta = tanhf(acc[0][ni][r] + ba + pa);
+        const float sb = sigmoidf_(acc[1][ni][r] + bb + pb);
         float* gp = og.y + (long)b * og.y_bstride;
         gp[(long)ch * T + t] = ta;
         gp[(long)(Ch + ch) * T + t] = sb;
@@ -802,12 +817,14 @@ extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
 }
 
 extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
-                                  const float* x, const float* cond, float* res, float* skip,
+                                  const float* x, const float* cond,
+                                  const vqvae_resblock_cproj* cproj, float* res, float* skip,
                                   int skip_accumulate, float* gates, float* z, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
-  VQ_REQUIRE(p && x && cond && gates && z && ws, "resblock_fwd: null pointer");
-  VQ_REQUIRE(p->Wd && p->Wc && (skip == nullptr || p->Ws) && (res == nullptr || p->Wr), "resblock_fwd: null weight");
+  VQ_REQUIRE(p && x && (cond || cproj) && gates && z && ws, "resblock_fwd: null pointer");
+  VQ_REQUIRE(p->Wd && (cproj || p->Wc) && (skip == nullptr || p->Ws) && (res == nullptr || p->Wr), "resblock_fwd: null weight");
+  if (cproj) VQ_REQUIRE(cproj->P && cproj->v0 && cproj->w0 && cproj->w1 && cproj->Tl >= 2, "resblock_fwd: bad cproj");
   hipStream_t st = (hipStream_t)s;
   RbLayout L = rb_layout(d);
   if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
@@ -819,7 +836,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
 
   PackArgs pa; pa.njob = 0;
   pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p->Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
-  pa.job[pa.njob++] = pack_fwd_job(w + L.pk_c, p->Wc, d->Cd, d->Cc, 1, Ch, ldd, 0, ldd);
+  if (!cproj) pa.job[pa.njob++] = pack_fwd_job(w + L.pk_c, p->Wc, d->Cd, d->Cc, 1, Ch, ldd, 0, ldd);
   if (res && skip) {
     VQ_REQUIRE(d->Cr % 32 == 0, "resblock: residual_channels must be a multiple of 32 when res and skip share a launch");
     pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Wr, d->Cr, Ch, 1, 0, ldo, 0, d->Cr);
@@ -834,7 +851,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
   // K1: h = dilconv(x) + cond_proj(c) + biases -> gate
   {
     GemmArgs g; memset(&g, 0, sizeof(g));
-    g.nseg = d->K + 1;
+    g.nseg = d->K + (cproj ? 0 : 1);
     const int rp = pad16(d->Cr);
     for (int j = 0; j < d->K; ++j) {
       Seg& sg = g.seg[j];
@@ -842,11 +859,17 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
       sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
       sg.w = w + L.pk_d + (size_t)j * rp * ldd; sg.ldw = ldd;
     }
-    Seg& sc = g.seg[d->K];
-    sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
-    sc.tmul = 1; sc.toff = 0; sc.tdiv = 1; sc.w = w + L.pk_c; sc.ldw = ldd;
+    if (cproj) {      // condition projection (incl. its bias) arrives pre-computed at latent rate
+      g.lerp.P = cproj->P; g.lerp.p_bstride = cproj->P_bstride; g.lerp.Tl = cproj->Tl;
+      g.lerp.v0 = cproj->v0; g.lerp.w0 = cproj->w0; g.lerp.w1 = cproj->w1;
+    } else {
+      Seg& sc = g.seg[d->K];
+      sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
+      sc.tmul = 1; sc.toff = 0; sc.tdiv = 1; sc.w = w + L.pk_c; sc.ldw = ldd;
+    }
     g.M = d->Cd; g.Tout = T; g.B = d->B;
-    g.out[0].y = gates; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].bias = p->bd; g.out[0].bias2 = p->bc;
+    g.out[0].y = gates; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].bias = p->bd;
+    g.out[0].bias2 = cproj ? nullptr : p->bc;
     g.out[0].rows = d->Cd;
     g.out[1].y = z; g.out[1].y_bstride = (long)Ch * T;
     if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
@@ -881,7 +904,8 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
                                   const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
-  VQ_REQUIRE(p && x && cond && gates && z && g_skip && ws && gr, "resblock_bwd: null pointer");
+  VQ_REQUIRE(p && x && gates && z && g_skip && ws && gr, "resblock_bwd: null pointer");
+  VQ_REQUIRE(cond || (!gcond && !gr->gWc && !gr->gbc), "resblock_bwd: condition gradients requested without a condition tensor");
   hipStream_t st = (hipStream_t)s;
   RbLayout L = rb_layout(d);
   if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
@@ -947,19 +971,25 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
   if (gr->gWd || gr->gWc || gr->gbd || gr->gbc) {
     WgradArgs wa; memset(&wa, 0, sizeof(wa));
     wa.gy = gh; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
-    wa.nseg = d->K + 1;
+    wa.nseg = d->K + (cond ? 1 : 0);
     for (int j = 0; j < d->K; ++j) {
       WSeg& sg = wa.seg[j];
       sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
       sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
       sg.gw = gr->gWd ? gr->gWd + j : nullptr; sg.gw_co_stride = (long)d->Cr * d->K; sg.gw_ci_stride = d->K;
     }
-    WSeg& sc = wa.seg[d->K];
-    sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
-    sc.tmul = 1; sc.toff = 0; sc.tdiv = 1;
-    sc.gw = gr->gWc; sc.gw_co_stride = d->Cc; sc.gw_ci_stride = 1;
+    if (cond) {
+      WSeg& sc = wa.seg[d->K];
+      sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
+      sc.tmul = 1; sc.toff = 0; sc.tdiv = 1;
+      sc.gw = gr->gWc; sc.gw_co_stride = d->Cc; sc.gw_ci_stride = 1;
+    }
     wa.seg[0].gb = gr->gbd; wa.seg[0].gb2 = gr->gbc; wa.accumulate = grads_accumulate;
-    if (int e = launch_wgrad(wa, L.p_h, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
+    int cins2[MAXTAPS + 1];
+    for (int j = 0; j < d->K; ++j) cins2[j] = d->Cr;
+    cins2[d->K] = d->Cc;
+    WgradPlan ph = cond ? L.p_h : plan_wgrad(d->Cd, d->B, d->T, cins2, d->K);
+    if (int e = launch_wgrad(wa, ph, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
   }
   // K6b / K6c: gWr, gbr from g_res ; gWs, gbs from g_skip
   for (int which = 0; which < 2; ++which) {

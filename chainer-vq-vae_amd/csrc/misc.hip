@@ -84,7 +84,8 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, long gy_bstrid
                                     int Tin, int Tout, const float* __restrict__ w0,
                                     const float* __restrict__ w1, const int32_t* __restrict__ lo0,
                                     const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
-                                    const int32_t* __restrict__ hi1, float* __restrict__ gx) {
+                                    const int32_t* __restrict__ hi1, float* __restrict__ gx,
+                                    long gx_bstride) {
   const long total = (long)B * C * Tin;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
@@ -96,7 +97,31 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, long gy_bstrid
     double acc = 0.0;     // numpy.bincount(weights=...) accumulates in float64
     for (int t = lo0[v]; t < hi0[v]; ++t) acc += (double)__fmul_rn(g[t], w0[t]);
     for (int t = lo1[v]; t < hi1[v]; ++t) acc += (double)__fmul_rn(g[t], w1[t]);
-    gx[i] = (float)acc;
+    gx[b * gx_bstride + (long)c * Tin + v] = (float)acc;
+  }
+}
+
+// one workgroup per (b,c) row: the row is staged through LDS with coalesced loads, then
+// thread v sums its contributing outputs (fixed order => deterministic).
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
+    const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
+    const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
+    const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
+    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride) {
+  extern __shared__ float row[];            // index t + (t >> 5): breaks the 64-stride bank pattern
+  const int rows = B * C;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int b = r / C, c = r % C;
+    const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
+    __syncthreads();
+    for (int t = threadIdx.x; t < Tout; t += 256) row[t + (t >> 5)] = g[t];
+    __syncthreads();
+    for (int v = threadIdx.x; v < Tin; v += 256) {
+      double acc = 0.0;
+      for (int t = lo0[v]; t < hi0[v]; ++t) acc += (double)__fmul_rn(row[t + (t >> 5)], w0[t]);
+      for (int t = lo1[v]; t < hi1[v]; ++t) acc += (double)__fmul_rn(row[t + (t >> 5)], w1[t]);
+      gx[(long)b * gx_bstride + (long)c * Tin + v] = (float)acc;
+    }
   }
 }
 
@@ -186,6 +211,26 @@ __global__ void xent_bwd_kernel(const float* __restrict__ y, const int32_t* __re
   }
 }
 
+// ---- concat / split of equally sized parameter arrays ---------------------------
+struct PtrList32 { float* p[32]; };
+__global__ void concat_kernel(const PtrList32 src, int n, long count, float* __restrict__ dst) {
+  const long total = (long)n * count;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x)
+    dst[i] = src.p[i / count][i % count];
+}
+__global__ void split_kernel(const float* __restrict__ src, const PtrList32 dst, int n, long count,
+                             int accumulate) {
+  const long total = (long)n * count;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    float* d = dst.p[i / count];
+    if (!d) continue;
+    const long j = i % count;
+    d[j] = accumulate ? d[j] + src[i] : src[i];
+  }
+}
+
 // ---- Adam / EMA ------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float lr, float c1, float c2, float eps) {
@@ -248,10 +293,17 @@ int vqvae_upsample_linear_fwd(const float* x, int B, int C, int Tin, int Tout, c
 int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, int Tin, int Tout,
                               const float* w0, const float* w1, const int32_t* lo0,
                               const int32_t* hi0, const int32_t* lo1, const int32_t* hi1, float* gx,
-                              vqvae_stream_t s) {
+                              long gx_bstride, vqvae_stream_t s) {
   VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd: null pointer");
   const size_t n = (size_t)B * C * Tin;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx);
+  const size_t lds = ((size_t)Tout + Tout / 32 + 1) * sizeof(float);
+  if (lds <= 60 * 1024) {
+    int nb = B * C;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+  } else {
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+  }
   VQ_LAUNCH_CHECK();
   return 0;
 }
@@ -297,6 +349,25 @@ int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse, c
   VQ_REQUIRE(y && t && lse && gy, "softmax_xent_bwd: null pointer");
   const size_t n = (size_t)B * q * T;
   hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, y, t, lse, gloss, B, q, T, (float)(1.0 / ((double)B * T)), gy);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_concat(float* dst, const float* const* srcs, int n, size_t count, vqvae_stream_t s) {
+  VQ_REQUIRE(dst && srcs && n >= 1 && n <= 32, "concat: bad arguments (1..32 arrays)");
+  PtrList32 pl;
+  for (int i = 0; i < n; ++i) { VQ_REQUIRE(srcs[i], "concat: null source"); pl.p[i] = (float*)srcs[i]; }
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for((size_t)n * count)), dim3(256), 0, (hipStream_t)s, pl, n, (long)count, dst);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_split(const float* src, float* const* dsts, int n, size_t count, int accumulate,
+                vqvae_stream_t s) {
+  VQ_REQUIRE(src && dsts && n >= 1 && n <= 32, "split: bad arguments (1..32 arrays)");
+  PtrList32 pl;
+  for (int i = 0; i < n; ++i) pl.p[i] = dsts[i];
+  hipLaunchKernelGGL(split_kernel, dim3(grid_for((size_t)n * count)), dim3(256), 0, (hipStream_t)s, src, pl, n, (long)count, accumulate);
   VQ_LAUNCH_CHECK();
   return 0;
 }

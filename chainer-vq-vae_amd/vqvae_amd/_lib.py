@@ -33,6 +33,10 @@ class ResblockParams(C.Structure):
     _fields_ = [(n, P) for n in ('Wd', 'bd', 'Wc', 'bc', 'Wr', 'br', 'Ws', 'bs')]
 
 
+class ResblockCproj(C.Structure):
+    _fields_ = [('P', P), ('P_bstride', c_long), ('Tl', c_int), ('v0', P), ('w0', P), ('w1', P)]
+
+
 class ResblockGrads(C.Structure):
     _fields_ = [(n, P) for n in ('gWd', 'gbd', 'gWc', 'gbc', 'gWr', 'gbr', 'gWs', 'gbs')]
 
@@ -67,8 +71,8 @@ PROTOTYPES = {
     'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),
     'vqvae_conv1d_bwd_weight': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P]),
     'vqvae_resblock_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc)]),
-    'vqvae_resblock_fwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
-                                   c_int, P, P, P, c_size_t, P]),
+    'vqvae_resblock_fwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P,
+                                   C.POINTER(ResblockCproj), P, P, c_int, P, P, P, c_size_t, P]),
     'vqvae_resblock_bwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
                                    P, P, P, P, c_int, P, C.POINTER(ResblockGrads), c_int, P,
                                    c_size_t, P]),
@@ -87,7 +91,9 @@ PROTOTYPES = {
     'vqvae_vq_grad_w': (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     'vqvae_upsample_linear_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_long, P]),
     'vqvae_upsample_linear_bwd': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
-                                          P, P]),
+                                          P, c_long, P]),
+    'vqvae_concat': (c_int, [P, PP, c_int, c_size_t, P]),
+    'vqvae_split': (c_int, [P, PP, c_int, c_size_t, c_int, P]),
     'vqvae_embed_broadcast_fwd': (c_int, [P, P, c_int, c_int, c_int, P, c_long, P]),
     'vqvae_embed_broadcast_bwd': (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, P, c_int, P,
                                           c_size_t, P]),

@@ -311,15 +311,62 @@ def resize_tables(H, outH):
     return _resize_cache[key]
 
 
-class ConditionAssemble(FunctionNode):
-    def __init__(self, upscale):
-        self.upscale = int(upscale)
+class LazyUpsampled(DeviceArray):
+    """The (B, Cl+G, T, 1) condition tensor of net.py:54-63 in unmaterialised form: it
+    carries the latent-rate tensor ``latent`` (B, Cl+G, Tl) = [local | speaker broadcast]
+    and is only expanded to full rate when something reads ``.ptr``.  ResidualNet
+    consumes ``latent`` directly (condition projection at the latent rate)."""
+    __slots__ = ('latent', 'upscale', '_full', '_make')
 
-    def forward(self, inputs):
-        local, E, ids = inputs
-        backend.require_device(local, E, ids)
+    def __init__(self, shape, latent, upscale, make):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(np.float32)
+        self._block = None
+        self.latent = latent
+        self.upscale = upscale
+        self._full = None
+        self._make = make
+
+    def materialize(self):
+        if self._full is None:
+            self._full = self._make()
+        return self._full
+
+    @property
+    def ptr(self):
+        return self.materialize().ptr
+
+    def reshape(self, *shape):
+        return self.materialize().reshape(*shape)
+
+    def get(self):
+        return self.materialize().get()
+
+
+class LatentGrad(DeviceArray):
+    """Gradient w.r.t. a LazyUpsampled condition, already pulled back to the latent
+    rate (B, Cl+G, Tl) by the consumer.  Only ConditionAssemble.backward may take it."""
+    __slots__ = ('latent',)
+
+    def __init__(self, shape, latent):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(np.float32)
+        self._block = None
+        self.latent = latent
+
+    @property
+    def ptr(self):
+        raise RuntimeError('a latent-rate condition gradient cannot be read at full rate')
+
+
+class ConditionAssemble(FunctionNode):
+    def __init__(self, upscale, lazy=True):
+        self.upscale = int(upscale)
+        self.lazy = lazy
+
+    def _full(self, local, E, ids):
         B, Cl, Tl = local.shape[:3]
-        n_id, G = E.shape
+        G = E.shape[1]
         T = self.upscale * Tl
         out = DeviceArray((B, Cl + G, T, 1), np.float32)
         bs = (Cl + G) * T
@@ -327,22 +374,45 @@ class ConditionAssemble(FunctionNode):
         _lib.call('vqvae_upsample_linear_fwd', local.ptr, B, Cl, Tl, T, tb['v0'].ptr, tb['v1'].ptr,
                   tb['w0'].ptr, tb['w1'].ptr, out.ptr, bs, _S())
         _lib.call('vqvae_embed_broadcast_fwd', E.ptr, ids.ptr, B, G, T, out.ptr + Cl * T * 4, bs, _S())
+        return out
+
+    def forward(self, inputs):
+        local, E, ids = inputs
+        backend.require_device(local, E, ids)
+        B, Cl, Tl = local.shape[:3]
+        n_id, G = E.shape
+        T = self.upscale * Tl
         self._dims = (B, Cl, Tl, G, T, n_id)
         self._ids = ids
         self._local_shape = local.shape
-        return out,
+        if not self.lazy or Tl < 2:
+            return self._full(local, E, ids),
+        # latent-rate condition [local | speaker] (B, Cl+G, Tl)
+        lat = DeviceArray((B, Cl + G, Tl), np.float32)
+        bs = (Cl + G) * Tl
+        tb = resize_tables(Tl, Tl)                # identity resize == strided copy into the slice
+        _lib.call('vqvae_upsample_linear_fwd', local.ptr, B, Cl, Tl, Tl, tb['v0'].ptr, tb['v1'].ptr,
+                  tb['w0'].ptr, tb['w1'].ptr, lat.ptr, bs, _S())
+        _lib.call('vqvae_embed_broadcast_fwd', E.ptr, ids.ptr, B, G, Tl, lat.ptr + Cl * Tl * 4, bs, _S())
+        return LazyUpsampled((B, Cl + G, T, 1), lat, self.upscale,
+                             lambda: self._full(local, E, ids)),
 
     def backward(self, indexes, gys):
         B, Cl, Tl, G, T, n_id = self._dims
         g = gys[0].data
-        bs = (Cl + G) * T
-        tb = resize_tables(Tl, T)
         gl = DeviceArray(self._local_shape, np.float32)
-        _lib.call('vqvae_upsample_linear_bwd', g.ptr, bs, B, Cl, Tl, T, tb['w0'].ptr, tb['w1'].ptr,
-                  tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr, gl.ptr, _S())
         gE = DeviceArray((n_id, G), np.float32)
         ws = backend.workspace(B * G * 4)
-        _lib.call('vqvae_embed_broadcast_bwd', g.ptr + Cl * T * 4, bs, self._ids.ptr, B, G, T, n_id,
+        if isinstance(g, LatentGrad):
+            g = g.latent
+            Tg = Tl
+        else:
+            Tg = T
+        bs = (Cl + G) * Tg
+        tb = resize_tables(Tl, Tg)
+        _lib.call('vqvae_upsample_linear_bwd', g.ptr, bs, B, Cl, Tl, Tg, tb['w0'].ptr, tb['w1'].ptr,
+                  tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr, gl.ptr, Cl * Tl, _S())
+        _lib.call('vqvae_embed_broadcast_bwd', g.ptr + Cl * Tg * 4, bs, self._ids.ptr, B, G, Tg, n_id,
                   gE.ptr, 0, ws.ptr, ws.nbytes, _S())
         return gl, gE, None
 

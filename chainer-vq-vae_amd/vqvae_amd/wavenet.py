@@ -58,8 +58,8 @@ class ResidualBlockFunction(FunctionNode):
         self.gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
         self.z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
         ws = _rb_workspace(d)
-        _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), x.ptr, cond.ptr, res.ptr, skip.ptr,
-                  0, self.gates.ptr, self.z.ptr, ws.ptr, ws.nbytes, _S())
+        _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), x.ptr, cond.ptr, None, res.ptr,
+                  skip.ptr, 0, self.gates.ptr, self.z.ptr, ws.ptr, ws.nbytes, _S())
         self.retain_inputs(tuple(range(10)))
         return res, skip
 
@@ -116,6 +116,24 @@ class ResidualStackFunction(FunctionNode):
         assert len(inputs) == 2 + 8 * nb
         self.descs, self.saved = [], []
         h = x
+        # condition projection at the latent rate (see vqvae_resblock_cproj in the header)
+        self.lat = None
+        if isinstance(cond, F.LazyUpsampled) and nb <= 32:
+            self.lat = lat = cond.latent                       # (B, Cc, Tl)
+            B, Cc, Tl = lat.shape
+            Cd = inputs[2].shape[0]
+            self.Wc_all = DeviceArray((nb * Cd, Cc, 1, 1), np.float32)
+            bc_all = DeviceArray((nb * Cd,), np.float32)
+            _lib.call('vqvae_concat', self.Wc_all.ptr, _lib.ptr_array([inputs[2 + 8 * i + 2] for i in range(nb)]),
+                      nb, Cd * Cc, _S())
+            _lib.call('vqvae_concat', bc_all.ptr, _lib.ptr_array([inputs[2 + 8 * i + 3] for i in range(nb)]),
+                      nb, Cd, _S())
+            self.pdesc = _lib.Conv1dDesc(B, Cc, Tl, nb * Cd, Tl, 1, 1, 0, 1, 0)
+            P_all = DeviceArray((B, nb * Cd, Tl), np.float32)
+            ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
+            _lib.call('vqvae_conv1d_fwd', C.byref(self.pdesc), lat.ptr, self.Wc_all.ptr, bc_all.ptr,
+                      P_all.ptr, ws.ptr, ws.nbytes, _S())
+            tb = F.resize_tables(Tl, x.shape[2])
         for i, dil in enumerate(self.dilations):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs[2 + 8 * i: 10 + 8 * i]
             d = _rb_desc(h, cond, Wd, Ws, dil)
@@ -125,8 +143,14 @@ class ResidualStackFunction(FunctionNode):
             gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
             z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
             ws = _rb_workspace(d)
-            _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, _p(res),
-                      None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
+            if self.lat is not None:
+                cp = _lib.ResblockCproj(P_all.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, Tl,
+                                        tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
+                _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, None, C.byref(cp),
+                          _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
+            else:
+                _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, None,
+                          _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
             self.descs.append(d)
             self.saved.append((h, gates, z))
             h = res
@@ -145,6 +169,7 @@ class ResidualStackFunction(FunctionNode):
         in_vars = self.get_retained_inputs()
         ins = [v.data for v in in_vars]
         cond = ins[1]
+        lat = self.lat
         g_skip = gys[0].data
         nb = len(self.dilations)
         grads = [None] * len(ins)
@@ -159,12 +184,15 @@ class ResidualStackFunction(FunctionNode):
             need_gx = (i > 0) or (0 in indexes)
             gx = DeviceArray(h.shape, np.float32) if need_gx else None
             gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(4)]
+            if lat is not None:
+                gp[2] = gp[3] = None           # condition_proj grads: one latent-rate conv, below
             gp += [None, None, None, None]     # res / skip conv grads: one launch each, below
             g_ress[i] = g_res                  # None for the last block: residual unused
             grd = _lib.ResblockGrads(*[_p(a) for a in gp])
             gh = DeviceArray((d.B, d.Cd, d.T), np.float32)
             ws = _rb_workspace(d)
-            _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, gates.ptr,
+            _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr,
+                      None if lat is not None else cond.ptr, gates.ptr,
                       z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(grd), 0,
                       ws.ptr, ws.nbytes, _S())
             grads[2 + 8 * i: 10 + 8 * i] = gp
@@ -172,7 +200,36 @@ class ResidualStackFunction(FunctionNode):
             g_res = gx
         d = self.descs[0]
         ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
-        if 1 in indexes:
+        if lat is not None:
+            # pull every block's gh back to the latent rate (adjoint of the epilogue lerp), then
+            # the (nb*Cd, Cc) 1x1 conv's own backward gives gWc_l, gbc_l and the condition grad
+            B, Cc, Tl = lat.shape
+            T = d.T
+            tb = F.resize_tables(Tl, T)
+            gP = DeviceArray((B, nb * d.Cd, Tl), np.float32)
+            for i in range(nb):
+                _lib.call('vqvae_upsample_linear_bwd', ghs[i].ptr, d.Cd * T, B, d.Cd, Tl, T,
+                          tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
+                          tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, _S())
+            wsc = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
+            gWc_all = DeviceArray(self.Wc_all.shape, np.float32)
+            gbc_all = DeviceArray((nb * d.Cd,), np.float32)
+            _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.pdesc), lat.ptr, gP.ptr, gWc_all.ptr,
+                      gbc_all.ptr, 0, wsc.ptr, wsc.nbytes, _S())
+            gWc = [_grad_out(in_vars[2 + 8 * i + 2], ins[2 + 8 * i + 2].shape) for i in range(nb)]
+            gbc = [_grad_out(in_vars[2 + 8 * i + 3], ins[2 + 8 * i + 3].shape) for i in range(nb)]
+            _lib.call('vqvae_split', gWc_all.ptr, _lib.ptr_array(gWc), nb, d.Cd * Cc, 0, _S())
+            _lib.call('vqvae_split', gbc_all.ptr, _lib.ptr_array(gbc), nb, d.Cd, 0, _S())
+            for i in range(nb):
+                grads[2 + 8 * i + 2] = gWc[i]
+                grads[2 + 8 * i + 3] = gbc[i]
+            if 1 in indexes:
+                glat = DeviceArray(lat.shape, np.float32)
+                _lib.call('vqvae_conv1d_bwd_data', C.byref(self.pdesc), self.Wc_all.ptr, gP.ptr,
+                          glat.ptr, 0, wsc.ptr, wsc.nbytes, _S())
+                grads[1] = F.LatentGrad(cond.shape, glat)
+            ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
+        elif 1 in indexes:
             gcond = DeviceArray(cond.shape, np.float32)
             Wc = _lib.ptr_array([ins[2 + 8 * i + 2] for i in range(nb)])
             _lib.call('vqvae_resstack_gcond_bwd', C.byref(d), nb, Wc, _lib.ptr_array(ghs), gcond.ptr,

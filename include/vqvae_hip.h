@@ -127,16 +127,32 @@ typedef struct {            /* gradients, same layouts; any pair may be NULL    
   float *gWd, *gbd, *gWc, *gbc, *gWr, *gbr, *gWs, *gbs;
 } vqvae_resblock_grads;
 
+/* Optional: the condition projection computed ONCE at the latent rate.  Up-sampling
+ * (net.py:54-55) is linear and acts per channel, so condition_proj(upsample(c)) ==
+ * upsample(condition_proj(c)): ResidualNet projects the (B,Cc,Tl) latent-rate
+ * condition through all blocks' 1x1 convs in one small GEMM and each block adds the
+ * align-corners lerp of its (B,Cd,Tl) slice P in the gate epilogue (v0/w0/w1 are the
+ * resize tables for Tl -> T, v1 == v0+1).  Removes Cc of K*Cr+Cc contraction steps. */
+typedef struct {
+  const float* P;        /* (B, Cd, Tl) incl. the bias bc; batch stride P_bstride      */
+  long P_bstride;
+  int Tl;
+  const int32_t* v0; const float* w0; const float* w1;
+} vqvae_resblock_cproj;
+
 size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d);
 /* res may be NULL (last block: residual unused, modules.py:89-96).  skip is
  * overwritten, or accumulated into when skip_accumulate != 0 (modules.py:92-95);
  * skip may be NULL too (ResidualNet computes the skip sum with vqvae_resstack_skip_fwd).
- * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd. */
+ * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd.
+ * With cproj != NULL, cond / Wc / bc are ignored (may be NULL).                       */
 int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
-                       const float* x, const float* cond, float* res, float* skip,
+                       const float* x, const float* cond, const vqvae_resblock_cproj* cproj,
+                       float* res, float* skip,
                        int skip_accumulate, float* gates, float* z, void* ws,
                        size_t ws_bytes, vqvae_stream_t s);
-/* g_res may be NULL; gx may be NULL; gcond (B,Cc,T) may be NULL and is accumulated
+/* g_res may be NULL; gx may be NULL; cond may be NULL (cproj mode: then gcond, gWc, gbc
+ * must be NULL); gcond (B,Cc,T) may be NULL and is accumulated
  * into when gcond_accumulate != 0; gh_out (B,Cd,T), if not NULL, receives the
  * gradient w.r.t. the pre-gate activation h (kept by ResidualNet for the stack-level
  * condition gradient); parameter grads are accumulated when grads_accumulate. */
@@ -204,7 +220,7 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               int Tout, const float* w0, const float* w1,
                               const int32_t* lo0, const int32_t* hi0,
                               const int32_t* lo1, const int32_t* hi1,
-                              float* gx, vqvae_stream_t s);
+                              float* gx, long gx_bstride, vqvae_stream_t s);
 
 /* ---- L.EmbedID + broadcast along T (net.py:57-61): y[b,c,t] = E[id[b],c]      */
 int vqvae_embed_broadcast_fwd(const float* E, const int32_t* ids, int B, int G, int T,
@@ -242,6 +258,13 @@ int vqvae_elementwise(int op, size_t n, const float* a, const float* b, float* o
 /* out[0] = scale * sum(x[0..n)) (deterministic two-stage); ws >= 4096 floats     */
 int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws,
               size_t ws_bytes, vqvae_stream_t s);
+
+/* ---- gather n (<= 32) equally sized arrays (host array of device pointers) into one
+ *      contiguous array and back (NULL destinations are skipped): lets ResidualNet
+ *      treat its blocks' condition_proj parameters as one (n*Cd, Cc) 1x1 conv.       */
+int vqvae_concat(float* dst, const float* const* srcs, int n, size_t count, vqvae_stream_t s);
+int vqvae_split(const float* src, float* const* dsts, int n, size_t count, int accumulate,
+                vqvae_stream_t s);
 
 /* ---- chainer.optimizers.Adam update rule (train.py:101-102) over a flat arena:
  *      m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m/(sqrt(v)+eps)

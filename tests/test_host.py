@@ -43,7 +43,7 @@ def test_argument_validation_without_device():
     assert lib.vqvae_conv1d_fwd(C.byref(d), 8, 8, None, 8, 8, 1 << 20, None) == -1
     rb = _lib.ResblockDesc(1, 16, 8, 40, 8, 4, 2, 1)              # Cd/2 not a multiple of 32
     assert lib.vqvae_resblock_workspace_bytes(C.byref(rb)) > 0
-    assert lib.vqvae_resblock_fwd(C.byref(rb), None, 8, 8, 8, 8, 0, 8, 8, 8, 1 << 30, None) == -1
+    assert lib.vqvae_resblock_fwd(C.byref(rb), None, 8, 8, None, 8, 8, 0, 8, 8, 8, 1 << 30, None) == -1
     assert lib.vqvae_vq_nearest_fwd(None, None, 1, 1, 1, 1, 0, None, None, None, None, 0, None) == -1
     with pytest.raises(_lib.HipError):
         _lib.call('vqvae_sum', None, 4, 1.0, None, None, 0, None)

@@ -40,8 +40,8 @@ def main():
     backend.synchronize()
     lib.vqvae_prof_enable(0)
     BT = B * cfg['length']
-    flops = {1: 2.0 * BT * 256 * 704, 2: 2.0 * BT * 512 * 128, 3: 2.0 * BT * 128 * 512,
-             4: 2.0 * BT * 256 * 512, 5: 2.0 * BT * 192 * 256}
+    flops = {1: 2.0 * BT * 256 * 512, 2: 2.0 * BT * 512 * 128, 3: 2.0 * BT * 128 * 512,
+             4: 2.0 * BT * 256 * 512}
     tot_all = 0
     for tag in sorted(NAMES):
         tot = C.c_double(0)
