@@ -101,27 +101,78 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, long gy_bstrid
   }
 }
 
-// one workgroup per (b,c) row: the row is staged through LDS with coalesced loads, then
-// thread v sums its contributing outputs (fixed order => deterministic).
+// one workgroup per (b,c) row: the weighted row (g*w0 | g*w1) is staged through LDS with
+// coalesced loads, then thread (v, part) sums one contributing range with four
+// independent fp64 accumulators in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
     const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
     const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
     const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
     const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride) {
-  extern __shared__ float row[];            // index t + (t >> 5): breaks the 64-stride bank pattern
+  extern __shared__ float sm[];             // [2][Tpad] products, index t + (t >> 5)
+  const int Tpad = Tout + (Tout >> 5) + 1;
+  float* r0 = sm;
+  float* r1 = sm + Tpad;
+  double* ps = (double*)(sm + 2 * Tpad + (Tpad & 1));   // [2][Tin] partial sums
   const int rows = B * C;
+  const bool vec = (Tout % 4 == 0) && (gy_bstride % 4 == 0) && (((uintptr_t)gy) % 16 == 0) &&
+                   (((uintptr_t)w0) % 16 == 0) && (((uintptr_t)w1) % 16 == 0);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int b = r / C, c = r % C;
     const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
     __syncthreads();
-    for (int t = threadIdx.x; t < Tout; t += 256) row[t + (t >> 5)] = g[t];
-    __syncthreads();
-    for (int v = threadIdx.x; v < Tin; v += 256) {
-      double acc = 0.0;
-      for (int t = lo0[v]; t < hi0[v]; ++t) acc += (double)__fmul_rn(row[t + (t >> 5)], w0[t]);
-      for (int t = lo1[v]; t < hi1[v]; ++t) acc += (double)__fmul_rn(row[t + (t >> 5)], w1[t]);
-      gx[(long)b * gx_bstride + (long)c * Tin + v] = (float)acc;
+    if (vec) {     // 16-B loads, eight in flight per thread before the first LDS write
+      const int n4 = Tout >> 2;
+      for (int base = 0; base < n4; base += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int q = base + k * 256 + threadIdx.x;
+          v[k] = q < n4 ? reinterpret_cast<const float4*>(g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int q = base + k * 256 + threadIdx.x;
+          if (q < n4) {
+            const int t = q << 2;
+            const float4 a = reinterpret_cast<const float4*>(w0)[q];
+            const float4 bq = reinterpret_cast<const float4*>(w1)[q];
+            const int o = t + (t >> 5);          // 4 consecutive t never straddle a 32-block
+            r0[o] = __fmul_rn(v[k].x, a.x); r0[o + 1] = __fmul_rn(v[k].y, a.y);
+            r0[o + 2] = __fmul_rn(v[k].z, a.z); r0[o + 3] = __fmul_rn(v[k].w, a.w);
+            r1[o] = __fmul_rn(v[k].x, bq.x); r1[o + 1] = __fmul_rn(v[k].y, bq.y);
+            r1[o + 2] = __fmul_rn(v[k].z, bq.z); r1[o + 3] = __fmul_rn(v[k].w, bq.w);
+          }
+        }
+      }
+    } else {
+      for (int t = threadIdx.x; t < Tout; t += 256) {
+        const float v = g[t];
+        r0[t + (t >> 5)] = __fmul_rn(v, w0[t]);
+        r1[t + (t >> 5)] = __fmul_rn(v, w1[t]);
+      }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * Tin; i += 256) {
+      const int part = i >= Tin ? 1 : 0;
+      const int v = part ? i - Tin : i;
+      const float* rr = part ? r1 : r0;
+      const int lo = part ? lo1[v] : lo0[v];
+      const int hi = part ? hi1[v] : hi0[v];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int t = lo;
+      for (; t + 3 < hi; t += 4) {
+        a0 += (double)rr[t + (t >> 5)];
+        a1 += (double)rr[t + 1 + ((t + 1) >> 5)];
+        a2 += (double)rr[t + 2 + ((t + 2) >> 5)];
+        a3 += (double)rr[t + 3 + ((t + 3) >> 5)];
+      }
+      for (; t < hi; ++t) a0 += (double)rr[t + (t >> 5)];
+      ps[part * Tin + v] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < Tin; v += 256)
+      gx[(long)b * gx_bstride + (long)c * Tin + v] = (float)(ps[v] + ps[Tin + v]);
   }
 }
 
@@ -296,10 +347,12 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               long gx_bstride, vqvae_stream_t s) {
   VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd: null pointer");
   const size_t n = (size_t)B * C * Tin;
-  const size_t lds = ((size_t)Tout + Tout / 32 + 1) * sizeof(float);
-  if (lds <= 60 * 1024) {
+  const size_t tpad = (size_t)Tout + Tout / 32 + 1;
+  const size_t lds = (2 * tpad + 2) * sizeof(float) + 2 * (size_t)Tin * sizeof(double);
+  if (lds <= 96 * 1024) {
     int nb = B * C;
     if (nb > 8192) nb = 8192;
+    VQ_CHECK_HIP(hipFuncSetAttribute((const void*)upsample_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   } else {
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
