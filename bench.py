@@ -139,6 +139,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=CFG['batch_per_gpu'])
+    ap.add_argument('--force-comm', action='store_true',
+                    help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
     cfg = dict(CFG)
     cfg['batch_per_gpu'] = args.batch
@@ -155,7 +157,7 @@ def main():
     from vqvae_amd import _lib, backend
     from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
     backend.init(local)
-    comm = RcclCommunicator(rank, n, local) if n > 1 else SingleCommunicator()
+    comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
 
     model, opt = build(cfg, n)
     model.to_gpu(local)
@@ -227,7 +229,7 @@ def main():
         if n == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if n > 1:
+    if n > 1 or args.force_comm:
         comm.barrier()
         comm.close()
 

@@ -16,6 +16,7 @@ logic, never on the GPU path.
 """
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -53,6 +54,8 @@ def _rendezvous_path():
 
 
 class RcclCommunicator(object):
+    always_reduce = True      # a 1-rank communicator still exercises the all-reduce (self-test)
+
     def __init__(self, rank=None, size=None, device=None, timeout=300.0):
         from . import _lib, backend
         self.rank = int(os.environ.get('RANK', 0)) if rank is None else rank
@@ -78,7 +81,16 @@ class RcclCommunicator(object):
                 raw = f.read()
             idbuf = C.create_string_buffer(raw, 128)
         comm = C.c_void_p()
-        _lib.call('vqvae_comm_init', C.byref(comm), self.size, self.rank, idbuf)
+        # RCCL prints a version banner on first init; keep stdout clean for callers that
+        # parse it (bench.py prints exactly one JSON line): route fd 1 to stderr meanwhile
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            _lib.call('vqvae_comm_init', C.byref(comm), self.size, self.rank, idbuf)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         self._comm = comm
         self._scalar = backend.zeros((1,), np.float32)
         self.barrier()

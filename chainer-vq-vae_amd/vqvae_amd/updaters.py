@@ -96,7 +96,7 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         loss2.backward()
         loss3.backward()
 
-        if n > 1:
+        if n > 1 or getattr(self.comm, 'always_reduce', False):
             self.comm.allreduce_grad(optimizer.grads)
 
         optimizer.update()
