@@ -206,6 +206,14 @@ def main():
         flop = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
         avg_ms = tot.value / max(cnt.value, 1)
         ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
+        # HBM bytes per launch of the same kernel: PMC counters cannot be read from inside this
+        # process, so the figure comes from the committed rocprofv3 --pmc summary of this command
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r1_roofline.json')) as fh:
+                traffic = json.load(fh)['per_launch']['hbm_traffic_bytes']
+        except Exception:
+            pass
         out = {
             'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
             'value': value, 'unit': 'samples/s', 'n_gpus': n, 'steps': args.steps,
@@ -223,7 +231,8 @@ def main():
                          'tanh*sigmoid gate)',
                          'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
-                         'traffic': None, 'launches': cnt.value, 'avg_launch_ms': avg_ms,
+                         'traffic': traffic, 'traffic_source': 'profiles/r1_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)',
+                         'launches': cnt.value, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop},
         }
         if n == 1 and not args.no_cpu_baseline:

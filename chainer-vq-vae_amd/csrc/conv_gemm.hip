@@ -1047,8 +1047,8 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
 
 extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                                        const float* const* Ws, const float* const* bs,
-                                       const float* const* z, float* skip, void* ws,
-                                       size_t ws_bytes, vqvae_stream_t s) {
+                                       const float* const* z, float* skip, int accumulate,
+                                       void* ws, size_t ws_bytes, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_fwd: 1..%d blocks", MAXSEG);
   VQ_REQUIRE(Ws && bs && z && skip && ws, "resstack_skip_fwd: null pointer");
@@ -1077,6 +1077,7 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   g.M = d->Cs; g.Tout = T; g.B = d->B;
   g.out[0].y = skip; g.out[0].y_bstride = (long)d->Cs * T; g.out[0].rows = d->Cs;
   g.out[0].bias = bsum;
+  g.out[0].accumulate = accumulate;
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st);
 }
 

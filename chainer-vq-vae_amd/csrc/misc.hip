@@ -262,6 +262,88 @@ __global__ void xent_bwd_kernel(const float* __restrict__ y, const int32_t* __re
   }
 }
 
+// ---- discretised mixture-of-logistics NLL (WaveNet.calculate_logistic_loss,
+//      modules.py:169-230).  Thread per (b,t); the 3*nmix channels are strided by T so
+//      every load is coalesced along t.  MODE 0: per-position loss -> block partial sums;
+//      MODE 1: gradient w.r.t. y.  Same op sequence as the oracle (tanh-form sigmoid,
+//      softplus = max(x,0) + log1p(exp(-|x|))).
+__device__ __forceinline__ float sig_(float x) { return tanhf(x * 0.5f) * 0.5f + 0.5f; }
+__device__ __forceinline__ float softplus_(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void mol_kernel(const float* __restrict__ y, const float* __restrict__ tg,
+                                                  int B, int nmix, int T, float half, float ls_min,
+                                                  const float* __restrict__ gloss, float scale,
+                                                  float* __restrict__ partial, float* __restrict__ gy) {
+  __shared__ float sh[4];
+  constexpr int MAXM = 16;
+  const long N = (long)B * T;
+  float lacc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+       i += (long)gridDim.x * blockDim.x) {
+    const long b = i / T;
+    const int t = (int)(i % T);
+    const float* yp = y + b * 3L * nmix * T + t;
+    const float tt = 127.5f * tg[i];
+    const bool left = tt < 127.5f * -0.999f, right = tt > 127.5f * 0.999f;
+    float lp[MAXM], v[MAXM], dpl[MAXM], dmi[MAXM], pin[MAXM], mii[MAXM], istd[MAXM];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) if (k < nmix) { lp[k] = yp[(long)k * T]; m = fmaxf(m, lp[k]); }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) if (k < nmix) se += expf(lp[k] - m);
+    const float lz = logf(se) + m;                       // log-sum-exp of the mixture logits
+    float vm = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) if (k < nmix) {
+      const float mu = yp[(long)(nmix + k) * T];
+      const float ls = fmaxf(yp[(long)(2 * nmix + k) * T], ls_min);
+      const float c = tt - mu;
+      const float is = expf(-ls);
+      const float p = is * (c + half), q = is * (c - half);
+      const float cp = sig_(p), cm = sig_(q);
+      const float cd = cp - cm;
+      float lpr;
+      if (left) { lpr = p - softplus_(p); dpl[k] = 1.f - cp; dmi[k] = 0.f; }
+      else if (right) { lpr = -softplus_(q); dpl[k] = 0.f; dmi[k] = -cm; }
+      else {
+        lpr = logf(fmaxf(cd, 1e-12f));
+        const float inv = cd >= 1e-12f ? 1.f / fmaxf(cd, 1e-12f) : 0.f;
+        dpl[k] = inv * cp * (1.f - cp);
+        dmi[k] = -inv * cm * (1.f - cm);
+      }
+      pin[k] = p; mii[k] = q; istd[k] = is;
+      v[k] = lpr + (lp[k] - lz);
+      vm = fmaxf(vm, v[k]);
+    }
+    float sv = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) if (k < nmix) sv += expf(v[k] - vm);
+    const float lse = logf(sv) + vm;
+    if (MODE == 0) {
+      lacc += lse;
+    } else {
+      const float gs = -(gloss ? gloss[0] : 1.f) * scale;      // d loss / d lse
+      float* gp = gy + b * 3L * nmix * T + t;
+      float gsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXM; ++k) if (k < nmix) { v[k] = gs * expf(v[k] - lse); gsum += v[k]; }
+#pragma unroll
+      for (int k = 0; k < MAXM; ++k) if (k < nmix) {
+        gp[(long)k * T] = v[k] - expf(lp[k] - lz) * gsum;
+        gp[(long)(nmix + k) * T] = v[k] * (dpl[k] + dmi[k]) * (-istd[k]);
+        const float gl = v[k] * (dpl[k] * (-pin[k]) + dmi[k] * (-mii[k]));
+        gp[(long)(2 * nmix + k) * T] = yp[(long)(2 * nmix + k) * T] >= ls_min ? gl : 0.f;
+      }
+    }
+  }
+  if (MODE == 0) {
+    const float tot = block_sum_256(lacc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  }
+}
+
 // ---- concat / split of equally sized parameter arrays ---------------------------
 struct PtrList32 { float* p[32]; };
 __global__ void concat_kernel(const PtrList32 src, int n, long count, float* __restrict__ dst) {
@@ -402,6 +484,35 @@ int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse, c
   VQ_REQUIRE(y && t && lse && gy, "softmax_xent_bwd: null pointer");
   const size_t n = (size_t)B * q * T;
   hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, y, t, lse, gloss, B, q, T, (float)(1.0 / ((double)B * T)), gy);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_mol_nll_fwd(const float* y, const float* t, int B, int n_mixture, int T, int quantize,
+                      float log_scale_min, float* loss, void* ws, size_t ws_bytes,
+                      vqvae_stream_t s) {
+  VQ_REQUIRE(y && t && loss && ws, "mol_nll_fwd: null pointer");
+  VQ_REQUIRE(n_mixture >= 1 && n_mixture <= 16 && quantize >= 2, "mol_nll_fwd: 1..16 mixtures supported");
+  if (ws_bytes < 4096 * 4) { set_error("mol_nll_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  const size_t N = (size_t)B * T;
+  const int np = grid_for(N, 256, 1024);
+  hipLaunchKernelGGL(mol_kernel<0>, dim3(np), dim3(256), 0, (hipStream_t)s, y, t, B, n_mixture, T,
+                     (float)(127.5 / (quantize - 1)), log_scale_min, (const float*)nullptr, 0.f,
+                     (float*)ws, (float*)nullptr);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, (float)(-1.0 / (double)N), loss);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_mol_nll_bwd(const float* y, const float* t, const float* gloss, int B, int n_mixture,
+                      int T, int quantize, float log_scale_min, float* gy, vqvae_stream_t s) {
+  VQ_REQUIRE(y && t && gy, "mol_nll_bwd: null pointer");
+  VQ_REQUIRE(n_mixture >= 1 && n_mixture <= 16 && quantize >= 2, "mol_nll_bwd: 1..16 mixtures supported");
+  const size_t N = (size_t)B * T;
+  hipLaunchKernelGGL(mol_kernel<1>, dim3(grid_for(N, 256, 2048)), dim3(256), 0, (hipStream_t)s, y, t, B,
+                     n_mixture, T, (float)(127.5 / (quantize - 1)), log_scale_min, gloss,
+                     (float)(1.0 / (double)N), (float*)nullptr, gy);
   VQ_LAUNCH_CHECK();
   return 0;
 }

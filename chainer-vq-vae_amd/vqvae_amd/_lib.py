@@ -77,8 +77,8 @@ PROTOTYPES = {
                                    P, P, P, P, c_int, P, C.POINTER(ResblockGrads), c_int, P,
                                    c_size_t, P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
-    'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, P, c_size_t,
-                                        P]),
+    'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
+                                        c_size_t, P]),
     'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
                                          c_size_t, P]),
     'vqvae_resstack_skip_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, P, PP, PP, PP, c_int, P,
@@ -100,6 +100,8 @@ PROTOTYPES = {
     'vqvae_softmax_xent_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vqvae_softmax_xent_fwd': (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     'vqvae_softmax_xent_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
+    'vqvae_mol_nll_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
+    'vqvae_mol_nll_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
     'vqvae_elementwise': (c_int, [c_int, c_size_t, P, P, P, c_float, c_float, P]),
     'vqvae_sum': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'vqvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, P]),
@@ -112,6 +114,7 @@ PROTOTYPES = {
 }
 
 # elementwise op codes / profiler tags (mirror the header)
+MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gemm.hip)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
     EW_MUL_SCALAR_DEV = range(10)
 PROF_RESBLOCK_GATE, PROF_RESBLOCK_OUT, PROF_RESBLOCK_BWD_GZ, PROF_RESBLOCK_BWD_GX, \

@@ -459,3 +459,45 @@ def softmax_cross_entropy(y, t):
     t = as_variable(t)
     t.requires_grad = False
     return SoftmaxCrossEntropy().apply((y, t))[0]
+
+
+# --------------------------------------------------------------------------- #
+# discretised mixture-of-logistics loss (WaveNet/modules.py:169-230)
+# --------------------------------------------------------------------------- #
+class MixtureOfLogisticsNLL(FunctionNode):
+    def __init__(self, quantize, log_scale_min):
+        self.quantize = int(quantize)
+        self.log_scale_min = float(log_scale_min)
+
+    def check_type_forward(self, in_vars):
+        y, t = in_vars
+        type_expect((y.ndim in (3, 4) and y.shape[1] % 3 == 0,
+                     'logistic loss: y must be (B, 3*nr_mix, T[,1])'),
+                    (np.dtype(t.dtype).kind == 'f', 'logistic loss: t must be float'),
+                    (t.shape[0] == y.shape[0] and t.shape[1] == 1 and t.shape[2] == y.shape[2],
+                     'logistic loss: t must be (B,1,T[,1]), got %s vs y %s' % (t.shape, y.shape)))
+
+    def forward(self, inputs):
+        y, t = inputs
+        backend.require_device(y, t)
+        B, C3, T = y.shape[:3]
+        loss = DeviceArray((), np.float32)
+        ws = backend.workspace(4096 * 4)
+        _lib.call('vqvae_mol_nll_fwd', y.ptr, t.ptr, B, C3 // 3, T, self.quantize,
+                  self.log_scale_min, loss.ptr, ws.ptr, ws.nbytes, _S())
+        self._saved = (y, t)
+        return loss,
+
+    def backward(self, indexes, gys):
+        y, t = self._saved
+        B, C3, T = y.shape[:3]
+        gy = DeviceArray(y.shape, np.float32)
+        _lib.call('vqvae_mol_nll_bwd', y.ptr, t.ptr, gys[0].data.ptr, B, C3 // 3, T, self.quantize,
+                  self.log_scale_min, gy.ptr, _S())
+        return gy, None
+
+
+def mixture_of_logistics_nll(y, t, quantize=256, log_scale_min=-40.0):
+    t = as_variable(t)
+    t.requires_grad = False
+    return MixtureOfLogisticsNLL(quantize, log_scale_min).apply((y, t))[0]

@@ -85,6 +85,11 @@ class ResidualBlockFunction(FunctionNode):
         return tuple([gx, gc] + gp)
 
 
+def _groups(nb, size=_lib.MAX_STACK_GROUP):
+    """[lo, hi) block ranges of at most ``size`` blocks (one resstack call each)."""
+    return [(lo, min(nb, lo + size)) for lo in range(0, nb, size)]
+
+
 def _grad_out(var, shape):
     """Gradient destination for input ``var``: its slot in the flat gradient arena
     when it is a Parameter that has no gradient yet, else a fresh array."""
@@ -118,16 +123,19 @@ class ResidualStackFunction(FunctionNode):
         h = x
         # condition projection at the latent rate (see vqvae_resblock_cproj in the header)
         self.lat = None
-        if isinstance(cond, F.LazyUpsampled) and nb <= 32:
+        if isinstance(cond, F.LazyUpsampled):
             self.lat = lat = cond.latent                       # (B, Cc, Tl)
             B, Cc, Tl = lat.shape
             Cd = inputs[2].shape[0]
             self.Wc_all = DeviceArray((nb * Cd, Cc, 1, 1), np.float32)
             bc_all = DeviceArray((nb * Cd,), np.float32)
-            _lib.call('vqvae_concat', self.Wc_all.ptr, _lib.ptr_array([inputs[2 + 8 * i + 2] for i in range(nb)]),
-                      nb, Cd * Cc, _S())
-            _lib.call('vqvae_concat', bc_all.ptr, _lib.ptr_array([inputs[2 + 8 * i + 3] for i in range(nb)]),
-                      nb, Cd, _S())
+            for lo, hi in _groups(nb):
+                _lib.call('vqvae_concat', self.Wc_all.ptr + lo * Cd * Cc * 4,
+                          _lib.ptr_array([inputs[2 + 8 * i + 2] for i in range(lo, hi)]),
+                          hi - lo, Cd * Cc, _S())
+                _lib.call('vqvae_concat', bc_all.ptr + lo * Cd * 4,
+                          _lib.ptr_array([inputs[2 + 8 * i + 3] for i in range(lo, hi)]),
+                          hi - lo, Cd, _S())
             self.pdesc = _lib.Conv1dDesc(B, Cc, Tl, nb * Cd, Tl, 1, 1, 0, 1, 0)
             P_all = DeviceArray((B, nb * Cd, Tl), np.float32)
             ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
@@ -156,12 +164,14 @@ class ResidualStackFunction(FunctionNode):
             h = res
         d = self.descs[0]
         skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
-        ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
-        Ws = _lib.ptr_array([inputs[2 + 8 * i + 6] for i in range(nb)])
-        bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(nb)])
-        zs = _lib.ptr_array([sv[2] for sv in self.saved])
-        _lib.call('vqvae_resstack_skip_fwd', C.byref(d), nb, Ws, bs, zs, skip.ptr, ws.ptr, ws.nbytes,
-                  _S())
+        for lo, hi in _groups(nb):
+            n = hi - lo
+            ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), n))
+            Ws = _lib.ptr_array([inputs[2 + 8 * i + 6] for i in range(lo, hi)])
+            bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(lo, hi)])
+            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
+            _lib.call('vqvae_resstack_skip_fwd', C.byref(d), n, Ws, bs, zs, skip.ptr,
+                      0 if lo == 0 else 1, ws.ptr, ws.nbytes, _S())
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
 
@@ -199,7 +209,6 @@ class ResidualStackFunction(FunctionNode):
             ghs[i] = gh
             g_res = gx
         d = self.descs[0]
-        ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
         if lat is not None:
             # pull every block's gh back to the latent rate (adjoint of the epilogue lerp), then
             # the (nb*Cd, Cc) 1x1 conv's own backward gives gWc_l, gbc_l and the condition grad
@@ -218,8 +227,11 @@ class ResidualStackFunction(FunctionNode):
                       gbc_all.ptr, 0, wsc.ptr, wsc.nbytes, _S())
             gWc = [_grad_out(in_vars[2 + 8 * i + 2], ins[2 + 8 * i + 2].shape) for i in range(nb)]
             gbc = [_grad_out(in_vars[2 + 8 * i + 3], ins[2 + 8 * i + 3].shape) for i in range(nb)]
-            _lib.call('vqvae_split', gWc_all.ptr, _lib.ptr_array(gWc), nb, d.Cd * Cc, 0, _S())
-            _lib.call('vqvae_split', gbc_all.ptr, _lib.ptr_array(gbc), nb, d.Cd, 0, _S())
+            for lo, hi in _groups(nb):
+                _lib.call('vqvae_split', gWc_all.ptr + lo * d.Cd * Cc * 4, _lib.ptr_array(gWc[lo:hi]),
+                          hi - lo, d.Cd * Cc, 0, _S())
+                _lib.call('vqvae_split', gbc_all.ptr + lo * d.Cd * 4, _lib.ptr_array(gbc[lo:hi]),
+                          hi - lo, d.Cd, 0, _S())
             for i in range(nb):
                 grads[2 + 8 * i + 2] = gWc[i]
                 grads[2 + 8 * i + 3] = gbc[i]
@@ -228,24 +240,28 @@ class ResidualStackFunction(FunctionNode):
                 _lib.call('vqvae_conv1d_bwd_data', C.byref(self.pdesc), self.Wc_all.ptr, gP.ptr,
                           glat.ptr, 0, wsc.ptr, wsc.nbytes, _S())
                 grads[1] = F.LatentGrad(cond.shape, glat)
-            ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), nb))
         elif 1 in indexes:
             gcond = DeviceArray(cond.shape, np.float32)
-            Wc = _lib.ptr_array([ins[2 + 8 * i + 2] for i in range(nb)])
-            _lib.call('vqvae_resstack_gcond_bwd', C.byref(d), nb, Wc, _lib.ptr_array(ghs), gcond.ptr,
-                      0, ws.ptr, ws.nbytes, _S())
+            for lo, hi in _groups(nb):
+                ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), hi - lo))
+                Wc = _lib.ptr_array([ins[2 + 8 * i + 2] for i in range(lo, hi)])
+                _lib.call('vqvae_resstack_gcond_bwd', C.byref(d), hi - lo, Wc, _lib.ptr_array(ghs[lo:hi]),
+                          gcond.ptr, 0 if lo == 0 else 1, ws.ptr, ws.nbytes, _S())
             grads[1] = gcond
         gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
         gbs = [_grad_out(in_vars[2 + 8 * i + 7], ins[2 + 8 * i + 7].shape) for i in range(nb)]
-        zs = _lib.ptr_array([sv[2] for sv in self.saved])
-        _lib.call('vqvae_resstack_skip_wgrad', C.byref(d), nb, g_skip.ptr, zs, _lib.ptr_array(gWs),
-                  _lib.ptr_array(gbs), 0, ws.ptr, ws.nbytes, _S())
         gWr = [None if g_ress[i] is None else
                _grad_out(in_vars[2 + 8 * i + 4], ins[2 + 8 * i + 4].shape) for i in range(nb)]
         gbr = [None if g_ress[i] is None else
                _grad_out(in_vars[2 + 8 * i + 5], ins[2 + 8 * i + 5].shape) for i in range(nb)]
-        _lib.call('vqvae_resstack_res_wgrad', C.byref(d), nb, _lib.ptr_array(g_ress), zs,
-                  _lib.ptr_array(gWr), _lib.ptr_array(gbr), 0, ws.ptr, ws.nbytes, _S())
+        for lo, hi in _groups(nb):
+            n = hi - lo
+            ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), n))
+            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
+            _lib.call('vqvae_resstack_skip_wgrad', C.byref(d), n, g_skip.ptr, zs,
+                      _lib.ptr_array(gWs[lo:hi]), _lib.ptr_array(gbs[lo:hi]), 0, ws.ptr, ws.nbytes, _S())
+            _lib.call('vqvae_resstack_res_wgrad', C.byref(d), n, _lib.ptr_array(g_ress[lo:hi]), zs,
+                      _lib.ptr_array(gWr[lo:hi]), _lib.ptr_array(gbr[lo:hi]), 0, ws.ptr, ws.nbytes, _S())
         for i in range(nb):
             grads[2 + 8 * i + 4] = gWr[i]
             grads[2 + 8 * i + 5] = gbr[i]
@@ -333,6 +349,10 @@ class WaveNet(Chain):
         self.quantize = quantize
         self.skip_channels = skip_channels
         self.log_scale_min = log_scale_min
+
+    def calculate_logistic_loss(self, y, t):
+        """modules.py:169-230 as one fused kernel pair."""
+        return F.mixture_of_logistics_nll(y, t, self.quantize, self.log_scale_min)
 
     def __call__(self, x, condition, generating=False):
         if generating:

@@ -165,14 +165,15 @@ int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params
 
 /* ---- ResidualNet-level contractions (WaveNet/modules.py:89-96): the arguments are
  *      HOST arrays of nblocks (<= 24) device pointers.
- *      skip_fwd : skip (B,Cs,T) = sum_l (Ws_l z_l + bs_l)   -- one GEMM, K = nblocks*Cd/2
+ *      skip_fwd : skip (B,Cs,T) (+)= sum_l (Ws_l z_l + bs_l) -- one GEMM, K = nblocks*Cd/2
+ *                 (deeper stacks are fed in groups of <= 24 blocks with accumulate)
  *      gcond_bwd: gcond (B,Cc,T) (+)= sum_l Wc_l^T gh_l     -- one GEMM, K = nblocks*Cd
  *      skip_wgrad: gWs_l (+)= g_skip z_l^T, gbs_l (+)= rowsum(g_skip) for every l     */
 size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks);
 int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                             const float* const* Ws, const float* const* bs,
-                            const float* const* z, float* skip, void* ws, size_t ws_bytes,
-                            vqvae_stream_t s);
+                            const float* const* z, float* skip, int accumulate, void* ws,
+                            size_t ws_bytes, vqvae_stream_t s);
 int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* Wc, const float* const* gh, float* gcond,
                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
@@ -241,6 +242,17 @@ int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T
 int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse,
                            const float* gloss, int B, int q, int T, float* gy,
                            vqvae_stream_t s);
+
+/* ---- WaveNet.calculate_logistic_loss (WaveNet/modules.py:169-230): discretised
+ *      mixture-of-logistics NLL.  y (B, 3*n_mixture, T) = [logit_probs | means |
+ *      log_scales], t (B,1,T) fp32 in [-1,1]; loss = -mean_{b,t} logsumexp_k(...).
+ *      n_mixture here is the number of logistics (the reference's `n_mixture` argument
+ *      is 3x that, params.py:38).  ws >= 4096 floats.                               */
+int vqvae_mol_nll_fwd(const float* y, const float* t, int B, int n_mixture, int T, int quantize,
+                      float log_scale_min, float* loss, void* ws, size_t ws_bytes,
+                      vqvae_stream_t s);
+int vqvae_mol_nll_bwd(const float* y, const float* t, const float* gloss, int B, int n_mixture,
+                      int T, int quantize, float log_scale_min, float* gy, vqvae_stream_t s);
 
 /* ---- element-wise helpers behind Variable arithmetic (net.py:90-92) and F.relu */
 #define VQVAE_EW_ADD       0   /* out = a + b                  */

@@ -441,14 +441,13 @@ def softplus(x):
     return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
 
 
-def mol_loss_fwd(y, t, quantize=256, log_scale_min=-40.0):
-    """WaveNet.calculate_logistic_loss (modules.py:169-230), forward only.
-    y:(B,3*nr_mix,T), t:(B,1,T) float."""
+def _mol_terms(y, t, quantize, log_scale_min):
     dt = y.dtype.type
     nr = y.shape[1] // 3
     logit_probs = y[:, :nr]
     means = y[:, nr:2 * nr]
-    log_scales = np.maximum(y[:, 2 * nr:3 * nr], dt(log_scale_min))     # modules.py:178-179
+    ls_raw = y[:, 2 * nr:3 * nr]
+    log_scales = np.maximum(ls_raw, dt(log_scale_min))                  # modules.py:178-179
     tt = np.broadcast_to(dt(127.5) * t, means.shape)                   # modules.py:181
     centered = tt - means
     inv_std = np.exp(-log_scales)
@@ -461,14 +460,48 @@ def mol_loss_fwd(y, t, quantize=256, log_scale_min=-40.0):
     log_one_minus_cdf_min = -softplus(min_in)                           # modules.py:191
     cdf_delta = cdf_plus - cdf_min
     inner = np.log(np.maximum(cdf_delta, dt(1e-12)))                    # modules.py:214-215
-    log_probs = np.where(tt < dt(127.5 * -0.999), log_cdf_plus,
-                         np.where(tt > dt(127.5 * 0.999), log_one_minus_cdf_min, inner))
+    left = tt < dt(127.5 * -0.999)
+    right = tt > dt(127.5 * 0.999)
+    log_probs = np.where(left, log_cdf_plus, np.where(right, log_one_minus_cdf_min, inner))
     m = logit_probs.max(axis=1, keepdims=True)
     lsm = logit_probs - (np.log(np.exp(logit_probs - m).sum(axis=1, keepdims=True)) + m)
     lp = log_probs + lsm                                                # modules.py:227
     mm = lp.max(axis=1, keepdims=True)
-    lse = np.log(np.exp(lp - mm).sum(axis=1)) + mm[:, 0]
-    return -lse.mean(dtype=y.dtype)                                     # modules.py:228-229
+    lse = np.log(np.exp(lp - mm).sum(axis=1, keepdims=True)) + mm
+    return dict(nr=nr, ls_raw=ls_raw, inv_std=inv_std, plus_in=plus_in, min_in=min_in,
+                cdf_plus=cdf_plus, cdf_min=cdf_min, cdf_delta=cdf_delta, left=left, right=right,
+                lsm=lsm, lp=lp, lse=lse)
+
+
+def mol_loss_fwd(y, t, quantize=256, log_scale_min=-40.0):
+    """WaveNet.calculate_logistic_loss (modules.py:169-230).
+    y:(B,3*nr_mix,T), t:(B,1,T) float."""
+    c = _mol_terms(y, t, quantize, log_scale_min)
+    return -c['lse'][:, 0].mean(dtype=y.dtype)                          # modules.py:228-229
+
+
+def mol_loss_bwd(y, t, quantize=256, log_scale_min=-40.0, gloss=1.0):
+    """Analytic gradient of mol_loss_fwd w.r.t. y (what Chainer's autograd yields for
+    modules.py:173-229; F.maximum routes the gradient to its first argument where
+    x1 >= x2).  Checked against fp64 finite differences in tests/test_oracle.py."""
+    dt = y.dtype.type
+    c = _mol_terms(y, t, quantize, log_scale_min)
+    B, _, T = y.shape
+    N = dt(B * T)
+    w = np.exp(c['lp'] - c['lse'])                       # responsibilities
+    gv = -w / N * dt(gloss)                              # d loss / d (log_probs + lsm)
+    g_logit = gv - np.exp(c['lsm']) * gv.sum(axis=1, keepdims=True)
+    one = dt(1)
+    sp = c['cdf_plus'] * (one - c['cdf_plus'])
+    sm = c['cdf_min'] * (one - c['cdf_min'])
+    live = c['cdf_delta'] >= dt(1e-12)
+    inv_d = np.where(live, one / np.maximum(c['cdf_delta'], dt(1e-12)), dt(0))
+    d_plus = np.where(c['left'], one - c['cdf_plus'], np.where(c['right'], dt(0), inv_d * sp))
+    d_min = np.where(c['left'], dt(0), np.where(c['right'], -c['cdf_min'], -inv_d * sm))
+    g_mean = gv * (d_plus + d_min) * (-c['inv_std'])
+    g_ls = gv * (d_plus * (-c['plus_in']) + d_min * (-c['min_in']))
+    g_ls = np.where(c['ls_raw'] >= dt(log_scale_min), g_ls, dt(0))
+    return np.concatenate((g_logit, g_mean, g_ls), axis=1)
 
 
 # --------------------------------------------------------------------------- #
@@ -561,15 +594,20 @@ def flatten_params(P, prefix=''):
 # --------------------------------------------------------------------------- #
 # VAE forward + the three-loss backward of the updaters
 # --------------------------------------------------------------------------- #
-def vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta=0.25):
-    """VAE.__call__ (net.py:79-96), softmax-CE loss (train.py:95).
-    x_enc:(B,1,L) x_dec:(B,q,T) speaker:(B,) t:(B,T) int32."""
+def vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta=0.25, loss_kind='softmax',
+                quantize=256, log_scale_min=-40.0):
+    """VAE.__call__ (net.py:79-96).  loss_kind 'softmax': softmax-CE (train.py:95),
+    x_dec:(B,q,T) one-hot, t:(B,T) int32.  loss_kind 'mol': discretised mixture of
+    logistics (train.py:93, modules.py:169-230), x_dec:(B,1,T) raw, t:(B,1,T) float."""
     z, enc_hs = encoder_fwd(P['encoder'], x_enc)                       # net.py:81
     e4, idx = vq_forward(expand4(z), P['vq'])                          # net.py:82 (and 83: same values)
     e = np.ascontiguousarray(squeeze4(e4))
     cond, ce_hs = cond_embed_fwd(P['condition_embed'], e, speaker)     # net.py:85
     y, dcache = wavenet_fwd(P['decoder'], x_dec, cond, n_loop, n_layer)  # net.py:86
-    loss1, logp = softmax_xent_fwd(y, t)                               # net.py:89
+    if loss_kind == 'softmax':
+        loss1, logp = softmax_xent_fwd(y, t)                           # net.py:89
+    else:
+        loss1, logp = mol_loss_fwd(y, t, quantize, log_scale_min), None
     diff = z - e
     loss2 = np.mean(diff ** 2, dtype=z.dtype)                          # net.py:90
     loss3 = z.dtype.type(beta) * np.mean(diff ** 2, dtype=z.dtype)     # net.py:91
@@ -578,14 +616,18 @@ def vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta=0.25):
     return (loss1, loss2, loss3), cache
 
 
-def vae_backward(P, cache, speaker, t, n_loop, n_layer, beta=0.25):
+def vae_backward(P, cache, speaker, t, n_loop, n_layer, beta=0.25, loss_kind='softmax',
+                 quantize=256, log_scale_min=-40.0):
     """Gradient of the updater's sequence (updaters.py:13-19):
     cleargrads; loss1.backward(); vq.cleargrads(); loss2.backward(); loss3.backward().
     Net effect: decoder, condition_embed <- dloss1; encoder <- dloss1 (straight
     through, utils.py:218-219) + dloss3; vq.W <- dloss2 only."""
     z, e = cache['z'], cache['e']
     G = {}
-    gy = softmax_xent_bwd(cache['logp'], t)
+    if loss_kind == 'softmax':
+        gy = softmax_xent_bwd(cache['logp'], t)
+    else:
+        gy = mol_loss_bwd(cache['y'], t, quantize, log_scale_min)
     gcond, G['decoder'] = wavenet_bwd(P['decoder'], cache['dcache'], cache['cond'],
                                       gy, n_loop, n_layer)
     G['condition_embed'], ge = cond_embed_bwd(P['condition_embed'], cache['ce_hs'],
@@ -604,17 +646,17 @@ def vae_backward(P, cache, speaker, t, n_loop, n_layer, beta=0.25):
 
 
 def train_step(P, state, batch, n_loop, n_layer, beta=0.25, alpha=2e-4, ema=None,
-               ema_decay=0.9999, grad_sum_hook=None):
+               ema_decay=0.9999, grad_sum_hook=None, loss_kind='softmax'):
     """One VQVAE_StandardUpdater.update_core (updaters.py:6-19) incl. the EMA
     blend that runs at forward time (utils.py:146-155).  ``state`` holds Adam
     m, v per flattened param name and the step count.  ``grad_sum_hook`` lets a
     test insert the data-parallel sum (updaters.py:71-72)."""
     x_enc, x_dec, speaker, t = batch
-    losses, cache = vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta)
+    losses, cache = vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta, loss_kind)
     if ema is not None:                      # EMA.__call__ runs right after target fwd
         for (n1, a), (n2, b) in zip(flatten_params(ema), flatten_params(P['decoder'])):
             ema_update(a, b, ema_decay)
-    G = vae_backward(P, cache, speaker, t, n_loop, n_layer, beta)
+    G = vae_backward(P, cache, speaker, t, n_loop, n_layer, beta, loss_kind)
     flatP = dict(flatten_params(P))
     flatG = dict(flatten_params(G))
     if grad_sum_hook is not None:
@@ -657,3 +699,10 @@ def synth_batch(B, length=7680, quantize=256, n_speaker=109, seed=71, sr=16000,
     t = q[:, 1:].astype(np.int32)
     speaker = rs.randint(0, n_speaker, size=B).astype(np.int32)
     return raw, np.ascontiguousarray(x_dec), speaker, t
+
+
+def synth_batch_raw(B, length=7680, n_speaker=109, seed=71, dtype=np.float32):
+    """The use_logistic / input_dim=1 variant of Preprocess's contract
+    (utils.py:104, 107): x_dec = raw[:, :-1], t = raw[:, 1:], both (B,1,L) float."""
+    raw, _, speaker, _ = synth_batch(B, length, 256, n_speaker, seed, dtype=dtype)
+    return raw, np.ascontiguousarray(raw[:, :, :-1]), speaker, np.ascontiguousarray(raw[:, :, 1:])

@@ -33,7 +33,11 @@ SMALL = dict(d=32, k=64, n_loop=2, n_layer=3, filter_size=2, input_dim=256, resi
              dilated=64, skip=64, out_dim=256, local_dim=32, global_dim=32, n_speaker=7)
 
 
-def build_model(cfg, seed=0, ema_decay=None):
+MOL = dict(d=32, k=64, n_loop=4, n_layer=7, filter_size=2, input_dim=1, residual=64,
+           dilated=64, skip=64, out_dim=30, local_dim=32, global_dim=32, n_speaker=7)   # 28 blocks
+
+
+def build_model(cfg, seed=0, ema_decay=None, use_logistic=False, tweak=None):
     """Builds (oracle params P, device model) with IDENTICAL initial weights."""
     import vqvae_amd as V
     from vqvae_amd.net import Encoder, ConditionEmbed, VAE
@@ -41,10 +45,12 @@ def build_model(cfg, seed=0, ema_decay=None):
     from vqvae_amd import functions as F
     rs = np.random.RandomState(seed)
     P = O.make_params(rs, **cfg)
+    if tweak is not None:
+        tweak(P)
     enc = Encoder(cfg['d'])
     wn = WaveNet(cfg['n_loop'], cfg['n_layer'], cfg['filter_size'], cfg['input_dim'],
-                 cfg['residual'], cfg['dilated'], cfg['skip'], cfg['out_dim'], False, 30, -40,
-                 cfg['local_dim'] + cfg['global_dim'], 0)
+                 cfg['residual'], cfg['dilated'], cfg['skip'], 256, use_logistic, cfg['out_dim'],
+                 -40, cfg['local_dim'] + cfg['global_dim'], 0)
     ce = ConditionEmbed(cfg['n_speaker'], cfg['global_dim'], cfg['local_dim'])
     # force lazy shapes
     for i, ci in zip(range(1, 6), [cfg['d']] + [cfg['local_dim']] * 4):
@@ -52,7 +58,8 @@ def build_model(cfg, seed=0, ema_decay=None):
     decoder = wn
     if ema_decay is not None:
         decoder = V.ExponentialMovingAverage(wn, ema_decay)
-    model = VAE(enc, decoder, ce, cfg['d'], cfg['k'], 0.25, F.softmax_cross_entropy)
+    loss_fun = wn.calculate_logistic_loss if use_logistic else F.softmax_cross_entropy   # train.py:92-95
+    model = VAE(enc, decoder, ce, cfg['d'], cfg['k'], 0.25, loss_fun)
     load_params(model, P, ema=ema_decay is not None)
     return P, model
 

@@ -310,3 +310,27 @@ def test_variable_arithmetic(gpu):
     loss.backward()
     assert vb.grad is None
     assert_close_scaled(va.grad.get(), 0.25 * 2 * (a - b) / a.size, 1e-5, 'grad')
+
+
+def test_mol_nll(gpu):
+    """WaveNet.calculate_logistic_loss (modules.py:169-230): loss and gradient vs the oracle,
+    incl. both edge branches, the log-scale clamp and a saturated (cdf_delta < 1e-12) term."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(8)
+    B, nm, T = 2, 10, 333
+    t = rs.uniform(-1, 1, (B, 1, T)).astype(np.float32)
+    t[0, 0, :5] = -1.0
+    t[1, 0, :5] = 1.0
+    y = rs.standard_normal((B, 3 * nm, T)).astype(np.float32)
+    y[:, nm:2 * nm] = 127.5 * t + 30 * rs.standard_normal((B, nm, T)).astype(np.float32)
+    y[:, 2 * nm:] = rs.uniform(0.5, 3.5, (B, nm, T)).astype(np.float32)
+    y[0, 2 * nm, 7] = -50.0            # clamped scale
+    y[1, nm + 1, 9] = 127.5 * t[1, 0, 9] + 4000.0   # far-off mean: saturated term
+    loss_ref = O.mol_loss_fwd(y, t)
+    g_ref = O.mol_loss_bwd(y, t)
+    vy = Variable(_dev(gpu, to4(y)))
+    loss = F.mixture_of_logistics_nll(vy, _dev(gpu, to4(t)))
+    assert_close(loss.data.get(), loss_ref, 1e-4, 'mol loss')
+    loss.backward()
+    assert_close_scaled(vy.grad.get(), g_ref, 1e-4, 'mol grad')

@@ -254,3 +254,17 @@ def test_mol_loss_runs_and_matches_bruteforce():
     ref = -np.log(np.sum(np.exp(lp - np.log(np.exp(lp).sum())) * np.maximum(cdf, 1e-12)))
     full = O.mol_loss_fwd(y[b:b + 1, :, i:i + 1], t[b:b + 1, :, i:i + 1])
     assert abs(float(full) - ref) < 1e-4 * max(1, abs(ref))
+
+
+def test_mol_grad_fd():
+    rs = np.random.RandomState(6)
+    t = rs.uniform(-0.9, 0.9, (2, 1, 5))
+    t[0, 0, 1], t[1, 0, 2] = -1.0, 1.0              # both edge branches
+    y = rs.standard_normal((2, 9, 5))
+    y[:, 3:6] = 127.5 * t + 20 * rs.standard_normal((2, 3, 5))     # means near the targets
+    y[:, 6:] = rs.uniform(1.0, 3.0, (2, 3, 5))                       # moderate scales: no saturation
+    y[0, 6, 0] = -45.0                              # below log_scale_min: no gradient through the clamp
+    f = lambda: float(O.mol_loss_fwd(y, t))
+    g = O.mol_loss_bwd(y, t)
+    np.testing.assert_allclose(g, _fd(f, y, 1e-6), rtol=2e-5, atol=1e-9)
+    assert g[0, 6, 0] == 0.0
