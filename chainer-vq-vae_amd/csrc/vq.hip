@@ -187,6 +187,28 @@ __global__ void vq_scatter64_kernel(const int32_t* __restrict__ idx, const float
   }
 }
 
+// small-problem form of the codebook gradient (training shape: N = B*T' ~ 2k rows): one
+// workgroup per code scans the index list from LDS and sums its rows in fp64 in index
+// order -- deterministic, no atomics (the scatter above serialises on hot codes).
+__global__ __launch_bounds__(64) void vq_gradw_scan_kernel(const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ gy, int B, int d,
+                                                           int T, int k, float* __restrict__ gW,
+                                                           int accumulate) {
+  extern __shared__ int32_t sidx[];
+  const int j = blockIdx.x;
+  const int N = B * T;
+  for (int n = threadIdx.x; n < N; n += 64) sidx[n] = idx[n];
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 64) {
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n)
+      if (sidx[n] == j) { const int b = n / T, t = n % T; acc += (double)gy[((long)b * d + c) * T + t]; }
+    const float v = (float)acc;
+    float* dst = gW + (long)j * d + c;
+    *dst = accumulate ? __fadd_rn(*dst, v) : v;
+  }
+}
+
 __global__ void vq_cast64_kernel(const double* __restrict__ g64, long n, float* gW, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
@@ -279,6 +301,11 @@ extern "C" int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d
   VQ_REQUIRE(idx && gy && gW && ws, "vq_grad_w: null pointer");
   if (ws_bytes < (size_t)k * d * 8) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
+  if ((long)B * T <= 12288) {          // index list fits LDS: scan form
+    hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(64), (size_t)B * T * 4, st, idx, gy, B, d, T, k, gW, accumulate);
+    VQ_LAUNCH_CHECK();
+    return 0;
+  }
   double* g64 = (double*)ws;
   VQ_CHECK_HIP(hipMemsetAsync(g64, 0, (size_t)k * d * 8, st));
   const long total = (long)B * d * T;
