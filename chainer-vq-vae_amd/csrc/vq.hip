@@ -194,18 +194,28 @@ __global__ __launch_bounds__(64) void vq_gradw_scan_kernel(const int32_t* __rest
                                                            const float* __restrict__ gy, int B, int d,
                                                            int T, int k, float* __restrict__ gW,
                                                            int accumulate) {
-  extern __shared__ int32_t sidx[];
   const int j = blockIdx.x;
   const int N = B * T;
-  for (int n = threadIdx.x; n < N; n += 64) sidx[n] = idx[n];
-  __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 64) {
+  const int lane = threadIdx.x;
+  for (int c0 = 0; c0 < d; c0 += 64) {
+    const int c = c0 + lane;
     double acc = 0.0;
-    for (int n = 0; n < N; ++n)
-      if (sidx[n] == j) { const int b = n / T, t = n % T; acc += (double)gy[((long)b * d + c) * T + t]; }
-    const float v = (float)acc;
-    float* dst = gW + (long)j * d + c;
-    *dst = accumulate ? __fadd_rn(*dst, v) : v;
+    for (int base = 0; base < N; base += 64) {
+      const int n = base + lane;
+      // 64 indices per step; the (few) matching rows are visited in ascending order
+      unsigned long long m = __ballot(n < N && idx[n] == j);
+      while (m) {
+        const int nn = base + __builtin_ctzll(m);
+        m &= m - 1;
+        const int b = nn / T, t = nn % T;
+        if (c < d) acc += (double)gy[((long)b * d + c) * T + t];
+      }
+    }
+    if (c < d) {
+      const float v = (float)acc;
+      float* dst = gW + (long)j * d + c;
+      *dst = accumulate ? __fadd_rn(*dst, v) : v;
+    }
   }
 }
 
@@ -301,8 +311,8 @@ extern "C" int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d
   VQ_REQUIRE(idx && gy && gW && ws, "vq_grad_w: null pointer");
   if (ws_bytes < (size_t)k * d * 8) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
-  if ((long)B * T <= 12288) {          // index list fits LDS: scan form
-    hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(64), (size_t)B * T * 4, st, idx, gy, B, d, T, k, gW, accumulate);
+  if ((long)B * T * k <= (1L << 26)) {   // small problem: scan form (N*k index tests)
+    hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(64), 0, st, idx, gy, B, d, T, k, gW, accumulate);
     VQ_LAUNCH_CHECK();
     return 0;
   }
