@@ -296,23 +296,32 @@ __global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
     const int Ch = a.M;
     const OutR& od = a.out[0];
+    const float* gates_b = od.add + (long)b * od.add_bstride;
+    float* gh_b = od.y + (long)b * od.y_bstride;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= Ch) continue;
+      for (int ni = 0; ni < 2; ++ni) {
+        const int t = t0 + wn * 64 + ni * 32 + li;
+        const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+        const bool tok = t < T;
+        // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
+        float ta[16], sb[16];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int t = t0 + wn * 64 + ni * 32 + li;
-          if (t >= T) continue;
-          const float* gp = od.add + (long)b * od.add_bstride;
-          const float ta = gp[(long)m * T + t];
-          const float sb = gp[(long)(Ch + m) * T + t];
-          const float gz = acc[mi][ni][r];
-          float* yp = od.y + (long)b * od.y_bstride;
-          yp[(long)m * T + t] = gz * sb * (1.f - ta * ta);
-          yp[(long)(Ch + m) * T + t] = gz * ta * sb * (1.f - sb);
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          const bool ok = tok && m < Ch;
+          ta[r] = ok ? gates_b[(long)m * T + t] : 0.f;
+          sb[r] = ok ? gates_b[(long)(Ch + m) * T + t] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (tok && m < Ch) {
+            const float gz = acc[mi][ni][r];
+            gh_b[(long)m * T + t] = gz * sb[r] * (1.f - ta[r] * ta[r]);
+            gh_b[(long)(Ch + m) * T + t] = gz * ta[r] * sb[r] * (1.f - sb[r]);
+          }
         }
       }
   }
@@ -361,6 +370,7 @@ constexpr int WBK = 32, WP = WBK + 1;
 struct WSeg {
   const float* x; long x_bstride; int x_cstride; int cin; int Tin;
   int tmul, toff, tdiv;
+  int vec;            // host: 16-B row loads of x are legal for this segment
   const float* gy;    // this segment's own output-gradient tensor (nullptr: WgradArgs.gy)
   float* gw; long gw_co_stride, gw_ci_stride;
   float* gb; float* gb2;   // bias-gradient destinations fed by this segment's gy (nullable)
@@ -372,6 +382,7 @@ struct WgradArgs {
   WSeg seg[MAXSEG]; int nseg;
   int ntile_m, ntile_n;      // ntile_n = total over segments
   int tchunk, nsplit_t;
+  int avec;                  // host: 16-B row loads of gy are legal
   float* slabs;              // [nsplit][ntile_m][ntile_n][128][128]
   float* bslabs;             // [nsplit][nseg][ntile_m*128]
   float* gbl[MAXSEG]; int ngbl;   // further copies of segment 0's bias grad (shared gy, many layers)
@@ -399,7 +410,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
-  const int l_k = tid & 31, l_r = tid >> 5;   // staging: column k, rows l_r + 8i
+  // staging roles.  scalar: column k = l_k, rows l_r + 8i (i < 16), one dword per load;
+  // vector (rows 16-B aligned, window inside the row): 4 consecutive k = v_c4.., rows
+  // v_row + 32i (i < 4), one dwordx4 per load -- 4x fewer VMEM instructions per tile.
+  const int l_k = tid & 31, l_r = tid >> 5;
+  const int v_row = tid >> 3, v_c4 = (tid & 7) * 4;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -415,33 +430,77 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride;
   const float* xb = sg.x + (long)b * sg.x_bstride;
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
+  const bool avec = a.avec != 0;
+  const bool bvec = sg.vec != 0;
 
   float ra[16], rbv[16];
   auto load = [&](int tb) {
-    const int t = tb + l_k;
-    const bool tok = t < tend;
-    const int tnum = t * sg.tmul + sg.toff;
-    bool xok = tok && tnum >= 0;
-    int tin = tnum;
-    if (sg.tdiv > 1) { xok = xok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
-    xok = xok && tin < sg.Tin;
+    if (avec) {
+      const int t = tb + v_c4;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = m0 + l_r + 8 * i;
-      ra[i] = (tok && m < a.M) ? gyb[(long)m * a.Tout + t] : 0.f;
-      const int ci = n0 + l_r + 8 * i;
-      rbv[i] = (xok && ci < sg.cin) ? xb[(long)ci * sg.x_cstride + tin] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + v_row + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < tend && m < a.M) v = *reinterpret_cast<const float4*>(gyb + (long)m * a.Tout + t);
+        ra[4 * i] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
+      }
+    } else {
+      const int t = tb + l_k;
+      const bool tok = t < tend;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + l_r + 8 * i;
+        ra[i] = (tok && m < a.M) ? gyb[(long)m * a.Tout + t] : 0.f;
+      }
+    }
+    if (bvec) {
+      const int t = tb + v_c4;
+      const int tin = t + sg.toff;                     // tmul == 1, tdiv == 1, toff % 4 == 0
+      const bool ok = t < tend && tin >= 0 && tin < sg.Tin;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = n0 + v_row + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && ci < sg.cin) v = *reinterpret_cast<const float4*>(xb + (long)ci * sg.x_cstride + tin);
+        rbv[4 * i] = v.x; rbv[4 * i + 1] = v.y; rbv[4 * i + 2] = v.z; rbv[4 * i + 3] = v.w;
+      }
+    } else {
+      const int t = tb + l_k;
+      const int tnum = t * sg.tmul + sg.toff;
+      bool xok = t < tend && tnum >= 0;
+      int tin = tnum;
+      if (sg.tdiv > 1) { xok = xok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+      xok = xok && tin < sg.Tin;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = n0 + l_r + 8 * i;
+        rbv[i] = (xok && ci < sg.cin) ? xb[(long)ci * sg.x_cstride + tin] : 0.f;
+      }
     }
   };
 
   if (tbeg < tend) load(tbeg);
   for (int tb = tbeg; tb < tend; tb += WBK) {
     __syncthreads();
+    if (avec) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      As[l_r + 8 * i][l_k] = ra[i];
-      Bs[l_r + 8 * i][l_k] = rbv[i];
-      bsum[i] += ra[i];
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[v_row + 32 * i][v_c4 + j] = ra[4 * i + j];
+        bsum[i] += (ra[4 * i] + ra[4 * i + 1]) + (ra[4 * i + 2] + ra[4 * i + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { As[l_r + 8 * i][l_k] = ra[i]; bsum[i] += ra[i]; }
+    }
+    if (bvec) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[v_row + 32 * i][v_c4 + j] = rbv[4 * i + j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Bs[l_r + 8 * i][l_k] = rbv[i];
     }
     __syncthreads();
     if (tb + WBK < tend) load(tb + WBK);
@@ -470,12 +529,23 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
         slab[row * BN + col] = acc[mi][ni][r];
       }
   if (do_bias) {
+    float* bs = a.bslabs + (((long)split * a.nseg + s) * a.ntile_m + mt) * BM;
+    if (avec) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = bsum[i];
+      for (int i = 0; i < 4; ++i) {
+        float v = bsum[i];
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
-      if (l_k == 0) a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + mt) * BM + l_r + 8 * i] = v;
+        for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off, 8);
+        if ((tid & 7) == 0) bs[v_row + 32 * i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = bsum[i];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
+        if (l_k == 0) bs[l_r + 8 * i] = v;
+      }
     }
   }
 }
@@ -651,6 +721,20 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   w.bslabs = any_b ? ws + p.slab_floats : nullptr;
   int t0 = 0;
   for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
+  // 16-B row loads: every row start and every chunk start must be 16-B aligned and no float4
+  // may straddle a row end
+  bool av = (w.Tout % 4 == 0) && (w.gy_bstride % 4 == 0) && (p.tchunk % 4 == 0);
+  for (int i = 0; i < w.nseg; ++i) {
+    const float* g = w.seg[i].gy ? w.seg[i].gy : w.gy;
+    av = av && (((uintptr_t)g) % 16 == 0);
+  }
+  w.avec = av ? 1 : 0;
+  for (int i = 0; i < w.nseg; ++i) {
+    WSeg& sg = w.seg[i];
+    sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && sg.toff % 4 == 0 && sg.Tin % 4 == 0 &&
+              sg.x_cstride % 4 == 0 && sg.x_bstride % 4 == 0 && w.Tout % 4 == 0 &&
+              p.tchunk % 4 == 0 && ((uintptr_t)sg.x) % 16 == 0) ? 1 : 0;
+  }
   ProfScope ps(tag, st);
   hipLaunchKernelGGL(wgrad_kernel, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
