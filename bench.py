@@ -113,23 +113,43 @@ def cpu_baseline(cfg):
                       local_dim=cfg['local_dim'], global_dim=cfg['global_dim'],
                       n_speaker=cfg['n_speaker'])
     batch = O.synth_batch(1, length=cfg['length'], n_speaker=cfg['n_speaker'], seed=71)
-    state = {}
-    O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])        # warm-up
-    times = []
-    t_all = time.time()
-    while len(times) < 3 or (time.time() - t_all < 12 and len(times) < 8):
-        t0 = time.time()
-        O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])
-        times.append(time.time() - t0)
-    med = float(np.median(times))
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    # BLAS with every core is not the CPU's best on these mid-sized GEMMs: try a few thread
+    # counts (one warm-up + two timed steps each) and report the fastest
+    candidates = sorted({c for c in (cores, 64, 32, 16) if c <= cores}, reverse=True)
+    if threadpool_limits is None:
+        candidates = [cores]
+    best = None
+    for nthr in candidates:
+        state = {}
+        ctx = threadpool_limits(limits=nthr) if threadpool_limits else None
+        try:
+            if ctx is not None:
+                ctx.__enter__()
+            O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])    # warm-up
+            times = []
+            for _ in range(2):
+                t0 = time.time()
+                O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])
+                times.append(time.time() - t0)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, nthr, len(times))
+    med, nthr, n = best
+    return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': nthr, 'kind': 'port',
             'sample': '%d full training steps (fwd + 3-loss bwd + Adam) at batch 1, length %d, '
-                      'median %.2f s/step, NumPy+BLAS threads = all %d visible cores'
-                      % (len(times), cfg['length'], med, cores)}
+                      'median %.2f s/step with %d BLAS threads (best of %s tried; %d cores visible)'
+                      % (n, cfg['length'], med, nthr, candidates, cores)}
 
 
 def main():

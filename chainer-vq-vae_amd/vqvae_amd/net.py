@@ -1,64 +1,70 @@
-"""Encoder / ConditionEmbed / VAE -- mirrors the reference's net.py (Encoder
-net.py:8-26, ConditionEmbed 29-64, VAE 67-96), same constructor and call
-signatures, same three returned losses."""
+"""Encoder / ConditionEmbed / VAE of the VQ-VAE audio model.
+
+Public surface (class names, constructor and call signatures, sub-link names and
+therefore parameter paths) is the reference's net.py (Encoder net.py:8-26,
+ConditionEmbed net.py:29-64, VAE net.py:67-96); the bodies are written for this
+runtime: activations fused into conv epilogues, the condition tensor kept at the
+latent rate until the decoder consumes it, one nearest-code search per step.
+"""
 from . import core, functions as F, links as L
 from .core import Chain, Variable
 from .utils import VQ
 
+# (ksize, stride, pad) of every encoder stage: 4-tap, stride-2, pad-1 along time (net.py:12-17)
+_DOWN = dict(ksize=(4, 1), stride=(2, 1), pad=(1, 0))
+# dilations of the "same"-padded 3-tap condition convs (net.py:34-43)
+_COND_DILATIONS = (1, 2, 4, 8, 16)
+
 
 class Encoder(Chain):
+    """Six stride-2 convs, 64x temporal down-sampling; ReLU after all but the last."""
+
+    depth = 6
+
     def __init__(self, d):
         super(Encoder, self).__init__()
         with self.init_scope():
-            self.conv1 = L.Convolution2D(1, d, (4, 1), (2, 1), (1, 0))
-            self.conv2 = L.Convolution2D(d, d, (4, 1), (2, 1), (1, 0))
-            self.conv3 = L.Convolution2D(d, d, (4, 1), (2, 1), (1, 0))
-            self.conv4 = L.Convolution2D(d, d, (4, 1), (2, 1), (1, 0))
-            self.conv5 = L.Convolution2D(d, d, (4, 1), (2, 1), (1, 0))
-            self.conv6 = L.Convolution2D(d, d, (4, 1), (2, 1), (1, 0))
+            width_in = 1
+            for stage in range(1, self.depth + 1):
+                setattr(self, 'conv%d' % stage, L.Convolution2D(width_in, d, **_DOWN))
+                width_in = d
 
     def __call__(self, x):
-        # F.relu(conv(x)) with the ReLU fused into the conv epilogue (net.py:20-24)
-        h = self.conv1(x, relu=True)
-        h = self.conv2(h, relu=True)
-        h = self.conv3(h, relu=True)
-        h = self.conv4(h, relu=True)
-        h = self.conv5(h, relu=True)
-        z = self.conv6(h)
-        return z
+        h = x
+        for stage in range(1, self.depth + 1):
+            conv = getattr(self, 'conv%d' % stage)
+            h = conv(h, relu=(stage < self.depth))      # ReLU fused in the GEMM epilogue
+        return h
 
 
 class ConditionEmbed(Chain):
+    """Local (latent) condition: five dilated 3-tap convs + ReLU, then x`upscale_factor`
+    align-corners up-sampling; global condition: speaker embedding broadcast over time;
+    both concatenated on the channel axis."""
+
     def __init__(self, n_global_cond, global_embed_dim, local_embed_dim, upscale_factor=64):
         super(ConditionEmbed, self).__init__()
         with self.init_scope():
-            self.local_embed1 = L.DilatedConvolution2D(
-                None, local_embed_dim, (3, 1), pad=(1, 0), dilate=(1, 1))
-            self.local_embed2 = L.DilatedConvolution2D(
-                None, local_embed_dim, (3, 1), pad=(2, 0), dilate=(2, 1))
-            self.local_embed3 = L.DilatedConvolution2D(
-                None, local_embed_dim, (3, 1), pad=(4, 0), dilate=(4, 1))
-            self.local_embed4 = L.DilatedConvolution2D(
-                None, local_embed_dim, (3, 1), pad=(8, 0), dilate=(8, 1))
-            self.local_embed5 = L.DilatedConvolution2D(
-                None, local_embed_dim, (3, 1), pad=(16, 0), dilate=(16, 1))
+            for i, dil in enumerate(_COND_DILATIONS, start=1):
+                # in_channels=None: inferred from the first input, like the reference
+                setattr(self, 'local_embed%d' % i, L.DilatedConvolution2D(
+                    None, local_embed_dim, (3, 1), pad=(dil, 0), dilate=(dil, 1)))
             self.global_embed = L.EmbedID(n_global_cond, global_embed_dim)
         self.upscale_factor = upscale_factor
 
     def __call__(self, local_condition, global_condition):
-        local_condition = self.local_embed1(local_condition, relu=True)
-        local_condition = self.local_embed2(local_condition, relu=True)
-        local_condition = self.local_embed3(local_condition, relu=True)
-        local_condition = self.local_embed4(local_condition, relu=True)
-        local_condition = self.local_embed5(local_condition, relu=True)
-        # resize_images(local) ++ resize_images(EmbedID(speaker)) ++ concat (net.py:54-63),
-        # written straight into the concatenated tensor
-        condition = F.condition_assemble(local_condition, self.global_embed.W, global_condition,
-                                         self.upscale_factor)
-        return condition
+        h = local_condition
+        for i in range(1, len(_COND_DILATIONS) + 1):
+            h = getattr(self, 'local_embed%d' % i)(h, relu=True)
+        # resize_images(local) ++ resize_images(EmbedID(speaker)) ++ concat in one node that
+        # keeps the result at the latent rate until a consumer needs the full-rate tensor
+        return F.condition_assemble(h, self.global_embed.W, global_condition, self.upscale_factor)
 
 
 class VAE(Chain):
+    """encoder -> VQ (straight-through) -> condition embed -> decoder, three losses:
+    loss1 reconstruction, loss2 codebook, loss3 = beta * commitment."""
+
     def __init__(self, encoder, decoder, condition_embed, d, k, beta, loss_func):
         super(VAE, self).__init__()
         self.beta = beta
@@ -70,19 +76,21 @@ class VAE(Chain):
             self.decoder = decoder
 
     def __call__(self, x_enc, x_dec, global_condition, t):
-        # forward
         z = self.encoder(x_enc)
-        e = self.vq(z)
-        e_ = self.vq(Variable(z.data))
-        local_condition = e
-        condition = self.condition_embed(local_condition, global_condition)
-        y = self.decoder(x_dec, condition)
+        z_const = Variable(z.data)            # stop-gradient view of the latents
 
-        # calculate loss
+        # Two quantiser applications route the gradients (net.py:82-83): through `e` the
+        # reconstruction loss reaches the encoder (identity backward) and, discarded by the
+        # updater, the codebook; through `e_cb` only the codebook is reached.  The second
+        # application reuses the first one's nearest-code search (same data, same codebook).
+        e = self.vq(z)
+        e_cb = self.vq(z_const)
+
+        y = self.decoder(x_dec, self.condition_embed(e, global_condition))
+
         loss1 = self.loss_func(y, t)
-        loss2 = F.mean((Variable(z.data) - e_) ** 2)
+        loss2 = F.mean((z_const - e_cb) ** 2)
         loss3 = self.beta * F.mean((z - Variable(e.data)) ** 2)
-        loss = loss1 + loss2 + loss3
-        core.report(
-            {'loss1': loss1, 'loss2': loss2, 'loss3': loss3, 'loss': loss}, self)
+        core.report({'loss1': loss1, 'loss2': loss2, 'loss3': loss3,
+                     'loss': loss1 + loss2 + loss3}, self)
         return loss1, loss2, loss3

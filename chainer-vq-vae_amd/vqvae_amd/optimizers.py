@@ -56,10 +56,14 @@ class Adam(object):
             if not p._shadow:
                 p._grad_slot = self.grads.flat_view(off, p.size, view.shape)
                 p.grad = None
+            p._owner_step = self._step_count        # lets caches notice parameter updates
             self._layout.append((n, off, p.size))
             off += p.size
         self.n_train = n_train
         return self
+
+    def _step_count(self):
+        return self.t
 
     def update(self):
         """One Adam step on every trainable parameter (chainer Adam update rule)."""

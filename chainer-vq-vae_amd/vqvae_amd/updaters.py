@@ -43,22 +43,28 @@ class StandardUpdater(object):
         self.iteration += 1
 
 
+def three_loss_backward(model, losses):
+    """The gradient routing of the reference's updaters (updaters.py:14-18, 58-69):
+    clear everything, back-propagate the reconstruction loss, throw away what it put on the
+    codebook, then add the codebook loss (-> vq.W only) and the commitment loss (-> encoder)."""
+    loss1, loss2, loss3 = losses
+    model.cleargrads()
+    loss1.backward()
+    model.vq.cleargrads()
+    loss2.backward()
+    loss3.backward()
+
+
 class VQVAE_StandardUpdater(StandardUpdater):
+    """Single-device step (updaters.py:5-19)."""
+
     def update_core(self):
-        batch = self._iterators['main'].next()
-        in_arrays = self.converter(batch, self.device)
-
         optimizer = self._optimizers['main']
+        in_arrays = self.converter(self._iterators['main'].next(), self.device)
         loss_func = self.loss_func or optimizer.target
-
-        loss1, loss2, loss3 = loss_func(*in_arrays)
-        optimizer.target.cleargrads()
-        loss1.backward()
-        optimizer.target.vq.cleargrads()
-        loss2.backward()
-        loss3.backward()
+        self.last_losses = loss_func(*in_arrays)
+        three_loss_backward(optimizer.target, self.last_losses)
         optimizer.update()
-        self.last_losses = (loss1, loss2, loss3)
 
 
 class VQVAE_ParallelUpdater(StandardUpdater):
@@ -80,24 +86,14 @@ class VQVAE_ParallelUpdater(StandardUpdater):
     def update_core(self):
         optimizer = self.get_optimizer('main')
         model = optimizer.target
-
-        batch = self.get_iterator('main').next()
         n = self.comm.size
-        in_arrays = self.converter(batch[self.comm.rank::n], self.device)
+        shard = self.get_iterator('main').next()[self.comm.rank::n]      # strided split
+        in_arrays = self.converter(shard, self.device)
 
-        model.cleargrads()
-        loss_func = self.loss_func or model
         with core.force_backprop_mode():
-            loss1, loss2, loss3 = loss_func(*in_arrays)
-
-        model.cleargrads()
-        loss1.backward()
-        model.vq.cleargrads()
-        loss2.backward()
-        loss3.backward()
+            self.last_losses = (self.loss_func or model)(*in_arrays)
+        three_loss_backward(model, self.last_losses)
 
         if n > 1 or getattr(self.comm, 'always_reduce', False):
-            self.comm.allreduce_grad(optimizer.grads)
-
+            self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place
         optimizer.update()
-        self.last_losses = (loss1, loss2, loss3)

@@ -15,7 +15,8 @@ _S = backend.stream
 
 
 class MuLaw(object):
-    """utils.py:12-29 (host-side data preparation; defines the synthetic inputs)."""
+    """mu-law companding + binning (host-side; defines the synthetic inputs).  Arithmetic
+    order follows utils.py:18-29 so that bin edges fall on the same samples."""
 
     def __init__(self, mu=256, int_type=np.int32, float_type=np.float32):
         self.mu = mu
@@ -24,15 +25,15 @@ class MuLaw(object):
 
     def transform(self, x):
         x = x.astype(self.float_type)
-        y = np.sign(x) * np.log(1 + self.mu * np.abs(x)) / np.log(1 + self.mu)
-        y = np.digitize(y, 2 * np.arange(self.mu) / self.mu - 1) - 1
-        return y.astype(self.int_type)
+        magnitude = np.log(1 + self.mu * np.abs(x))
+        companded = np.sign(x) * magnitude / np.log(1 + self.mu)       # in [-1, 1]
+        edges = 2 * np.arange(self.mu) / self.mu - 1                   # left bin edges
+        return (np.digitize(companded, edges) - 1).astype(self.int_type)
 
     def itransform(self, y):
-        y = y.astype(self.float_type)
-        y = 2 * y / self.mu - 1
-        x = np.sign(y) / self.mu * ((self.mu) ** np.abs(y) - 1)
-        return x.astype(self.float_type)
+        centred = 2 * y.astype(self.float_type) / self.mu - 1
+        expanded = np.sign(centred) / self.mu * (self.mu ** np.abs(centred) - 1)
+        return expanded.astype(self.float_type)
 
 
 class ExponentialMovingAverage(Chain):
@@ -94,6 +95,7 @@ class StraightThrough(FunctionNode):
     (identity, same object), gW = onehot^T gy accumulated in float64."""
 
     mode = 0          # 0: MFMA + exact re-check; 1: exact everywhere (tests)
+    preset = None     # (indexes, embeded) of an identical earlier search, or None
 
     def check_type_forward(self, in_vars):
         type_expect((len(in_vars) == 2, 'StraightThrough takes (x, W)'))
@@ -113,6 +115,11 @@ class StraightThrough(FunctionNode):
                              'type(W): {0}, type(x): {1}'.format(type(W), type(xs)))
         B, d, T = xs.shape[:3]
         k = W.shape[0]
+        self._dims = (B, d, T, k)
+        if self.preset is not None:
+            self.indexes, embeded = self.preset
+            self.n_rechecked = None
+            return embeded,
         idx_shape = (B, T, 1) if xs.ndim == 4 else (B, T)
         self.indexes = DeviceArray(idx_shape, np.int32)
         embeded = DeviceArray(xs.shape, np.float32)
@@ -143,9 +150,16 @@ class StraightThrough(FunctionNode):
         return ret
 
 
+def _straight_through_node(x, W, preset=None):
+    node = StraightThrough()
+    node.preset = preset
+    y, = node.apply((x, W))
+    return y, node
+
+
 def straight_through(x, W):
-    y, = StraightThrough().apply((x, W))
-    return y
+    """utils.py:234-236."""
+    return _straight_through_node(x, W)[0]
 
 
 class VQ(Link):
@@ -168,4 +182,21 @@ class VQ(Link):
             self._initialize_params(x.shape[1])
             if isinstance(x.data, DeviceArray):
                 self.W.to_gpu()
-        return straight_through(x, self.W)
+        # the reference quantises the same latents twice per step (net.py:82-83); the second
+        # application reuses the first search while both arrays are still alive and unchanged
+        key = (x.data, self.W.data)
+        preset = None
+        c = self._cache
+        if c is not None and c[0]() is key[0] and c[1]() is key[1] and c[2] == self._w_version():
+            preset = c[3]
+        y, node = _straight_through_node(x, self.W, preset)
+        if preset is None and isinstance(x.data, DeviceArray):
+            self._cache = (weakref.ref(key[0]), weakref.ref(key[1]), self._w_version(),
+                           (node.indexes, y.data))
+        return y
+
+    _cache = None
+
+    def _w_version(self):
+        opt = getattr(self.W, '_owner_step', None)
+        return opt() if opt is not None else 0
