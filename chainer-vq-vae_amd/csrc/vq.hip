@@ -190,28 +190,59 @@ __global__ void vq_scatter64_kernel(const int32_t* __restrict__ idx, const float
 // small-problem form of the codebook gradient (training shape: N = B*T' ~ 2k rows): one
 // workgroup per code scans the index list from LDS and sums its rows in fp64 in index
 // order -- deterministic, no atomics (the scatter above serialises on hot codes).
-__global__ __launch_bounds__(64) void vq_gradw_scan_kernel(const int32_t* __restrict__ idx,
-                                                           const float* __restrict__ gy, int B, int d,
-                                                           int T, int k, float* __restrict__ gW,
-                                                           int accumulate) {
+__global__ __launch_bounds__(256) void vq_gradw_scan_kernel(const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ gy, int B, int d,
+                                                            int T, int k, float* __restrict__ gW,
+                                                            int accumulate) {
+  extern __shared__ int32_t rows[];        // the rows quantised to code j, ascending
+  __shared__ int wcnt[4];
+  __shared__ int total;
   const int j = blockIdx.x;
   const int N = B * T;
-  const int lane = threadIdx.x;
-  for (int c0 = 0; c0 < d; c0 += 64) {
-    const int c = c0 + lane;
-    double acc = 0.0;
-    for (int base = 0; base < N; base += 64) {
-      const int n = base + lane;
-      // 64 indices per step; the (few) matching rows are visited in ascending order
-      unsigned long long m = __ballot(n < N && idx[n] == j);
-      while (m) {
-        const int nn = base + __builtin_ctzll(m);
-        m &= m - 1;
-        const int b = nn / T, t = nn % T;
-        if (c < d) acc += (double)gy[((long)b * d + c) * T + t];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 256) {
+    const int n = base + tid;
+    const bool hit = n < N && idx[n] == j;          // independent loads: pipelined
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    if (hit) rows[off + __popcll(m & ((1ull << lane) - 1ull))] = n;
+    __syncthreads();
+    if (tid == 0) total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int cnt = total;
+  // a collapsed codebook sends most rows to a few codes: split the row list of one code
+  // over P thread groups (4 independent accumulators each), combined in a fixed order
+  __shared__ double part[256];
+  const int dch = d < 256 ? d : 256;
+  const int P = 256 / dch;                   // thread groups per channel
+  for (int c0 = 0; c0 < d; c0 += dch) {
+    const int c = c0 + tid % dch;
+    const int g = tid / dch;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (g < P && c < d) {
+      const float* gc = gy + (long)c * T;
+      int q = g;
+      for (; q + 3 * P < cnt; q += 4 * P) {
+        const int n0 = rows[q], n1 = rows[q + P], n2 = rows[q + 2 * P], n3 = rows[q + 3 * P];
+        a0 += (double)gc[(long)(n0 / T) * d * T + n0 % T];
+        a1 += (double)gc[(long)(n1 / T) * d * T + n1 % T];
+        a2 += (double)gc[(long)(n2 / T) * d * T + n2 % T];
+        a3 += (double)gc[(long)(n3 / T) * d * T + n3 % T];
       }
+      for (; q < cnt; q += P) { const int n = rows[q]; a0 += (double)gc[(long)(n / T) * d * T + n % T]; }
     }
-    if (c < d) {
+    __syncthreads();
+    part[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && c < d) {
+      double acc = part[tid];
+      for (int gg = 1; gg < P; ++gg) acc += part[gg * dch + tid];
       const float v = (float)acc;
       float* dst = gW + (long)j * d + c;
       *dst = accumulate ? __fadd_rn(*dst, v) : v;
@@ -311,8 +342,8 @@ extern "C" int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d
   VQ_REQUIRE(idx && gy && gW && ws, "vq_grad_w: null pointer");
   if (ws_bytes < (size_t)k * d * 8) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
-  if ((long)B * T * k <= (1L << 26)) {   // small problem: scan form (N*k index tests)
-    hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(64), 0, st, idx, gy, B, d, T, k, gW, accumulate);
+  if ((long)B * T <= 8192 && (long)B * T * k <= (1L << 26)) {   // small problem: scan form
+    hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(256), (size_t)B * T * 4, st, idx, gy, B, d, T, k, gW, accumulate);
     VQ_LAUNCH_CHECK();
     return 0;
   }
