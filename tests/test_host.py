@@ -195,3 +195,30 @@ def test_link_signatures_match_reference():
                                        'condition_dim', 'dropout_zero_rate']
     assert sig(V.WaveNet.__call__) == ['x', 'condition', 'generating']
     assert sig(V.ExponentialMovingAverage.__init__) == ['target', 'decay']
+
+
+def test_snapshot_key_layout_and_roundtrip(tmp_path):
+    """the .npz key tree generate.py reads (generate.py:67-81)."""
+    import vqvae_amd as V
+    from vqvae_amd import serializers
+    model, enc, wn, ce = _c1_model()
+    path = str(tmp_path / 'snap.npz')
+    state = serializers.model_state(model)
+    for key in ('updater/model:main/encoder/conv1/W', 'updater/model:main/vq/W',
+                'updater/model:main/decoder/target/resnet/0/conv/W',
+                'updater/model:main/decoder/ema/proj2/b',
+                'updater/model:main/condition_embed/global_embed/W'):
+        assert key in state, key
+    np.savez(path, **state)
+    # generate.py-style partial loads by prefix
+    enc2 = V.Encoder(64)
+    serializers.load_npz(path, enc2, 'updater/model:main/encoder/')
+    for (n, a), (_, b) in zip(enc.namedparams(), enc2.namedparams()):
+        np.testing.assert_array_equal(a.data, b.data)
+    wn2 = V.WaveNet(2, 10, 2, 256, 256, 256, 256, 256, False, 30, -40, 192, 0)
+    serializers.load_npz(path, wn2, 'updater/model:main/decoder/ema/')
+    np.testing.assert_array_equal(wn2.proj1.W.data, wn.proj1.W.data)
+    with pytest.raises(KeyError):
+        serializers.load_npz(path, V.Encoder(64), 'updater/model:main/nonexistent/')
+    with pytest.raises(ValueError):
+        serializers.load_npz(path, V.Encoder(32), 'updater/model:main/encoder/')
