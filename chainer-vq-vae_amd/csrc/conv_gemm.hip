@@ -1263,3 +1263,28 @@ extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.accumulate = accumulate;
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
+
+extern "C" int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x, const float* gh,
+                                    float* gWd, float* gbd, int accumulate, void* ws,
+                                    size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(x && gh && ws && (gWd || gbd), "resblock_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const int T = d->T;
+  int cins[MAXTAPS];
+  for (int j = 0; j < d->K; ++j) cins[j] = d->Cr;
+  WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, d->K);
+  if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resblock_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
+  WgradArgs wa; memset(&wa, 0, sizeof(wa));
+  wa.gy = gh; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
+  wa.nseg = d->K;
+  for (int j = 0; j < d->K; ++j) {
+    WSeg& sg = wa.seg[j];
+    sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
+    sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
+    sg.gw = gWd ? gWd + j : nullptr; sg.gw_co_stride = (long)d->Cr * d->K; sg.gw_ci_stride = d->K;
+  }
+  wa.seg[0].gb = gbd;
+  wa.accumulate = accumulate;
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+}

@@ -131,6 +131,10 @@ int vqvae_event_create(void** ev) {
 }
 int vqvae_event_destroy(void* ev) { VQ_CHECK_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
 int vqvae_event_record(void* ev, vqvae_stream_t s) { VQ_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return 0; }
+int vqvae_stream_wait_event(vqvae_stream_t s, void* ev) {
+  VQ_CHECK_HIP(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
+  return 0;
+}
 int vqvae_event_synchronize(void* ev) { VQ_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev)); return 0; }
 int vqvae_event_elapsed_ms(float* ms, void* a, void* b) {
   VQ_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));

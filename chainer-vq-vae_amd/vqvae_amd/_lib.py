@@ -62,6 +62,7 @@ PROTOTYPES = {
     'vqvae_event_destroy': (c_int, [P]),
     'vqvae_event_record': (c_int, [P, P]),
     'vqvae_event_synchronize': (c_int, [P]),
+    'vqvae_stream_wait_event': (c_int, [P, P]),
     'vqvae_event_elapsed_ms': (c_int, [C.POINTER(c_float), P, P]),
     'vqvae_prof_enable': (c_int, [c_int]),
     'vqvae_prof_reset': (c_int, []),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     'vqvae_resblock_bwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P, P,
                                    P, P, P, P, c_int, P, C.POINTER(ResblockGrads), c_int, P,
                                    c_size_t, P]),
+    'vqvae_resblock_wgrad': (c_int, [C.POINTER(ResblockDesc), P, P, P, P, c_int, P, c_size_t, P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
                                         c_size_t, P]),

@@ -12,8 +12,8 @@ import numpy as np
 
 from . import _lib
 
-_state = {'stream': None, 'device': None, 'pool': {}, 'live_bytes': 0, 'pool_bytes': 0,
-          'ws': None}
+_state = {'stream': None, 'side': None, 'device': None, 'pool': {}, 'live_bytes': 0,
+          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': True}
 
 
 def init(device=0):
@@ -52,8 +52,57 @@ def stream():
     return _state['stream']
 
 
+def side_stream():
+    """Second HIP stream for work that is independent of the serial backward/forward chain
+    (weight gradients, the skip GEMM): its workgroups fill the residency tail of the chain's
+    kernels.  Ordering is by events only (record_event / wait_event)."""
+    if _state['side'] is None:
+        stream()
+        s = C.c_void_p()
+        _lib.call('vqvae_stream_create', C.byref(s))
+        _state['side'] = s
+    return _state['side']
+
+
+def overlap_enabled():
+    return _state['overlap']
+
+
+def set_overlap(on):
+    _state['overlap'] = bool(on)
+
+
+class Event(object):
+    """A pooled hipEvent."""
+
+    def __init__(self):
+        if _state['events']:
+            self.h = _state['events'].pop()
+        else:
+            e = C.c_void_p()
+            _lib.call('vqvae_event_create', C.byref(e))
+            self.h = e
+
+    def record(self, s):
+        _lib.call('vqvae_event_record', self.h, s)
+        return self
+
+    def __del__(self):
+        try:
+            _state['events'].append(self.h)
+        except Exception:
+            pass
+
+
+def wait_event(s, event):
+    """Stream ``s`` waits on the GPU until ``event`` has completed."""
+    _lib.call('vqvae_stream_wait_event', s, event.h)
+
+
 def synchronize():
     _lib.call('vqvae_stream_synchronize', stream())
+    if _state['side'] is not None:
+        _lib.call('vqvae_stream_synchronize', _state['side'])
 
 
 def device_info():
@@ -244,10 +293,13 @@ def require_device(*arrays):
 # one growing scratch buffer shared by all entry points (single stream => the
 # kernels that use it are ordered)
 # --------------------------------------------------------------------------- #
-def workspace(nbytes):
-    ws = _state['ws']
+def workspace(nbytes, slot='main'):
+    """Growing scratch buffer; one per stream ('main', 'side').  A buffer is only ever
+    replaced between uses on its own stream (callers size the side buffer before they start
+    enqueueing work that uses it)."""
+    ws = _state['ws'].get(slot)
     if ws is None or ws.nbytes < nbytes:
-        _state['ws'] = None
+        _state['ws'][slot] = None
         ws = DeviceArray((int(nbytes * 1.25) // 4 + 64,), np.float32)
-        _state['ws'] = ws
+        _state['ws'][slot] = ws
     return ws

@@ -186,6 +186,60 @@ class ResidualStackFunction(FunctionNode):
         g_res = None
         ghs = [None] * nb
         g_ress = [None] * nb
+        # Two streams.  The backward-data chain (gz -> gh -> gx, block by block) is serial and
+        # each of its kernels leaves a residency tail (1920 workgroups on 1024 slots); the
+        # weight gradients of block l only need gh_l, so they -- and the pull-back of gh_l to
+        # the latent rate -- run on the side stream and fill those tails.
+        overlap = backend.overlap_enabled()
+        side = backend.side_stream() if overlap else _S()
+        slot = 'side' if overlap else 'main'
+        d0 = self.descs[0]
+        gP = tb = None
+        if lat is not None:
+            Bl, Cc, Tl = lat.shape
+            tb = F.resize_tables(Tl, d0.T)
+            gP = DeviceArray((Bl, nb * d0.Cd, Tl), np.float32)
+        # side-stream scratch, sized once for everything it will run (never regrown mid-flight)
+        # res-conv weight gradients: one batched launch on the MAIN stream after the chain (it
+        # then overlaps with whatever the side stream still has queued); balances the two queues
+        grp = nb + 1
+        need = max(_lib.load().vqvae_resblock_workspace_bytes(C.byref(d0)),
+                   _lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), min(nb, _lib.MAX_STACK_GROUP)))
+        ws_side = backend.workspace(need, slot)
+
+        # skip-conv weight gradients need only g_skip and the saved z_l: start them right away
+        gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
+        gbs = [_grad_out(in_vars[2 + 8 * i + 7], ins[2 + 8 * i + 7].shape) for i in range(nb)]
+        gWr = [None] * nb
+        gbr = [None] * nb
+        if overlap:
+            backend.wait_event(side, backend.Event().record(_S()))       # g_skip is ready
+        for lo, hi in _groups(nb):
+            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
+            _lib.call('vqvae_resstack_skip_wgrad', C.byref(d0), hi - lo, g_skip.ptr, zs,
+                      _lib.ptr_array(gWs[lo:hi]), _lib.ptr_array(gbs[lo:hi]), 0, ws_side.ptr,
+                      ws_side.nbytes, side)
+
+        pending = [nb]          # res-conv weight gradients are issued for blocks [lo, pending)
+
+        def flush_res(lo):
+            """gWr_l, gbr_l for blocks lo..pending-1 (their g_res_l exist once the chain has
+            passed block l+1)."""
+            hi = pending[0]
+            if hi <= lo:
+                return
+            for i in range(lo, hi):
+                if g_ress[i] is not None:
+                    gWr[i] = _grad_out(in_vars[2 + 8 * i + 4], ins[2 + 8 * i + 4].shape)
+                    gbr[i] = _grad_out(in_vars[2 + 8 * i + 5], ins[2 + 8 * i + 5].shape)
+            for glo, ghi in _groups(hi - lo):
+                a, b = lo + glo, lo + ghi
+                wsm = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), b - a))
+                zs = _lib.ptr_array([self.saved[i][2] for i in range(a, b)])
+                _lib.call('vqvae_resstack_res_wgrad', C.byref(d0), b - a, _lib.ptr_array(g_ress[a:b]), zs,
+                          _lib.ptr_array(gWr[a:b]), _lib.ptr_array(gbr[a:b]), 0, wsm.ptr, wsm.nbytes, _S())
+            pending[0] = lo
+
         for i in range(nb - 1, -1, -1):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = ins[2 + 8 * i: 10 + 8 * i]
             d = self.descs[i]
@@ -194,32 +248,46 @@ class ResidualStackFunction(FunctionNode):
             need_gx = (i > 0) or (0 in indexes)
             gx = DeviceArray(h.shape, np.float32) if need_gx else None
             gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(4)]
-            if lat is not None:
-                gp[2] = gp[3] = None           # condition_proj grads: one latent-rate conv, below
-            gp += [None, None, None, None]     # res / skip conv grads: one launch each, below
             g_ress[i] = g_res                  # None for the last block: residual unused
-            grd = _lib.ResblockGrads(*[_p(a) for a in gp])
             gh = DeviceArray((d.B, d.Cd, d.T), np.float32)
             ws = _rb_workspace(d)
-            _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr,
-                      None if lat is not None else cond.ptr, gates.ptr,
-                      z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(grd), 0,
-                      ws.ptr, ws.nbytes, _S())
+            if lat is not None:
+                # chain on the main stream: gz, gate derivative -> gh, then gx
+                none = _lib.ResblockGrads(*([None] * 8))
+                _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, None, gates.ptr,
+                          z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(none), 0,
+                          ws.ptr, ws.nbytes, _S())
+                if overlap:
+                    backend.wait_event(side, backend.Event().record(_S()))
+                _lib.call('vqvae_resblock_wgrad', C.byref(d), h.ptr, gh.ptr, gp[0].ptr, gp[1].ptr, 0,
+                          ws_side.ptr, ws_side.nbytes, side)
+                _lib.call('vqvae_upsample_linear_bwd', gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
+                          tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
+                          tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, side)
+                gp[2] = gp[3] = None           # condition_proj grads: one latent-rate conv, below
+            else:
+                grd = _lib.ResblockGrads(*([_p(a) for a in gp] + [None] * 4))
+                _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, gates.ptr,
+                          z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(grd), 0,
+                          ws.ptr, ws.nbytes, _S())
+            gp += [None, None, None, None]     # res / skip conv grads: batched launches
             grads[2 + 8 * i: 10 + 8 * i] = gp
             ghs[i] = gh
             g_res = gx
+            if pending[0] - i >= grp:          # g_res of blocks i .. pending-1 are all available
+                flush_res(i)
         d = self.descs[0]
+        # weight gradients of the res convs of the blocks not yet covered (those nearest the input)
+        flush_res(0)
+        if overlap:
+            # join: everything issued after this point on the main stream (and everything the
+            # caller issues after backward returns) is ordered behind the side stream's work
+            backend.wait_event(_S(), backend.Event().record(side))
         if lat is not None:
-            # pull every block's gh back to the latent rate (adjoint of the epilogue lerp), then
-            # the (nb*Cd, Cc) 1x1 conv's own backward gives gWc_l, gbc_l and the condition grad
+            # every block's gh has been pulled back to the latent rate (adjoint of the epilogue
+            # lerp) on the side stream; the (nb*Cd, Cc) 1x1 conv's own backward then gives
+            # gWc_l, gbc_l and the condition gradient
             B, Cc, Tl = lat.shape
-            T = d.T
-            tb = F.resize_tables(Tl, T)
-            gP = DeviceArray((B, nb * d.Cd, Tl), np.float32)
-            for i in range(nb):
-                _lib.call('vqvae_upsample_linear_bwd', ghs[i].ptr, d.Cd * T, B, d.Cd, Tl, T,
-                          tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
-                          tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, _S())
             wsc = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
             gWc_all = DeviceArray(self.Wc_all.shape, np.float32)
             gbc_all = DeviceArray((nb * d.Cd,), np.float32)
@@ -248,20 +316,6 @@ class ResidualStackFunction(FunctionNode):
                 _lib.call('vqvae_resstack_gcond_bwd', C.byref(d), hi - lo, Wc, _lib.ptr_array(ghs[lo:hi]),
                           gcond.ptr, 0 if lo == 0 else 1, ws.ptr, ws.nbytes, _S())
             grads[1] = gcond
-        gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
-        gbs = [_grad_out(in_vars[2 + 8 * i + 7], ins[2 + 8 * i + 7].shape) for i in range(nb)]
-        gWr = [None if g_ress[i] is None else
-               _grad_out(in_vars[2 + 8 * i + 4], ins[2 + 8 * i + 4].shape) for i in range(nb)]
-        gbr = [None if g_ress[i] is None else
-               _grad_out(in_vars[2 + 8 * i + 5], ins[2 + 8 * i + 5].shape) for i in range(nb)]
-        for lo, hi in _groups(nb):
-            n = hi - lo
-            ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), n))
-            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
-            _lib.call('vqvae_resstack_skip_wgrad', C.byref(d), n, g_skip.ptr, zs,
-                      _lib.ptr_array(gWs[lo:hi]), _lib.ptr_array(gbs[lo:hi]), 0, ws.ptr, ws.nbytes, _S())
-            _lib.call('vqvae_resstack_res_wgrad', C.byref(d), n, _lib.ptr_array(g_ress[lo:hi]), zs,
-                      _lib.ptr_array(gWr[lo:hi]), _lib.ptr_array(gbr[lo:hi]), 0, ws.ptr, ws.nbytes, _S())
         for i in range(nb):
             grads[2 + 8 * i + 4] = gWr[i]
             grads[2 + 8 * i + 5] = gbr[i]

@@ -59,6 +59,7 @@ int vqvae_event_create(void** ev);
 int vqvae_event_destroy(void* ev);
 int vqvae_event_record(void* ev, vqvae_stream_t s);
 int vqvae_event_synchronize(void* ev);
+int vqvae_stream_wait_event(vqvae_stream_t s, void* ev);   /* s waits (on the GPU) for ev */
 int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline).
@@ -162,6 +163,13 @@ int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params
                        float* gx, float* gcond, int gcond_accumulate, float* gh_out,
                        const vqvae_resblock_grads* g, int grads_accumulate, void* ws,
                        size_t ws_bytes, vqvae_stream_t s);
+
+/* Weight gradients of the dilated conv only: gWd (+)= gh x_taps^T, gbd (+)= rowsum(gh), from
+ * the gh that vqvae_resblock_bwd wrote to gh_out.  Split out so ResidualNet can run it on a
+ * second stream, concurrently with the next block's backward-data chain.              */
+int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x, const float* gh,
+                         float* gWd, float* gbd, int accumulate, void* ws, size_t ws_bytes,
+                         vqvae_stream_t s);
 
 /* ---- ResidualNet-level contractions (WaveNet/modules.py:89-96): the arguments are
  *      HOST arrays of nblocks (<= 24) device pointers.

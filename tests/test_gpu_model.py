@@ -149,3 +149,36 @@ def test_snapshot_resume_is_bit_identical(gpu, tmp_path):
     it2.i = 2
     upd2.update()
     np.testing.assert_array_equal(opt2.params.get(), want)
+
+
+def test_two_stream_backward_is_deterministic_and_equals_single_stream(gpu):
+    """The side-stream weight-gradient overlap must not change a single bit: (a) repeated runs
+    from identical state agree bitwise (a race would show up as run-to-run differences),
+    (b) the overlapped schedule equals the single-stream schedule bitwise."""
+    import vqvae_amd as V
+    from vqvae_amd import backend
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL, residual=128, dilated=128, skip=128, n_layer=6)
+    batches = [O.synth_batch(4, length=2048, n_speaker=cfg['n_speaker'], seed=50 + s) for s in range(2)]
+
+    def run(overlap):
+        backend.set_overlap(overlap)
+        try:
+            _, model = H.build_model(cfg, seed=7, ema_decay=0.999)
+            model.to_gpu()
+            opt = Adam(2e-4)
+            opt.setup(model)
+            upd = V.VQVAE_StandardUpdater(_Iter(batches), opt, device=0)
+            for _ in range(3):
+                upd.update()
+            return opt.params.get(), opt.grads.get()
+        finally:
+            backend.set_overlap(True)
+    p0, g0 = run(True)
+    for _ in range(3):
+        p1, g1 = run(True)
+        np.testing.assert_array_equal(g1, g0)
+        np.testing.assert_array_equal(p1, p0)
+    p2, g2 = run(False)
+    np.testing.assert_array_equal(g2, g0)
+    np.testing.assert_array_equal(p2, p0)
