@@ -112,6 +112,196 @@ __global__ __launch_bounds__(64 * NW) void vq_mfma_kernel(
   }
 }
 
+// Register-resident variant for d == 2*DP (64 or 128): each wavefront keeps the B fragment of
+// its 32 latent columns in DP VGPRs for the whole sweep, the codebook streams through LDS in
+// double-buffered tiles of 64 codes (two independent 32x32 accumulators per wave keep the
+// matrix pipe issuing back to back), one barrier per tile.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void vq_mfma_reg_kernel(
+    const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ wn,
+    const int* __restrict__ wmax_bits, int B, int T, int k,
+    int32_t* __restrict__ idx, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+  constexpr int D = 2 * DP, WP = D + 1, TILE = 64;
+  extern __shared__ float smem[];          // Wt[2][TILE][WP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long N = (long)B * T;
+  const long n = (long)blockIdx.x * 128 + wave * 32 + li;      // this lane's latent column
+  // B fragment: lane (k = lk, j = li) holds z[c = 2*kk + lk][column li] for every kk
+  float zf[DP];
+  float zn = 0.f;
+  {
+    const bool ok = n < N;
+    const long bb = ok ? n / T : 0, t = ok ? n % T : 0;
+    const float* zp = z + (bb * D) * T + t;
+#pragma unroll
+    for (int kk = 0; kk < DP; ++kk) {
+      zf[kk] = ok ? zp[(long)(2 * kk + lk) * T] : 0.f;
+      zn = fmaf(zf[kk], zf[kk], zn);
+    }
+    zn += __shfl_xor(zn, 32, 64);           // both halves of the column
+  }
+  // staging role: thread loads 8 float4 of a 64 x D tile (row-contiguous) per tile
+  constexpr int F4_PER_ROW = D / 4, F4_PER_THREAD = TILE * F4_PER_ROW / 256;
+  float4 st[F4_PER_THREAD];
+  auto load_tile = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      const int j = jt * TILE + r;
+      st[i] = j < k ? *reinterpret_cast<const float4*>(W + (long)j * D + 4 * c4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* wt = smem + (size_t)buf * TILE * WP;
+#pragma unroll
+    for (int i = 0; i < F4_PER_THREAD; ++i) {
+      const int f = tid + 256 * i;
+      const int r = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+      float* p = wt + r * WP + 4 * c4;
+      p[0] = st[i].x; p[1] = st[i].y; p[2] = st[i].z; p[3] = st[i].w;
+    }
+  };
+  float m1 = INFINITY, m2 = INFINITY;
+  int i1 = 0x7fffffff;
+  const int ntile = (k + TILE - 1) / TILE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int jt = 0; jt < ntile; ++jt) {
+    const int cur = jt & 1;
+    if (jt + 1 < ntile) load_tile(jt + 1);
+    const float* wt = smem + (size_t)cur * TILE * WP;
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    const float* w0 = wt + li * WP + lk;
+    const float* w1 = w0 + 32 * WP;
+#pragma unroll
+    for (int kk = 0; kk < DP; ++kk) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[2 * kk], zf[kk], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[2 * kk], zf[kk], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (j < k) {
+          const float v = fmaf(-2.f, h ? a1[r] : a0[r], wn[j]);
+          if (v < m1) { m2 = m1; m1 = v; i1 = j; }
+          else if (v < m2) { m2 = v; }
+        }
+      }
+    if (jt + 1 < ntile) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  {
+    const float om1 = __shfl_xor(m1, 32, 64);
+    const float om2 = __shfl_xor(m2, 32, 64);
+    const int oi1 = __shfl_xor(i1, 32, 64);
+    if (om1 < m1 || (om1 == m1 && oi1 < i1)) { m2 = fminf(m1, om2); m1 = om1; i1 = oi1; }
+    else { m2 = fminf(m2, om1); }
+  }
+  if (lk == 0 && n < N) {
+    const float wmax = __int_as_float(*wmax_bits);
+    const float band = 12.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
+    idx[n] = i1;
+    if (!(m2 - m1 > band)) {
+      const int slot = atomicAdd(nflag, 1);
+      flagged[slot] = (int32_t)n;
+    }
+  }
+}
+
+// Exact re-evaluation, batched: a workgroup takes R queued rows at a time and streams the
+// codebook through LDS in [256 codes][32 c] chunks (coalesced loads, conflict-free reads);
+// thread j owns code j of the chunk and carries the R running sums in the reference's order
+// (sequential over c; sub, mul, add individually rounded).  Codebook traffic drops R-fold
+// versus one row per workgroup.
+template <int R>
+__global__ __launch_bounds__(256) void vq_exact_batched_kernel(
+    const float* __restrict__ z, const float* __restrict__ W, int B, int d, int T, int k,
+    const int32_t* __restrict__ list, const int32_t* __restrict__ nlist, int32_t* __restrict__ idx) {
+  constexpr int CH = 32, WPC = CH + 1;
+  extern __shared__ float smem[];
+  float* zs = smem;                      // [R][d]
+  float* wt = zs + R * d;                // [256][WPC]
+  float* rv = wt + 256 * WPC;            // [256]
+  int* ri = (int*)(rv + 256);            // [256]
+  const int tid = threadIdx.x;
+  const long count = (long)(*nlist);
+  for (long q0 = (long)blockIdx.x * R; q0 < count; q0 += (long)gridDim.x * R) {
+    __syncthreads();
+    for (int e = tid; e < R * d; e += 256) {
+      const int r = e / d, c = e % d;
+      float v = 0.f;
+      if (q0 + r < count) { const long n = list[q0 + r]; v = z[((n / T) * d + c) * T + n % T]; }
+      zs[e] = v;
+    }
+    float best[R];
+    int bi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = INFINITY; bi[r] = 0x7fffffff; }
+    for (int j0 = 0; j0 < k; j0 += 256) {
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      for (int c0 = 0; c0 < d; c0 += CH) {
+        __syncthreads();
+        // coalesced: 8 threads cover one code's 32-float (128-B) chunk as float4
+        for (int f = tid; f < 256 * (CH / 4); f += 256) {
+          const int r = f / (CH / 4), c4 = f % (CH / 4);
+          const int j = j0 + r, c = c0 + 4 * c4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < k) {
+            const float* wp = W + (long)j * d + c;
+            if (c + 3 < d && (d & 3) == 0) v = *reinterpret_cast<const float4*>(wp);
+            else { if (c < d) v.x = wp[0]; if (c + 1 < d) v.y = wp[1]; if (c + 2 < d) v.z = wp[2]; if (c + 3 < d) v.w = wp[3]; }
+          }
+          float* p = wt + r * WPC + 4 * c4;
+          p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+        }
+        __syncthreads();
+        const float* wr = wt + tid * WPC;
+        const int cmax = min(CH, d - c0);
+        for (int c = 0; c < cmax; ++c) {
+          const float w = wr[c];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float df = __fsub_rn(zs[r * d + c0 + c], w);
+            acc[r] = __fadd_rn(acc[r], __fmul_rn(df, df));
+          }
+        }
+      }
+      const int j = j0 + tid;
+      if (j < k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (acc[r] < best[r] || bi[r] == 0x7fffffff) { best[r] = acc[r]; bi[r] = j; }   // j ascends
+      }
+    }
+    for (int r = 0; r < R; ++r) {
+      if (q0 + r >= count) break;
+      __syncthreads();
+      rv[tid] = best[r];
+      ri[tid] = bi[r];
+      __syncthreads();
+      for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) {
+          const float ov = rv[tid + s], mv = rv[tid];
+          const int oi = ri[tid + s], mi = ri[tid];
+          if (oi != 0x7fffffff && (mi == 0x7fffffff || ov < mv || (ov == mv && oi < mi))) { rv[tid] = ov; ri[tid] = oi; }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) idx[list[q0 + r]] = ri[0];
+    }
+  }
+}
+
 // exact evaluation in the reference's order for the queued rows (list != null) or
 // for every row (list == null).  One 256-thread block per row.
 __global__ __launch_bounds__(256) void vq_exact_kernel(
@@ -299,6 +489,18 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
     hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
+    if (d == 64 || d == 128) {
+      const size_t lds = 2 * 64 * (size_t)(d + 1) * 4;
+      const unsigned grid = (unsigned)((N + 127) / 128);
+      if (d == 64) {
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_reg_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_mfma_reg_kernel<32>, dim3(grid), dim3(256), lds, st, z, W, wn, wmax_bits, B, T, k, idx, flagged, nflag);
+      } else {
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_reg_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_mfma_reg_kernel<64>, dim3(grid), dim3(256), lds, st, z, W, wn, wmax_bits, B, T, k, idx, flagged, nflag);
+      }
+      VQ_LAUNCH_CHECK();
+    } else {
     const int NC = 32 * nw;
     const size_t lds = ((size_t)dpad * NC + 32 * (size_t)(dpad + 1)) * 4;
     const unsigned grid = (unsigned)((N + NC - 1) / NC);
@@ -313,10 +515,17 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
       hipLaunchKernelGGL(vq_mfma_kernel<1>, dim3(grid), dim3(64), lds, st, z, W, wn, wmax_bits, B, d, T, k, dpad, idx, flagged, nflag);
     }
     VQ_LAUNCH_CHECK();
-    const size_t lds2 = ((size_t)d + 512) * 4;
-    unsigned g2 = (unsigned)(N < 4096 ? N : 4096);
-    hipLaunchKernelGGL(vq_exact_kernel, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, flagged, nflag, idx);
-    VQ_LAUNCH_CHECK();
+    }
+    {
+      // exact re-check of the queued rows, 8 rows per workgroup pass
+      constexpr int R = 8;
+      const size_t lds2 = ((size_t)R * d + 256 * 33 + 512) * 4;
+      VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_exact_batched_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const long maxb = (N + R - 1) / R;
+      unsigned g2 = (unsigned)(maxb < 2048 ? maxb : 2048);
+      hipLaunchKernelGGL(vq_exact_batched_kernel<R>, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, flagged, nflag, idx);
+      VQ_LAUNCH_CHECK();
+    }
     if (n_rechecked) VQ_CHECK_HIP(hipMemcpyAsync(n_rechecked, nflag, 4, hipMemcpyDeviceToDevice, st));
   } else {
     const size_t lds2 = ((size_t)d + 512) * 4;
