@@ -701,6 +701,34 @@ def synth_batch(B, length=7680, quantize=256, n_speaker=109, seed=71, sr=16000,
     return raw, np.ascontiguousarray(x_dec), speaker, t
 
 
+def preprocess_contract(raw, length, quantize=256, start=0, mu_law_input=True, use_logistic=False,
+                        speaker_id=0):
+    """The array half of Preprocess.__call__ (utils.py:57-110) for an already loaded and trimmed
+    waveform: peak-normalise, mu-law, pad with zeros / bin quantize//2 or crop `length+1`
+    samples at `start`, one-hot, and the 4-tuple (raw, x_dec, speaker, t)."""
+    L = length + 1
+    raw = raw / np.abs(raw).max()                                         # utils.py:58
+    raw = raw.astype(np.float32)
+    q = MuLaw(quantize).transform(raw) if (mu_law_input or not use_logistic) else None   # utils.py:62
+    if len(raw) <= L:                                                     # utils.py:66-75
+        pad = L - len(raw)
+        raw = np.concatenate((raw, np.zeros(pad, dtype=np.float32)))
+        if q is not None:
+            q = np.concatenate((q, quantize // 2 * np.ones(pad))).astype(np.int32)
+    else:                                                                 # utils.py:76-81
+        raw = raw[start:start + L]
+        if q is not None:
+            q = q[start:start + L]
+    raw4 = raw[None, :, None]                                             # utils.py:88-89
+    if mu_law_input:
+        one_hot = np.identity(quantize, dtype=np.float32)[q]              # utils.py:85-87
+        x_dec = np.expand_dims(one_hot.T, 2)[:, :-1]
+    else:
+        x_dec = raw4[:, :-1]
+    t = raw4[:, 1:] if use_logistic else np.expand_dims(q, 1)[1:]         # utils.py:105-109
+    return raw4, x_dec, np.array(speaker_id, dtype=np.int32), t
+
+
 def synth_batch_raw(B, length=7680, n_speaker=109, seed=71, dtype=np.float32):
     """The use_logistic / input_dim=1 variant of Preprocess's contract
     (utils.py:104, 107): x_dec = raw[:, :-1], t = raw[:, 1:], both (B,1,L) float."""

@@ -182,6 +182,33 @@ def main():
                         seed_z=1, seed_w=2, seed_gy=3, shape=np.array([B, d, T, k]),
                         idx=idx, gW_rows=nz.astype(np.int32), gW_vals=gW[nz],
                         e_sum=np.float64(e.astype(np.float64).sum()))
+    # ---- Preprocess output contract (utils.py:54-110): pad / crop / one-hot / speaker id,
+    #      with librosa.load / effects.trim stubbed to hand back a synthetic waveform -------- #
+    import random
+    import tempfile
+    lib = sys.modules['librosa']
+    waves = {}
+    lib.load = lambda path, sr, res_type=None: (waves[os.path.basename(path)].copy(), sr)
+    lib.effects = types.SimpleNamespace(trim=lambda raw, top_db: (raw, None))
+    root = tempfile.mkdtemp()
+    for spk in ('p225', 'p226', 'p227'):
+        os.makedirs(os.path.join(root, 'wav48', spk))
+    rs = np.random.RandomState(17)
+    waves['short.wav'] = (0.3 * rs.standard_normal(100)).astype(np.float32)      # padding branch
+    waves['long.wav'] = (0.3 * rs.standard_normal(700)).astype(np.float32)       # cropping branch
+    out = {}
+    for use_logistic, input_dim, tag in ((False, 256, 'mulaw'), (True, 1, 'logistic')):
+        pre = utils.Preprocess(16000, 'kaiser_fast', 20, input_dim, 256, 255, use_logistic, root, 'VCTK')
+        for name, spk in (('short.wav', 'p226'), ('long.wav', 'p227')):
+            random.seed(5)
+            raw, x_dec, speaker, t = pre(os.path.join(root, 'wav48', spk, name))
+            key = '%s_%s_' % (tag, name.split('.')[0])
+            out[key + 'raw'], out[key + 'x_dec'] = raw, x_dec
+            out[key + 'speaker'], out[key + 't'] = speaker, t
+    out['wave_short'], out['wave_long'] = waves['short.wav'], waves['long.wav']
+    random.seed(5)
+    out['crop_start'] = np.int64(random.randint(0, 700 - 256 - 1))               # utils.py:78
+    np.savez_compressed(os.path.join(HERE, 'preprocess.npz'), **out)
     print('golden vectors written to', HERE)
 
 

@@ -268,3 +268,21 @@ def test_mol_grad_fd():
     g = O.mol_loss_bwd(y, t)
     np.testing.assert_allclose(g, _fd(f, y, 1e-6), rtol=2e-5, atol=1e-9)
     assert g[0, 6, 0] == 0.0
+
+
+def test_preprocess_contract_golden():
+    """Input contract of the hot path, pinned by running the reference's Preprocess.__call__
+    (utils.py:54-110, librosa stubbed) on synthetic waveforms: padding and cropping branches,
+    mu-law/one-hot and raw/logistic variants, shapes, dtypes and values."""
+    g = np.load(os.path.join(GOLD, 'preprocess.npz'))
+    for tag, mu_in, logi in (('mulaw', True, False), ('logistic', False, True)):
+        for name, spk in (('short', 1), ('long', 2)):          # sorted speakers p225,p226,p227
+            raw, x_dec, speaker, t = O.preprocess_contract(
+                g['wave_' + name], 255, 256, int(g['crop_start']), mu_in, logi, spk)
+            key = '%s_%s_' % (tag, name)
+            for got, k in ((raw, 'raw'), (x_dec, 'x_dec'), (speaker, 'speaker'), (t, 't')):
+                want = g[key + k]
+                assert got.shape == want.shape and got.dtype == want.dtype, (key + k, got.shape, want.shape, got.dtype, want.dtype)
+                np.testing.assert_array_equal(got, want)
+    assert g['mulaw_short_x_dec'].shape == (256, 255, 1) and g['mulaw_short_t'].shape == (255, 1)
+    assert g['mulaw_short_t'][-1, 0] == 128          # padded with bin quantize//2 (utils.py:74)
