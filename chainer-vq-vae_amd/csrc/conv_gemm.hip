@@ -27,7 +27,7 @@ namespace vq {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
+constexpr int BM = 128, BN = 128, BK = 16, NT = 256;   // wgrad tiles; conv_gemm derives BM/NT from WM
 constexpr int MAXSEG = 24;   // a whole ResidualNet's blocks can feed one contraction
 constexpr int MAXTAPS = 4;
 
@@ -82,8 +82,11 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return x >= 0.f ? r : 1.f - r;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
+// WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
+// halves the activation-tile loads per FLOP and is used whenever M >= 256.
+template <int EPI, int WM>
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(const GemmArgs a) {
+  constexpr int BM = 64 * WM, NT = 128 * WM;
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
 
@@ -120,9 +123,12 @@ __global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
   float4 rb0, rb1;
   bool rvec = false;
 
-  // thread roles for the staging loads
-  const int a_k = tid >> 5, a_col = (tid & 31) * 4;   // A (and vector B): rows a_k, a_k+8
-  const int b_n = tid & 127, b_k = tid >> 7;          // scalar B: rows b_k + 2i
+  // thread roles for the staging loads (per K step: A = 16 x BM, B = 16 x 128 floats)
+  constexpr int ACOLS4 = BM / 4;                        // float4 per A row
+  const int a_k = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;    // A: rows a_k, a_k + 8
+  const int v_k = tid >> 5, v_col = (tid & 31) * 4;     // vector B: row v_k (+8 when WM == 2)
+  constexpr int BROWS = NT / 128;                        // scalar B: rows b_k + BROWS*i
+  const int b_n = tid & 127, b_k = tid >> 7;
 
   auto load_tiles = [&](int s, int c0) {
     const Seg& sg = a.seg[s];
@@ -133,11 +139,11 @@ __global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
     const int tw = t0 * sg.tmul + sg.toff;   // window start (when tmul==1,tdiv==1)
     rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
     if (rvec) {
-      const int ci0 = c0 + a_k, ci1 = c0 + a_k + 8;
+      const int ci0 = c0 + v_k, ci1 = c0 + v_k + 8;
       rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
       rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ci0 < sg.cin) rb0 = *reinterpret_cast<const float4*>(xb + (long)ci0 * sg.x_cstride + tw + a_col);
-      if (ci1 < sg.cin) rb1 = *reinterpret_cast<const float4*>(xb + (long)ci1 * sg.x_cstride + tw + a_col);
+      if (ci0 < sg.cin) rb0 = *reinterpret_cast<const float4*>(xb + (long)ci0 * sg.x_cstride + tw + v_col);
+      if (WM == 2 && ci1 < sg.cin) rb1 = *reinterpret_cast<const float4*>(xb + (long)ci1 * sg.x_cstride + tw + v_col);
     } else {
       const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
       bool ok = tnum >= 0;
@@ -145,29 +151,33 @@ __global__ __launch_bounds__(NT, 4) void conv_gemm_kernel(const GemmArgs a) {
       if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
       ok = ok && tin < sg.Tin;
       const float* xp = xb + (long)(c0 + b_k) * sg.x_cstride + tin;
-      const long cs2 = 2L * sg.x_cstride;
+      const long csr = (long)BROWS * sg.x_cstride;
       const int cb = c0 + b_k;
-      rb0.x = (ok && cb + 0 < sg.cin) ? xp[0 * cs2] : 0.f;
-      rb0.y = (ok && cb + 2 < sg.cin) ? xp[1 * cs2] : 0.f;
-      rb0.z = (ok && cb + 4 < sg.cin) ? xp[2 * cs2] : 0.f;
-      rb0.w = (ok && cb + 6 < sg.cin) ? xp[3 * cs2] : 0.f;
-      rb1.x = (ok && cb + 8 < sg.cin) ? xp[4 * cs2] : 0.f;
-      rb1.y = (ok && cb + 10 < sg.cin) ? xp[5 * cs2] : 0.f;
-      rb1.z = (ok && cb + 12 < sg.cin) ? xp[6 * cs2] : 0.f;
-      rb1.w = (ok && cb + 14 < sg.cin) ? xp[7 * cs2] : 0.f;
+      rb0.x = (ok && cb + 0 * BROWS < sg.cin) ? xp[0 * csr] : 0.f;
+      rb0.y = (ok && cb + 1 * BROWS < sg.cin) ? xp[1 * csr] : 0.f;
+      rb0.z = (ok && cb + 2 * BROWS < sg.cin) ? xp[2 * csr] : 0.f;
+      rb0.w = (ok && cb + 3 * BROWS < sg.cin) ? xp[3 * csr] : 0.f;
+      if (WM == 2) {
+        rb1.x = (ok && cb + 4 * BROWS < sg.cin) ? xp[4 * csr] : 0.f;
+        rb1.y = (ok && cb + 5 * BROWS < sg.cin) ? xp[5 * csr] : 0.f;
+        rb1.z = (ok && cb + 6 * BROWS < sg.cin) ? xp[6 * csr] : 0.f;
+        rb1.w = (ok && cb + 7 * BROWS < sg.cin) ? xp[7 * csr] : 0.f;
+      }
     }
   };
   auto store_tiles = [&](int buf) {
     *reinterpret_cast<float4*>(&As[buf][a_k][a_col]) = ra0;
     *reinterpret_cast<float4*>(&As[buf][a_k + 8][a_col]) = ra1;
     if (rvec) {
-      *reinterpret_cast<float4*>(&Bs[buf][a_k][a_col]) = rb0;
-      *reinterpret_cast<float4*>(&Bs[buf][a_k + 8][a_col]) = rb1;
+      *reinterpret_cast<float4*>(&Bs[buf][v_k][v_col]) = rb0;
+      if (WM == 2) *reinterpret_cast<float4*>(&Bs[buf][v_k + 8][v_col]) = rb1;
     } else {
-      Bs[buf][b_k + 0][b_n] = rb0.x;  Bs[buf][b_k + 2][b_n] = rb0.y;
-      Bs[buf][b_k + 4][b_n] = rb0.z;  Bs[buf][b_k + 6][b_n] = rb0.w;
-      Bs[buf][b_k + 8][b_n] = rb1.x;  Bs[buf][b_k + 10][b_n] = rb1.y;
-      Bs[buf][b_k + 12][b_n] = rb1.z; Bs[buf][b_k + 14][b_n] = rb1.w;
+      Bs[buf][b_k + 0 * BROWS][b_n] = rb0.x;  Bs[buf][b_k + 1 * BROWS][b_n] = rb0.y;
+      Bs[buf][b_k + 2 * BROWS][b_n] = rb0.z;  Bs[buf][b_k + 3 * BROWS][b_n] = rb0.w;
+      if (WM == 2) {
+        Bs[buf][b_k + 4 * BROWS][b_n] = rb1.x;  Bs[buf][b_k + 5 * BROWS][b_n] = rb1.y;
+        Bs[buf][b_k + 6 * BROWS][b_n] = rb1.z;  Bs[buf][b_k + 7 * BROWS][b_n] = rb1.w;
+      }
     }
   };
 
@@ -630,7 +640,9 @@ static bool seg_vec_ok(const Seg& s) {
 
 template <int EPI>
 static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
-  g.ntile_m = cdiv(g.M, BM);
+  const bool big = (g.M % 256 == 0) && (EPI != EPI_GATE_BWD);    // 256-row tiles (8 waves)
+  const int bm = big ? 256 : 128;
+  g.ntile_m = cdiv(g.M, bm);
   g.ntile_n = cdiv(g.Tout, BN);
   for (int i = 0; i < g.nseg; ++i) g.seg[i].vec = seg_vec_ok(g.seg[i]) ? 1 : 0;
   if (EPI == EPI_LINEAR && g.out[1].y != nullptr)
@@ -640,7 +652,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if (nblk <= 0) return 0;
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
   ProfScope ps(tag, st);
-  hipLaunchKernelGGL(conv_gemm_kernel<EPI>, dim3((unsigned)nblk), dim3(NT), 0, st, g);
+  if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2>), dim3((unsigned)nblk), dim3(256), 0, st, g);
   VQ_LAUNCH_CHECK();
   return 0;
 }
