@@ -182,3 +182,38 @@ def test_two_stream_backward_is_deterministic_and_equals_single_stream(gpu):
     p2, g2 = run(False)
     np.testing.assert_array_equal(g2, g0)
     np.testing.assert_array_equal(p2, p0)
+
+
+def test_evaluator_uses_ema_weights(gpu):
+    """Evaluation runs with config.train=False, i.e. on the EMA copy (utils.py:156-157): after
+    training steps the target and EMA weights differ, so the validation loss must equal the
+    oracle's forward with the EMA decoder, not with the live one."""
+    import copy
+    import vqvae_amd as V
+    from vqvae_amd.evaluator import Evaluator
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    P, model = H.build_model(cfg, seed=8, ema_decay=0.5)
+    P_ema = copy.deepcopy(P['decoder'])
+    model.to_gpu()
+    opt = Adam(5e-3)
+    opt.setup(model)
+    batches = [O.synth_batch(2, length=512, n_speaker=cfg['n_speaker'], seed=80 + s) for s in range(3)]
+    upd = V.VQVAE_StandardUpdater(_Iter(batches), opt, device=0)
+    state = {}
+    for s in range(2):
+        upd.update()
+        O.train_step(P, state, batches[s], cfg['n_loop'], cfg['n_layer'], alpha=5e-3, ema=P_ema, ema_decay=0.5)
+
+    class Once(_Iter):
+        def next(self):
+            if self.i >= 1:
+                raise StopIteration
+            return _Iter.next(self)
+    rep = Evaluator(Once([batches[2]]), model, device=0).evaluate()
+    P_eval = dict(P, decoder=P_ema)
+    (l1, l2, l3), _ = O.vae_forward(P_eval, *batches[2], cfg['n_loop'], cfg['n_layer'])
+    (l1_live, _, _), _ = O.vae_forward(P, *batches[2], cfg['n_loop'], cfg['n_layer'])
+    assert abs(float(l1) - float(l1_live)) > 1e-3            # the two decoders really differ
+    assert_close(rep['validation/main/loss1'], float(l1), 1e-4, 'validation loss1 (EMA weights)')
+    assert_close(rep['validation/main/loss2'], float(l2), 1e-4, 'validation loss2')
