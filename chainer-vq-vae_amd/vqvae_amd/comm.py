@@ -10,9 +10,9 @@ keyed by the launcher's (MASTER_PORT, parent pid); the launcher
 (`python -m torch.distributed.run`) only supplies RANK/WORLD_SIZE/MASTER_* --
 torch itself is never imported in a GPU process (it bundles its own HIP runtime).
 
-``GlooHostCommunicator`` -- the same interface over torch.distributed/gloo on
-host NumPy buffers; used by the world_size-2 CPU tests of the shard/sum/lr
-logic, never on the GPU path.
+The world_size-2 CPU tests drive the same shard / sum / lr logic through a
+gloo-backed communicator with this interface that lives in tests/dp_worker.py
+(torch is test tooling only; nothing in this package imports it).
 """
 import ctypes as C
 import os
@@ -122,28 +122,3 @@ class RcclCommunicator(object):
         if self._comm is not None:
             self._lib.call('vqvae_comm_destroy', self._comm)
             self._comm = None
-
-
-class GlooHostCommunicator(object):
-    """torch.distributed/gloo on host buffers -- CPU tests only."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self._dist = dist
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
-
-    def allreduce_grad(self, flat):
-        import torch
-        t = torch.from_numpy(flat)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return flat
-
-    def barrier(self):
-        self._dist.barrier()
-
-    def max_scalar(self, v):
-        import torch
-        t = torch.tensor([v], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t[0])

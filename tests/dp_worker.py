@@ -12,10 +12,36 @@ for p in (os.path.join(ROOT, 'chainer-vq-vae_amd'), os.path.join(ROOT, 'oracle')
     sys.path.insert(0, p)
 
 
+class GlooHostCommunicator(object):
+    """The communicator interface of vqvae_amd.comm (rank, size, allreduce_grad, barrier,
+    max_scalar) over torch.distributed/gloo on host NumPy buffers -- CPU tests only."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._dist = dist
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+
+    def allreduce_grad(self, flat):
+        import torch
+        t = torch.from_numpy(flat)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return flat
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def max_scalar(self, v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+
 def run_rank(out_path):
     import torch.distributed as dist
     import vqvae_oracle as O
-    from vqvae_amd.comm import GlooHostCommunicator, scaled_alpha, shard
+    from vqvae_amd.comm import scaled_alpha, shard
     dist.init_process_group('gloo')
     comm = GlooHostCommunicator()
     cfg = dict(d=8, k=16, n_loop=1, n_layer=3, residual=16, dilated=32, skip=16, out_dim=256,
