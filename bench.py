@@ -159,6 +159,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=CFG['batch_per_gpu'])
+    ap.add_argument('--index-input', action='store_true',
+                    help='feed x_dec as mu-law bin indices produced on the device (device-side input '
+                         'pipeline) instead of the reference\'s one-hot float tensor')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -187,7 +190,12 @@ def main():
     shards = []
     for s in range(2):                      # two distinct resident minibatches, alternated
         ex = synth_examples(B, cfg, seed=71 + 1000 * rank + s)
-        shards.append(V.concat_examples(ex, device=local))
+        if args.index_input:
+            from vqvae_amd.inputs import DeviceInputPipeline
+            raw = np.stack([e[0][0, :, 0] for e in ex])
+            shards.append(DeviceInputPipeline(cfg['quantize'])(raw, np.array([e[2] for e in ex])))
+        else:
+            shards.append(V.concat_examples(ex, device=local))
     it = ResidentIterator(shards)
     upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local)
 
@@ -239,7 +247,8 @@ def main():
             'value': value, 'unit': 'samples/s', 'n_gpus': n, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic', 'samples_per_sec_per_gpu': value / n,
+            'data': 'synthetic' + (' (x_dec as device-computed bin indices)' if args.index_input else ''),
+            'samples_per_sec_per_gpu': value / n,
             'config': {'workload': 'BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
                                    'd=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256, '
                                    'cond 64+128, EMA 0.9999, Adam lr=2e-4/N' % (1 if n == 1 else 2, B),

@@ -344,6 +344,66 @@ __global__ __launch_bounds__(256) void mol_kernel(const float* __restrict__ y, c
   }
 }
 
+// ---- device-side input pipeline -----------------------------------------
+// mu-law binning by threshold search: thr[j-1] (j = 1..mu-1) is the smallest fp32 input whose
+// NumPy MuLaw.transform (utils.py:18-23) is >= j, found on the host by bisection against that
+// very function; the transform is monotone, so bin(x) = #{j : x >= thr[j-1]} reproduces it bit
+// for bit without re-implementing log/digitize rounding on the device.
+__global__ void mulaw_bins_kernel(const float* __restrict__ x, size_t n, const float* __restrict__ thr,
+                                  int nthr, int32_t* __restrict__ q) {
+  extern __shared__ float sthr[];
+  for (int i = threadIdx.x; i < nthr; i += blockDim.x) sthr[i] = thr[i];
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    int lo = 0, hi = nthr;                 // count of thresholds <= v  (upper bound search)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sthr[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    q[i] = lo;
+  }
+}
+
+// one-hot(idx) as fp32 (B, q, T): what Preprocess feeds the decoder (utils.py:85-87); used by the
+// index-input embed conv's weight gradient so that it stays the dense contraction
+__global__ void onehot_kernel(const int32_t* __restrict__ idx, long idx_bstride, int B, int q, int T,
+                              float* __restrict__ out) {
+  const long total = (long)B * q * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int c = (int)(r % q);
+    const long b = r / q;
+    out[i] = idx[b * idx_bstride + t] == c ? 1.f : 0.f;
+  }
+}
+
+// causal embed conv of a one-hot input, as a gather: y[b,co,t] = bias[co] +
+// sum_tap W[co, idx[b, t-(K-1-tap)], tap]   (zero for negative times; modules.py:127-128,151-152)
+__global__ void embed_gather_kernel(const int32_t* __restrict__ idx, long idx_bstride, int B, int T,
+                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                    int Cout, int q, int K, float* __restrict__ y) {
+  const long total = (long)B * Cout * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long r = i / T;
+    const int co = (int)(r % Cout);
+    const long b = r / Cout;
+    const int32_t* ib = idx + b * idx_bstride;
+    const float* wc = W + (long)co * q * K;
+    float acc = 0.f;
+    for (int tap = 0; tap < K; ++tap) {                 // same order as the GEMM's segments
+      const int ti = t - (K - 1 - tap);
+      if (ti >= 0) acc = __fadd_rn(acc, wc[(long)ib[ti] * K + tap]);
+    }
+    y[i] = bias ? __fadd_rn(acc, bias[co]) : acc;
+  }
+}
+
 // ---- concat / split of equally sized parameter arrays ---------------------------
 struct PtrList32 { float* p[32]; };
 __global__ void concat_kernel(const PtrList32 src, int n, long count, float* __restrict__ dst) {
@@ -513,6 +573,30 @@ int vqvae_mol_nll_bwd(const float* y, const float* t, const float* gloss, int B,
   hipLaunchKernelGGL(mol_kernel<1>, dim3(grid_for(N, 256, 2048)), dim3(256), 0, (hipStream_t)s, y, t, B,
                      n_mixture, T, (float)(127.5 / (quantize - 1)), log_scale_min, gloss,
                      (float)(1.0 / (double)N), (float*)nullptr, gy);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_mulaw_bins(const float* x, size_t n, const float* thresholds, int n_thresholds,
+                     int32_t* q, vqvae_stream_t s) {
+  VQ_REQUIRE(x && thresholds && q && n_thresholds >= 1 && n_thresholds <= 8192, "mulaw_bins: bad arguments");
+  hipLaunchKernelGGL(mulaw_bins_kernel, dim3(grid_for(n)), dim3(256), (size_t)n_thresholds * 4, (hipStream_t)s, x, n, thresholds, n_thresholds, q);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, float* out,
+                 vqvae_stream_t s) {
+  VQ_REQUIRE(idx && out && B > 0 && q > 0 && T > 0, "onehot: bad arguments");
+  hipLaunchKernelGGL(onehot_kernel, dim3(grid_for((size_t)B * q * T, 256, 4096)), dim3(256), 0, (hipStream_t)s, idx, idx_bstride, B, q, T, out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, const float* W,
+                           const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s) {
+  VQ_REQUIRE(idx && W && y && B > 0 && T > 0 && Cout > 0 && q > 0 && K >= 1, "embed_gather_fwd: bad arguments");
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)B * Cout * T, 256, 4096)), dim3(256), 0, (hipStream_t)s, idx, idx_bstride, B, T, W, b, Cout, q, K, y);
   VQ_LAUNCH_CHECK();
   return 0;
 }

@@ -94,6 +94,9 @@ PROTOTYPES = {
     'vqvae_upsample_linear_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_long, P]),
     'vqvae_upsample_linear_bwd': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                           P, c_long, P]),
+    'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
+    'vqvae_onehot': (c_int, [P, c_long, c_int, c_int, c_int, P, P]),
+    'vqvae_embed_gather_fwd': (c_int, [P, c_long, c_int, c_int, P, P, c_int, c_int, c_int, P, P]),
     'vqvae_concat': (c_int, [P, PP, c_int, c_size_t, P]),
     'vqvae_split': (c_int, [P, PP, c_int, c_size_t, c_int, P]),
     'vqvae_embed_broadcast_fwd': (c_int, [P, P, c_int, c_int, c_int, P, c_long, P]),

@@ -501,3 +501,55 @@ def mixture_of_logistics_nll(y, t, quantize=256, log_scale_min=-40.0):
     t = as_variable(t)
     t.requires_grad = False
     return MixtureOfLogisticsNLL(quantize, log_scale_min).apply((y, t))[0]
+
+
+# --------------------------------------------------------------------------- #
+# decoder embed conv on bin indices (device-side input pipeline)
+# --------------------------------------------------------------------------- #
+class EmbedConvFromIndices(FunctionNode):
+    """Causal (K,1) conv of the one-hot of ``idx`` (modules.py:127-128, 151-152) without the
+    one-hot: forward is a K-column gather of W (bit-identical to the dense conv); the weight
+    gradient materialises the one-hot on the device and reuses the dense wgrad kernel."""
+
+    def check_type_forward(self, in_vars):
+        idx, W = in_vars[0], in_vars[1]
+        type_expect((idx.dtype == np.int32, 'embed_conv_indices: indices must be int32'),
+                    (W.ndim in (3, 4), 'embed_conv_indices: W must be (Cout, q, K[,1])'))
+
+    def forward(self, inputs):
+        idx, W = inputs[0], inputs[1]
+        b = inputs[2] if len(inputs) > 2 else None
+        backend.require_device(idx, W)
+        B = idx.shape[0]
+        T = idx.size // B
+        Cout, q, K = W.shape[:3]
+        y = DeviceArray((B, Cout, T, 1), np.float32)
+        _lib.call('vqvae_embed_gather_fwd', idx.ptr, T, B, T, W.ptr, _p(b), Cout, q, K, y.ptr, _S())
+        self._saved = (idx, B, T, Cout, q, K, b is not None)
+        return y,
+
+    def backward(self, indexes, gys):
+        idx, B, T, Cout, q, K, has_b = self._saved
+        gy = gys[0].data
+        onehot = DeviceArray((B, q, T), np.float32)
+        _lib.call('vqvae_onehot', idx.ptr, T, B, q, T, onehot.ptr, _S())
+        desc = _conv_desc(B, q, T, Cout, T, K, 1, K - 1, 1, False)
+        ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(desc)))
+        wv = self.inputs[1]
+        buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
+        gW = buf.reshape(wv.shape) if buf is not None else DeviceArray(wv.shape, np.float32)
+        gb = None
+        if has_b:
+            bv = self.inputs[2]
+            buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
+            gb = buf if buf is not None else DeviceArray((Cout,), np.float32)
+        _lib.call('vqvae_conv1d_bwd_weight', C.byref(desc), onehot.ptr, gy.ptr, gW.ptr, _p(gb), 0,
+                  ws.ptr, ws.nbytes, _S())
+        return (None, gW, gb) if has_b else (None, gW)
+
+
+def embed_conv_indices(idx, W, b=None):
+    idx = as_variable(idx)
+    idx.requires_grad = False
+    args = (idx, W) if b is None else (idx, W, b)
+    return EmbedConvFromIndices().apply(args)[0]

@@ -411,9 +411,14 @@ class WaveNet(Chain):
     def __call__(self, x, condition, generating=False):
         if generating:
             raise NotImplementedError('incremental generation is out of the hot-path scope')
-        length = x.shape[2]
-        # causal conv: pad 1 then crop to `length` (modules.py:151-152), fused as out_len
-        x = self.embed(x, out_len=length)
+        if np.dtype(x.dtype) == np.int32:
+            # device-side input pipeline: x holds mu-law bin indices (B, T) instead of the
+            # one-hot (B, q, T, 1) tensor -- the embed conv is a gather of its weight columns
+            x = F.embed_conv_indices(x, self.embed.W, self.embed.b)
+        else:
+            length = x.shape[2]
+            # causal conv: pad 1 then crop to `length` (modules.py:151-152), fused as out_len
+            x = self.embed(x, out_len=length)
         # residual & skip connections (modules.py:155)
         z = F.relu(self.resnet(x, condition))
         # output (modules.py:158-159); the ReLU after proj1 is fused into its epilogue

@@ -279,6 +279,21 @@ int vqvae_elementwise(int op, size_t n, const float* a, const float* b, float* o
 int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws,
               size_t ws_bytes, vqvae_stream_t s);
 
+/* ---- device-side input pipeline (the step right before the hot path; utils.py:18-23, 85-110).
+ *      mulaw_bins: q[i] = MuLaw(mu).transform(x[i]) by searching host-computed thresholds
+ *                  (thresholds[j-1] = smallest fp32 x with transform(x) >= j; bit-exact with NumPy).
+ *      onehot    : fp32 (B,q,T) one-hot of idx (B rows of idx_bstride int32).
+ *      embed_gather_fwd: the decoder's causal embed conv (modules.py:127-128,151-152) applied to
+ *                  an INDEX input instead of the 125.8 MB one-hot tensor:
+ *                  y[b,co,t] = b[co] + sum_tap W[co, idx[b,t-(K-1-tap)], tap]; bit-identical to
+ *                  vqvae_conv1d_fwd on the one-hot tensor.                                   */
+int vqvae_mulaw_bins(const float* x, size_t n, const float* thresholds, int n_thresholds,
+                     int32_t* q, vqvae_stream_t s);
+int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, float* out,
+                 vqvae_stream_t s);
+int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, const float* W,
+                           const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s);
+
 /* ---- gather n (<= 32) equally sized arrays (host array of device pointers) into one
  *      contiguous array and back (NULL destinations are skipped): lets ResidualNet
  *      treat its blocks' condition_proj parameters as one (n*Cd, Cc) 1x1 conv.       */

@@ -334,3 +334,41 @@ def test_mol_nll(gpu):
     assert_close(loss.data.get(), loss_ref, 1e-4, 'mol loss')
     loss.backward()
     assert_close_scaled(vy.grad.get(), g_ref, 1e-4, 'mol grad')
+
+
+def test_device_input_pipeline(gpu):
+    """SURVEY 8f row 3.  (1) device mu-law binning == utils.py:18-23 bit for bit (golden +
+    random + threshold neighbours); (2) the embed conv on indices is bit-identical to the dense
+    conv on the one-hot tensor, forward and weight gradient."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    from vqvae_amd.inputs import DeviceInputPipeline, _f32_key, _key_f32
+    pipe = DeviceInputPipeline(256)
+    g = np.load(os.path.join(GOLD, 'mulaw.npz'))
+    rs = np.random.RandomState(4)
+    k = _f32_key(pipe._thr_host)
+    x = np.concatenate([g['x'], rs.uniform(-1, 1, 300000).astype(np.float32), pipe._thr_host,
+                        _key_f32(k - 1), _key_f32(k + 1)])
+    np.testing.assert_array_equal(pipe.bins(x).get(), O.MuLaw(256).transform(x))
+
+    B, T, q, Cout, K = 3, 700, 256, 64, 2
+    raw = rs.uniform(-1, 1, (B, T + 1)).astype(np.float32)
+    x_enc, x_dec, spk, t = pipe(raw, np.zeros(B, np.int32))
+    qs = O.MuLaw(256).transform(raw)
+    np.testing.assert_array_equal(x_dec.get(), qs[:, :-1])
+    np.testing.assert_array_equal(t.get().reshape(B, T), qs[:, 1:])
+    W = (rs.standard_normal((Cout, q, K, 1)) / np.sqrt(q * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    onehot = np.identity(q, dtype=np.float32)[qs[:, :-1]].transpose(0, 2, 1)[..., None]
+    vW1, vb1 = Variable(_dev(gpu, W)), Variable(_dev(gpu, b))
+    y_dense = F.convolution_1d(Variable(_dev(gpu, onehot)), vW1, vb1, pad=K - 1, out_len=T)
+    vW2, vb2 = Variable(_dev(gpu, W)), Variable(_dev(gpu, b))
+    y_idx = F.embed_conv_indices(x_dec, vW2, vb2)
+    np.testing.assert_array_equal(y_idx.data.get(), y_dense.data.get())
+    gy = rs.standard_normal((B, Cout, T, 1)).astype(np.float32)
+    y_dense.grad = _dev(gpu, gy)
+    y_dense.backward()
+    y_idx.grad = _dev(gpu, gy)
+    y_idx.backward()
+    np.testing.assert_array_equal(vW2.grad.get(), vW1.grad.get())
+    np.testing.assert_array_equal(vb2.grad.get(), vb1.grad.get())

@@ -217,3 +217,35 @@ def test_evaluator_uses_ema_weights(gpu):
     assert abs(float(l1) - float(l1_live)) > 1e-3            # the two decoders really differ
     assert_close(rep['validation/main/loss1'], float(l1), 1e-4, 'validation loss1 (EMA weights)')
     assert_close(rep['validation/main/loss2'], float(l2), 1e-4, 'validation loss2')
+
+
+def test_index_input_step_equals_onehot_step(gpu):
+    """The device input pipeline (raw crops -> device mu-law bins -> index-fed embed conv) gives
+    the same training step, bit for bit, as the reference's one-hot input contract."""
+    import vqvae_amd as V
+    from vqvae_amd.inputs import DeviceInputPipeline
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    x_enc, x_dec, spk, t = O.synth_batch(2, length=512, n_speaker=cfg['n_speaker'], seed=21)
+    raw = x_enc[:, 0, :]
+
+    def run(use_index):
+        _, model = H.build_model(cfg, seed=9, ema_decay=0.999)
+        model.to_gpu()
+        opt = Adam(2e-4)
+        opt.setup(model)
+        if use_index:
+            args = DeviceInputPipeline(256)(raw, spk)
+        else:
+            args = [gpu.to_device(a) for a in (x_enc[..., None], x_dec[..., None], spk, t[..., None])]
+
+        class It(object):
+            def next(self):
+                return args
+        upd = V.VQVAE_StandardUpdater(It(), opt, converter=lambda b, d: b, device=0)
+        upd.update()
+        return [float(l.data.get()) for l in upd.last_losses], opt.params.get()
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    np.testing.assert_array_equal(p1, p0)

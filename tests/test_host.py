@@ -222,3 +222,21 @@ def test_snapshot_key_layout_and_roundtrip(tmp_path):
         serializers.load_npz(path, V.Encoder(64), 'updater/model:main/nonexistent/')
     with pytest.raises(ValueError):
         serializers.load_npz(path, V.Encoder(32), 'updater/model:main/encoder/')
+
+
+def test_mulaw_thresholds_reproduce_transform():
+    """bin(x) = #{j : x >= thr[j-1]} equals utils.py:18-23 for every tested x in [-1, 1], incl.
+    both neighbours of every threshold (what the device kernel relies on)."""
+    from vqvae_amd.inputs import _f32_key, _key_f32, mulaw_thresholds
+    from vqvae_amd.utils import MuLaw
+    thr = mulaw_thresholds(256)
+    assert thr.shape == (255,) and np.all(np.diff(thr) > 0)
+    f = MuLaw(256).transform
+    rs = np.random.RandomState(0)
+    k = _f32_key(thr)
+    x = np.concatenate([rs.uniform(-1, 1, 200000).astype(np.float32), thr,
+                        _key_f32(k - 1), _key_f32(k + 1), np.float32([-1, 0, 1, -0.0, 1e-30, -1e-30])])
+    got = np.searchsorted(thr, x, side='right').astype(np.int32)
+    np.testing.assert_array_equal(got, f(x))
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'mulaw.npz'))
+    np.testing.assert_array_equal(np.searchsorted(thr, g['x'], side='right'), g['q'])
