@@ -56,9 +56,13 @@ def synth_examples(B, cfg, seed):
         raw = raw + 0.05 * rs.standard_normal(L)
         raw = (raw / np.abs(raw).max()).astype(np.float32)
         q = mu.transform(raw)
-        one_hot = np.expand_dims(eye[q].T, 2)
-        ex.append((raw[None, :, None], one_hot[:, :-1], np.array(rs.randint(0, cfg['n_speaker']), np.int32),
-                   np.expand_dims(q, 1)[1:]))
+        spk = np.array(rs.randint(0, cfg['n_speaker']), np.int32)
+        raw3 = raw[None, :, None]
+        if cfg.get('use_logistic', False):          # utils.py:104, 107: raw in, raw target
+            ex.append((raw3, raw3[:, :-1], spk, raw3[:, 1:]))
+        else:
+            one_hot = np.expand_dims(eye[q].T, 2)
+            ex.append((raw3, one_hot[:, :-1], spk, np.expand_dims(q, 1)[1:]))
     return ex
 
 
@@ -93,12 +97,14 @@ def build(cfg, n_gpus):
     from vqvae_amd.optimizers import Adam
     V.core.seed_initializers(0)
     encoder = V.Encoder(cfg['d'])
+    logistic = cfg.get('use_logistic', False)
     wavenet = V.WaveNet(cfg['n_loop'], cfg['n_layer'], cfg['filter_size'], cfg['input_dim'],
-                        cfg['residual'], cfg['dilated'], cfg['skip'], cfg['quantize'], False, 30,
-                        -40, cfg['local_dim'] + cfg['global_dim'], 0)
+                        cfg['residual'], cfg['dilated'], cfg['skip'], cfg['quantize'], logistic,
+                        cfg.get('n_mixture', 30), -40, cfg['local_dim'] + cfg['global_dim'], 0)
     cond = V.ConditionEmbed(cfg['n_speaker'], cfg['global_dim'], cfg['local_dim'])
     decoder = V.ExponentialMovingAverage(wavenet, cfg['ema_mu'])       # train.py:87-90
-    model = V.VAE(encoder, decoder, cond, cfg['d'], cfg['k'], cfg['beta'], F.softmax_cross_entropy)
+    loss_fun = wavenet.calculate_logistic_loss if logistic else F.softmax_cross_entropy   # train.py:92-95
+    model = V.VAE(encoder, decoder, cond, cfg['d'], cfg['k'], cfg['beta'], loss_fun)
     return model, Adam(cfg['lr'] / n_gpus)                              # train.py:101
 
 
@@ -159,6 +165,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=CFG['batch_per_gpu'])
+    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
+                    help='c2: BASELINE configs[1]/[2] (softmax, 20 blocks, fp32) -- the metric config; '
+                         'c5: configs[4] (mixture of logistics, input_dim=1, n_loop=4 -> 40 blocks)')
+    ap.add_argument('--bf16', action='store_true',
+                    help='bf16 MFMA operands with fp32 accumulation (configs[4] precision)')
     ap.add_argument('--index-input', action='store_true',
                     help='feed x_dec as mu-law bin indices produced on the device (device-side input '
                          'pipeline) instead of the reference\'s one-hot float tensor')
@@ -167,6 +178,8 @@ def main():
     args = ap.parse_args()
     cfg = dict(CFG)
     cfg['batch_per_gpu'] = args.batch
+    if args.workload == 'c5':
+        cfg.update(n_loop=4, input_dim=1, use_logistic=True, n_mixture=30)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -180,6 +193,8 @@ def main():
     from vqvae_amd import _lib, backend
     from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
     backend.init(local)
+    if args.bf16:
+        backend.set_matmul_dtype('bfloat16')
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
 
     model, opt = build(cfg, n)
@@ -232,6 +247,7 @@ def main():
         # `dilconv1d` fwd = 2*B*T*Cout*Cin*K (the condition projection is no longer in this
         # kernel's contraction: it is computed once at the latent rate and lerped in the epilogue)
         flop = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
+        peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS      # dense bf16 MFMA peak
         avg_ms = tot.value / max(cnt.value, 1)
         ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
         # HBM bytes per launch of the same kernel: PMC counters cannot be read from inside this
@@ -246,25 +262,31 @@ def main():
             'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
             'value': value, 'unit': 'samples/s', 'n_gpus': n, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16 operands, f32 accumulate' if args.bf16 else 'f32',
             'data': 'synthetic' + (' (x_dec as device-computed bin indices)' if args.index_input else ''),
             'samples_per_sec_per_gpu': value / n,
-            'config': {'workload': 'BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
-                                   'd=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256, '
-                                   'cond 64+128, EMA 0.9999, Adam lr=2e-4/N' % (1 if n == 1 else 2, B),
+            'config': {'workload': ('BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
+                                    'd=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256, '
+                                    'cond 64+128, EMA 0.9999, Adam lr=2e-4/N' % (1 if n == 1 else 2, B))
+                       if args.workload == 'c2' else
+                       ('BASELINE configs[4]: mixture-of-logistics decoder (use_logistic, input_dim=1, '
+                        '10 logistics), n_loop=4 n_layer=10 (40 blocks), batch %d/GPU, length 7680' % B),
                        'global_batch': n * B, 'length': T,
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
             'losses_last_step': losses,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: '
                          'dilated causal conv k=2 as MFMA GEMM + latent-rate condition lerp + '
                          'tanh*sigmoid gate)',
-                         'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
+                         'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': (ach / peak) if ach else None,
                          'traffic': traffic, 'traffic_source': 'profiles/r1_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)',
                          'launches': cnt.value, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop},
         }
-        if n == 1 and not args.no_cpu_baseline:
+        if args.bf16 or args.workload != 'c2':
+            out['roofline']['traffic'] = None
+        if n == 1 and not args.no_cpu_baseline and args.workload == 'c2' and not args.bf16:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))
     if n > 1 or args.force_comm:

@@ -26,6 +26,12 @@
 namespace vq {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// 0: fp32 operands on v_mfma_f32_32x32x2_f32 (default); 1: operands rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) when they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// HBM tensors, epilogues and accumulators stay fp32 in both modes.
+static int g_matmul_dtype = 0;
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;   // wgrad tiles; conv_gemm derives BM/NT from WM
 constexpr int MAXSEG = 24;   // a whole ResidualNet's blocks can feed one contraction
@@ -84,7 +90,7 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 
 // WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
 // halves the activation-tile loads per FLOP and is used whenever M >= 256.
-template <int EPI, int WM>
+template <int EPI, int WM, bool BF16>
 __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(const GemmArgs a) {
   constexpr int BM = 64 * WM, NT = 128 * WM;
   __shared__ float As[2][BK][BM];
@@ -194,6 +200,23 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
       load_tiles(s, c0);
     }
+    if (BF16) {
+      // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
+      // k-group = lk) supplies k = 8*lk .. 8*lk+7
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
+          bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
+        }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
@@ -204,6 +227,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -399,6 +423,7 @@ struct WgradArgs {
   int accumulate;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   __shared__ float As[BM][WP];
   __shared__ float Bs[BN][WP];
@@ -514,6 +539,24 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
     }
     __syncthreads();
     if (tb + WBK < tend) load(tb + WBK);
+    if (BF16) {
+#pragma unroll
+      for (int k16 = 0; k16 < WBK / 16; ++k16) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            af[h][j] = (__bf16)As[wm * 64 + h * 32 + li][k16 * 16 + 8 * lk + j];
+            bf[h][j] = (__bf16)Bs[wn * 64 + h * 32 + li][k16 * 16 + 8 * lk + j];
+          }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < WBK / 2; ++kk) {
       const float a0 = As[wm * 64 + li][kk * 2 + lk];
@@ -524,6 +567,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
     }
   }
 
@@ -652,8 +696,13 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if (nblk <= 0) return 0;
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
   ProfScope ps(tag, st);
-  if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2>), dim3((unsigned)nblk), dim3(256), 0, st, g);
+  if (g_matmul_dtype == 1) {
+    if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, true>), dim3((unsigned)nblk), dim3(256), 0, st, g);
+  } else {
+    if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)nblk), dim3(256), 0, st, g);
+  }
   VQ_LAUNCH_CHECK();
   return 0;
 }
@@ -749,7 +798,8 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
               p.tchunk % 4 == 0 && ((uintptr_t)sg.x) % 16 == 0) ? 1 : 0;
   }
   ProfScope ps(tag, st);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
+  if (g_matmul_dtype == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
+  else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
   const long total = (long)p.ntile_m * BM * p.ntile_n * BN + (long)p.nseg * p.ntile_m * BM;
   int nb = (int)((total + 63) / 64);
@@ -762,6 +812,13 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
 }  // namespace vq
 
 using namespace vq;
+
+extern "C" int vqvae_set_matmul_dtype(int dtype) {
+  VQ_REQUIRE(dtype == 0 || dtype == 1, "set_matmul_dtype: 0 (fp32) or 1 (bf16 operands)");
+  vq::g_matmul_dtype = dtype;
+  return 0;
+}
+extern "C" int vqvae_get_matmul_dtype(void) { return vq::g_matmul_dtype; }
 
 // ---------------------------------------------------------------------------
 // C ABI: generic conv1d

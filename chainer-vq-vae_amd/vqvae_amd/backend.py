@@ -99,6 +99,12 @@ def wait_event(s, event):
     _lib.call('vqvae_stream_wait_event', s, event.h)
 
 
+def set_matmul_dtype(name):
+    """'float32' (default, exact fp32 MFMA) or 'bfloat16' (bf16 operands, fp32 accumulate)."""
+    code = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1}[name]
+    _lib.call('vqvae_set_matmul_dtype', code)
+
+
 def synchronize():
     _lib.call('vqvae_stream_synchronize', stream())
     if _state['side'] is not None:

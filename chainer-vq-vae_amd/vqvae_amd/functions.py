@@ -417,10 +417,13 @@ class ConditionAssemble(FunctionNode):
         return gl, gE, None
 
 
+LAZY_CONDITION = True     # keep the condition at the latent rate until a consumer needs it
+
+
 def condition_assemble(local, E, ids, upscale):
     ids = as_variable(ids)
     ids.requires_grad = False
-    return ConditionAssemble(upscale).apply((local, E, ids))[0]
+    return ConditionAssemble(upscale, lazy=LAZY_CONDITION).apply((local, E, ids))[0]
 
 
 # --------------------------------------------------------------------------- #

@@ -81,6 +81,14 @@ int vqvae_prof_enable(int tag_mask);
 int vqvae_prof_reset(void);
 int vqvae_prof_read(int tag, double* total_ms, int* launches);
 
+/* ---- operand precision of every MFMA contraction (convs fwd / bwd-data / bwd-weight,
+ *      ResidualBlock / ResidualNet entry points).  0 (default): fp32 operands on
+ *      v_mfma_f32_32x32x2_f32 -- exact fp32.  1: operands rounded to bf16 (round-to-nearest-even)
+ *      as they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation -- BASELINE configs[4].
+ *      Tensors in HBM, biases, gates, losses, optimizer and the vector quantiser stay fp32.     */
+int vqvae_set_matmul_dtype(int dtype);
+int vqvae_get_matmul_dtype(void);
+
 /* ---- generic 1-D convolution == chainer L.Convolution2D / L.DilatedConvolution2D
  *      with ksize=(K,1), stride=(s,1), pad=(p,0), dilate=(d,1)
  *      (net.py:12-17 encoder, net.py:34-43 condition embed, modules.py:17-22,

@@ -72,6 +72,27 @@ class MuLaw(object):
 # with ksize=(K,1), stride=(s,1), pad=(p,0), dilate=(d,1)
 # (call sites net.py:12-17, 34-43; modules.py:13-22, 127-141)  [chainer-recalled]
 # --------------------------------------------------------------------------- #
+# bf16-operand emulation (BASELINE configs[4]): when enabled, every contraction rounds BOTH
+# operands to bfloat16 (round-to-nearest-even) and accumulates in fp32 -- what the HIP path does
+# with v_cvt_pk_bf16_f32 + v_mfma_f32_32x32x16_bf16.  Biases and everything else stay fp32.
+_BF16 = [False]
+
+
+def set_bf16(on):
+    _BF16[0] = bool(on)
+
+
+def bf16_round(a):
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _op(a):
+    return bf16_round(a) if (_BF16[0] and a.dtype == np.float32) else a
+
+
 def conv_out_len(L, K, stride, pad, dil):
     return (L + 2 * pad - dil * (K - 1) - 1) // stride + 1
 
@@ -84,7 +105,8 @@ def conv1d_fwd(x, W, b, stride=1, pad=0, dil=1):
     Co, Ci2, K = W.shape
     assert Ci == Ci2
     Lo = conv_out_len(L, K, stride, pad, dil)
-    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad)))
+    xp = np.pad(_op(x), ((0, 0), (0, 0), (pad, pad)))
+    W = _op(W)
     y = np.zeros((B, Co, Lo), dtype=x.dtype)
     for j in range(K):
         xs = xp[:, :, j * dil: j * dil + (Lo - 1) * stride + 1: stride]
@@ -99,7 +121,10 @@ def conv1d_bwd(x, W, gy, stride=1, pad=0, dil=1, need_gx=True):
     B, Ci, L = x.shape
     Co, _, K = W.shape
     Lo = gy.shape[2]
-    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad)))
+    xp = np.pad(_op(x), ((0, 0), (0, 0), (pad, pad)))
+    gb = gy.sum(axis=(0, 2))
+    gy = _op(gy)
+    W = _op(W)
     gW = np.zeros_like(W)
     gxp = np.zeros_like(xp) if need_gx else None
     for j in range(K):
@@ -109,7 +134,6 @@ def conv1d_bwd(x, W, gy, stride=1, pad=0, dil=1, need_gx=True):
         gW[:, :, j] = np.tensordot(gy, xs, axes=((0, 2), (0, 2)))
         if need_gx:
             gxp[:, :, sl] += np.matmul(np.ascontiguousarray(W[:, :, j].T), gy)
-    gb = gy.sum(axis=(0, 2))
     gx = gxp[:, :, pad: pad + L] if need_gx else None
     return gx, gW, gb
 

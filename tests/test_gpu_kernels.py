@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import zlib
 
 import vqvae_oracle as O
 from helpers import assert_close, assert_close_scaled, to4
@@ -39,7 +40,7 @@ def test_conv1d_fwd_bwd(gpu, case, relu):
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     B, Cin, Tin, Cout, K, stride, pad, dil, crop = case
-    rs = np.random.RandomState(hash(case) % 2**31)
+    rs = np.random.RandomState(zlib.crc32(repr(case).encode()))     # hash(None) moves with ASLR
     x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
     W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
     b = rs.standard_normal(Cout).astype(np.float32)
@@ -49,6 +50,10 @@ def test_conv1d_fwd_bwd(gpu, case, relu):
     if relu:
         y_ref = O.relu(y_ref)
     gy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    if relu:
+        # an output within rounding noise of 0 may take either side of the ReLU mask on the two
+        # implementations (seen once in ~2e4 seeds): give those positions no upstream gradient
+        gy[np.abs(y_ref) < 1e-5] = 0
     gyr = gy * (y_ref > 0) if relu else gy
     if crop is not None:
         nat = O.conv_out_len(Tin, K, stride, pad, dil)
@@ -372,3 +377,48 @@ def test_device_input_pipeline(gpu):
     y_idx.backward()
     np.testing.assert_array_equal(vW2.grad.get(), vW1.grad.get())
     np.testing.assert_array_equal(vb2.grad.get(), vb1.grad.get())
+
+
+@pytest.fixture
+def bf16_mode(gpu):
+    gpu.set_matmul_dtype('bfloat16')
+    O.set_bf16(True)
+    yield
+    O.set_bf16(False)
+    gpu.set_matmul_dtype('float32')
+
+
+@pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[4], CONV_CASES[6], CONV_CASES[8]])
+def test_conv1d_bf16_operands(gpu, bf16_mode, case):
+    """BASELINE configs[4] precision mode: operands rounded to bf16 (RNE), fp32 accumulate -- against
+    the oracle with the same operand rounding, at the fp32 tolerance (only summation order differs)."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Tin, Cout, K, stride, pad, dil, crop = case
+    rs = np.random.RandomState(zlib.crc32(repr(case).encode()))
+    x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    y_ref = O.conv1d_fwd(x, W, b, stride, pad, dil)
+    if crop is not None:
+        y_ref = y_ref[:, :, :crop]
+    gy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    gfull = gy
+    if crop is not None:
+        gfull = np.zeros((B, Cout, O.conv_out_len(Tin, K, stride, pad, dil)), np.float32)
+        gfull[:, :, :crop] = gy
+    gx_ref, gW_ref, gb_ref = O.conv1d_bwd(x, W, gfull, stride, pad, dil)
+    vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+    y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil, out_len=crop)
+    assert_close(y.data.get(), y_ref, 1e-4, 'y (bf16 operands)')
+    O.set_bf16(False)
+    y32 = O.conv1d_fwd(x, W, b, stride, pad, dil)
+    O.set_bf16(True)
+    if crop is not None:
+        y32 = y32[:, :, :crop]
+    assert np.abs(y32 - y_ref).max() > 1e-4          # the mode really changes the arithmetic
+    y.grad = _dev(gpu, to4(gy))
+    y.backward()
+    assert_close_scaled(vx.grad.get(), gx_ref, 1e-4, 'gx (bf16 operands)')
+    assert_close_scaled(vW.grad.get(), gW_ref, 1e-4, 'gW (bf16 operands)')
+    assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'gb')
