@@ -168,3 +168,29 @@ int vqvae_prof_read(int tag, double* total_ms, int* launches) {
 }
 
 }  // extern "C"
+
+// ---- hipGraph capture / replay ------------------------------------------------------------------
+extern "C" int vqvae_graph_capture_begin(vqvae_stream_t s) {
+  VQ_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+extern "C" int vqvae_graph_capture_end(vqvae_stream_t s, void** graph_exec) {
+  VQ_REQUIRE(graph_exec, "graph_capture_end: null output");
+  hipGraph_t g = nullptr;
+  VQ_CHECK_HIP(hipStreamEndCapture((hipStream_t)s, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  VQ_CHECK_HIP(e);
+  *graph_exec = (void*)ex;
+  return 0;
+}
+extern "C" int vqvae_graph_launch(void* graph_exec, vqvae_stream_t s) {
+  VQ_REQUIRE(graph_exec, "graph_launch: null graph");
+  VQ_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)s));
+  return 0;
+}
+extern "C" int vqvae_graph_destroy(void* graph_exec) {
+  if (graph_exec) VQ_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}

@@ -41,6 +41,24 @@ class ResblockGrads(C.Structure):
     _fields_ = [(n, P) for n in ('gWd', 'gbd', 'gWc', 'gbc', 'gWr', 'gbr', 'gWs', 'gbs')]
 
 
+class GenBlock(C.Structure):
+    _fields_ = [(n, P) for n in ('conv_W', 'conv_b', 'cond_W', 'cond_b', 'res_W', 'res_b',
+                                 'skip_W', 'skip_b', 'ring')] + [('dilation', c_int)]
+
+
+class GenDesc(C.Structure):
+    _fields_ = ([(n, c_int) for n in ('n', 'n_blocks', 'input_dim', 'residual', 'dilated', 'skip',
+                                      'cond_dim', 'out_dim', 'sample_mode')]
+                + [('log_scale_min', c_float)]
+                + [(n, P) for n in ('embed_W', 'embed_b', 'proj1_W', 'proj1_b', 'proj2_W', 'proj2_b')]
+                + [('blocks', C.POINTER(GenBlock))]
+                + [(n, P) for n in ('step', 'x_cur', 'x_prev', 'h0', 'h1', 'z', 'skip_acc', 's1',
+                                    'logits', 'cond')]
+                + [('cond_bstride', c_long), ('cond_cstride', c_long), ('cond_follows_step', c_int),
+                   ('uniforms', P), ('n_uniform', c_int), ('forced_next', P), ('out', P),
+                   ('out_bstride', c_long), ('logits_out', P), ('max_steps', c_int)])
+
+
 # name -> (restype, argtypes); this table IS the list of symbols the header declares
 PROTOTYPES = {
     'vqvae_last_error_string': (c_char_p, []),
@@ -118,6 +136,11 @@ PROTOTYPES = {
     'vqvae_comm_allreduce_sum_f32': (c_int, [P, P, c_size_t, P]),
     'vqvae_comm_allreduce_max_f32': (c_int, [P, P, c_size_t, P]),
     'vqvae_comm_destroy': (c_int, [P]),
+    'vqvae_wavenet_gen_step': (c_int, [C.POINTER(GenDesc), P]),
+    'vqvae_graph_capture_begin': (c_int, [P]),
+    'vqvae_graph_capture_end': (c_int, [P, C.POINTER(c_void_p)]),
+    'vqvae_graph_launch': (c_int, [P, P]),
+    'vqvae_graph_destroy': (c_int, [P]),
 }
 
 # elementwise op codes / profiler tags (mirror the header)
@@ -127,6 +150,8 @@ EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_
 PROF_RESBLOCK_GATE, PROF_RESBLOCK_OUT, PROF_RESBLOCK_BWD_GZ, PROF_RESBLOCK_BWD_GX, \
     PROF_RESBLOCK_BWD_GC, PROF_RESBLOCK_WGRAD, PROF_CONV_FWD, PROF_CONV_BWD_DATA, \
     PROF_CONV_WGRAD, PROF_VQ_NEAREST = range(1, 11)
+GEN_NONE, GEN_SOFTMAX, GEN_MOL = range(3)
+GEN_MAX_N = 4
 
 
 class HipError(RuntimeError):

@@ -4,8 +4,9 @@ same constructor and call signatures.  The per-block graph of ~10 Chainer
 functions (dilated conv, crop, 1x1 conv, add, split, tanh, sigmoid, mul, two
 1x1 convs, add) is one fused FunctionNode backed by vqvae_resblock_fwd/bwd.
 
-Training path only: the queue-based incremental generation
-(modules.py:58-74, 98-110, 232-255) is out of scope.
+The queue-based incremental generation (modules.py:58-74, 98-110, 232-255) is exposed at the
+WaveNet level -- initialize(n) / generate(x, condition) / generate_sequence(...) -- with the
+per-block push/pop fused into one device-side step (generation.py, csrc/generate.hip).
 """
 import ctypes as C
 
@@ -401,6 +402,7 @@ class WaveNet(Chain):
             self.proj2 = L.Convolution2D(skip_channels, output_dim, 1)
         self.input_dim = input_dim
         self.quantize = quantize
+        self.use_logistic = bool(use_logistic)
         self.skip_channels = skip_channels
         self.log_scale_min = log_scale_min
 
@@ -409,8 +411,7 @@ class WaveNet(Chain):
         return F.mixture_of_logistics_nll(y, t, self.quantize, self.log_scale_min)
 
     def __call__(self, x, condition, generating=False):
-        if generating:
-            raise NotImplementedError('incremental generation is out of the hot-path scope')
+        # `generating` is accepted and ignored, as in modules.py:148-160
         if np.dtype(x.dtype) == np.int32:
             # device-side input pipeline: x holds mu-law bin indices (B, T) instead of the
             # one-hot (B, q, T, 1) tensor -- the embed conv is a gather of its weight columns
@@ -425,3 +426,41 @@ class WaveNet(Chain):
         z = self.proj1(z, relu=True)
         y = self.proj2(z)
         return y
+
+    # ---- incremental generation (modules.py:232-255; generate.py:100-145) ----
+    def initialize(self, n):
+        """modules.py:232-244: fresh all-zero queues for ``n`` sequences (the reference supports
+        n = 1, generate.py:42; here 1..4 run in lockstep)."""
+        from .generation import GenerationState
+        self._gen = GenerationState(self, n)
+
+    def _gen_state(self):
+        st = getattr(self, '_gen', None)
+        if st is None:
+            raise RuntimeError('call WaveNet.initialize(n) before generate (generate.py:100)')
+        return st
+
+    def generate(self, x, condition):
+        """modules.py:246-255: one step.  x (n, input_dim, 1, 1), condition (n, condition_dim, 1, 1)
+        -> logits Variable (n, out_dim, 1, 1); the queues advance by one sample."""
+        from .core import Variable
+        xd = x.data if isinstance(x, Variable) else x
+        cd = condition.data if isinstance(condition, Variable) else condition
+        backend.require_device(xd, cd)
+        return Variable(self._gen_state().step_logits(xd, cd))
+
+    def generate_sequence(self, condition, uniforms, n_steps=None, forced=None, return_logits=False,
+                          graph_steps=8):
+        """The loop of generate.py:101-145 as one device-resident run from fresh queues:
+        condition (n, condition_dim, T[, 1]) on the device; ``uniforms`` the host doubles NumPy's
+        RNG would hand generate.py:117 / 136 -- (T, n) for the softmax output, (T, n, nr_mix) for
+        the mixture of logistics.  Returns the device array ``output`` (n, T): int32 mu-law bins or
+        float32 samples, last column 0 as in generate.py:103-105 (plus the per-step logits
+        (steps, n, out_dim) when ``return_logits``).  ``forced`` (T, n) feeds these values back
+        instead of the samples (teacher forcing)."""
+        from .core import Variable
+        cd = condition.data if isinstance(condition, Variable) else condition
+        backend.require_device(cd)
+        self.initialize(cd.shape[0])
+        mode = _lib.GEN_MOL if self.use_logistic else _lib.GEN_SOFTMAX
+        return self._gen_state().run(cd, uniforms, mode, n_steps, forced, return_logits, graph_steps)

@@ -329,6 +329,71 @@ int vqvae_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, vqvae_stream_
 int vqvae_comm_allreduce_max_f32(void* comm, float* buf, size_t n, vqvae_stream_t s);
 int vqvae_comm_destroy(void* comm);
 
+/* ---- incremental generation: WaveNet.initialize / WaveNet.generate /
+ *      ResidualNet.generate / ResidualBlock.push+pop (WaveNet/modules.py:58-74, 98-110,
+ *      232-255) and the sampling loop of generate.py:105-145.
+ *      One call enqueues ONE audio-sample step for n sequences in lockstep: embed on the
+ *      2-sample embed queue, per block the pad-free dilated conv on the queue ends + condition
+ *      projection + gate, res/skip 1x1s + queue push, relu/proj1/relu/proj2, then (optionally)
+ *      the sampler, the feedback of the sample into the input vector and the advance of the
+ *      device-side step counter.  Because the step index lives in device memory the identical
+ *      launch sequence serves every step: capture it once with vqvae_graph_* and replay.
+ *      "initialize" (modules.py:58-67, 232-244) = the caller zero-fills step, x_cur, x_prev and
+ *      every ring.  All weights in their Chainer layout.                                     */
+#define VQVAE_GEN_NONE    0   /* no sampling: logits only, the caller writes x_cur (modules.py:246) */
+#define VQVAE_GEN_SOFTMAX 1   /* numpy.random.choice over softmax(y) (generate.py:135-141)          */
+#define VQVAE_GEN_MOL     2   /* softmax-weighted logistic samples (generate.py:113-133)            */
+#define VQVAE_GEN_MAX_N   4
+typedef struct {
+  const float* conv_W; const float* conv_b;   /* (dilated, residual, 2), (dilated)    modules.py:13-16 */
+  const float* cond_W; const float* cond_b;   /* (dilated, cond_dim), (dilated)       modules.py:17-18 */
+  const float* res_W;  const float* res_b;    /* (residual, dilated/2), (residual)    modules.py:19-20 */
+  const float* skip_W; const float* skip_b;   /* (skip, dilated/2), (skip)            modules.py:21-22 */
+  float* ring;       /* (dilation, n, residual): the block's queue minus its newest entry (58-62)   */
+  int dilation;
+} vqvae_gen_block;
+typedef struct {
+  int n;                     /* sequences in lockstep, 1..VQVAE_GEN_MAX_N (generate.py:42: 1)        */
+  int n_blocks;
+  int input_dim, residual, dilated, skip, cond_dim, out_dim;
+  int sample_mode;           /* VQVAE_GEN_*                                                          */
+  float log_scale_min;       /* params.py:39, generate.py:111                                        */
+  const float* embed_W; const float* embed_b;   /* (residual, input_dim, 2)   modules.py:127-128     */
+  const float* proj1_W; const float* proj1_b;   /* (skip, skip)               modules.py:135         */
+  const float* proj2_W; const float* proj2_b;   /* (out_dim, skip)            modules.py:141         */
+  const vqvae_gen_block* blocks;                /* HOST array [n_blocks]                             */
+  /* device state, caller-owned */
+  int* step;                 /* current step t; advanced by the call                                 */
+  float* x_cur;              /* (n, input_dim) input of this step (x_dec, generate.py:52, 127, 139)   */
+  float* x_prev;             /* (n, input_dim) older half of the embed queue (modules.py:236-237)     */
+  float* h0; float* h1;      /* (n, residual) ping-pong block input/output                           */
+  float* z;                  /* (n, dilated/2)                                                       */
+  float* skip_acc;           /* (n, skip)                                                            */
+  float* s1;                 /* (n, skip)                                                            */
+  float* logits;             /* (n, out_dim) = WaveNet.generate's return value                       */
+  /* per-step inputs */
+  const float* cond;         /* element (b, c) of step t at cond[b*cond_bstride + c*cond_cstride + (cond_follows_step ? t : 0)] */
+  long cond_bstride, cond_cstride;
+  int cond_follows_step;
+  const double* uniforms;    /* (max_steps, n, n_uniform) doubles in [0,1): what numpy.random would draw */
+  int n_uniform;
+  const void* forced_next;   /* NULL, or (max_steps, n) int32 [softmax] / float [mol]: fed back instead of
+                                the sample (teacher forcing; index -1 = all-zero vector)              */
+  /* outputs */
+  void* out;                 /* NULL, or sample of step t at out[b*out_bstride + t] (int32 / float)  */
+  long out_bstride;
+  float* logits_out;         /* NULL, or (max_steps, n, out_dim)                                     */
+  int max_steps;             /* calls with *step >= max_steps are no-ops on the device               */
+} vqvae_gen_desc;
+int vqvae_wavenet_gen_step(const vqvae_gen_desc* d, vqvae_stream_t s);
+
+/* ---- hipGraph capture/replay of a launch sequence on one stream (launch-bound inner loops:
+ *      the per-sample chain of generate.py:105-145)                                          */
+int vqvae_graph_capture_begin(vqvae_stream_t s);
+int vqvae_graph_capture_end(vqvae_stream_t s, void** graph_exec);
+int vqvae_graph_launch(void* graph_exec, vqvae_stream_t s);
+int vqvae_graph_destroy(void* graph_exec);
+
 #ifdef __cplusplus
 }
 #endif

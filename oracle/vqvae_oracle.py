@@ -529,6 +529,120 @@ def mol_loss_bwd(y, t, quantize=256, log_scale_min=-40.0, gloss=1.0):
 
 
 # --------------------------------------------------------------------------- #
+# incremental generation (WaveNet/modules.py:58-74, 98-110, 232-255;
+# generate.py:105-145) -- SURVEY section 8f row 2
+# --------------------------------------------------------------------------- #
+def wavenet_initialize(p, n, n_loop, n_layer, dtype=np.float32):
+    """WaveNet.initialize(n) (modules.py:232-244) -> ResidualNet.initialize (98-100) ->
+    ResidualBlock.initialize (58-67): all-zero queues; the convs lose their padding.
+    (proj1_queue / proj2_queue3 have length 1: the 1x1 convs see the current value only.)"""
+    We = p['embed'][0]
+    R = We.shape[0]
+    st = {'embed_queue': np.zeros((n, We.shape[1], 2), dtype), 'queues': []}
+    for dil in wavenet_dilations(n_loop, n_layer):
+        K = p['blocks'][0]['conv'][0].shape[2]
+        st['queues'].append(np.zeros((n, R, dil * (K - 1) + 1), dtype))
+    return st
+
+
+def wavenet_generate_step(p, st, x, cond_t, n_loop, n_layer):
+    """WaveNet.generate(x, condition) (modules.py:246-255): x (n, input_dim, 1),
+    cond_t (n, cond_dim, 1) -> y (n, out_dim, 1).  Queues are updated in place of ``st``."""
+    We, be = p['embed']
+    st['embed_queue'] = np.concatenate((st['embed_queue'][:, :, 1:], x), axis=2)     # modules.py:247
+    h = conv1d_fwd(st['embed_queue'], We, be, stride=1, pad=0, dil=1)                # pad (0,0): 234
+    skip_sum = None
+    for i, (blk, dil) in enumerate(zip(p['blocks'], wavenet_dilations(n_loop, n_layer))):
+        # push (modules.py:71-74); the condition queue has length 1 => it IS cond_t
+        st['queues'][i] = np.concatenate((st['queues'][i][:, :, 1:], h), axis=2)
+        q = st['queues'][i]
+        # pop (modules.py:68-69) = __call__(queue, condition_queue) with conv.pad = 0 (64)
+        Wd, bd = blk['conv']
+        Wc, bc = blk['condition_proj']
+        Wr, br = blk['res']
+        Ws, bs = blk['skip']
+        hh = conv1d_fwd(q, Wd, bd, stride=1, pad=0, dil=dil)          # length dil+1 -> 1 (40-41)
+        hh = hh + conv1d_fwd(cond_t, Wc, bc)                          # modules.py:44
+        Ch = hh.shape[1] // 2
+        z = np.tanh(hh[:, :Ch]) * sigmoid(hh[:, Ch:])                 # modules.py:47-48
+        h = conv1d_fwd(z, Wr, br) + q[:, :, -1:]                      # modules.py:54 (lengths differ)
+        skip = conv1d_fwd(z, Ws, bs)                                  # modules.py:55
+        skip_sum = skip if skip_sum is None else skip_sum + skip      # modules.py:105-109
+    s = relu(skip_sum)                                                # modules.py:249
+    W1, b1 = p['proj1']
+    W2, b2 = p['proj2']
+    z1 = relu(conv1d_fwd(s, W1, b1))                                  # modules.py:251-252
+    return conv1d_fwd(z1, W2, b2)                                     # modules.py:254-255
+
+
+def softmax_axis1(y):
+    """chainer.functions.softmax (axis=1): exp(y - max) / sum, in the input dtype. [chainer-recalled]"""
+    e = np.exp(y - y.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def choice_from_uniform(p, u):
+    """numpy.random.choice(len(p), p=p) (generate.py:136-138) for the uniform double ``u`` it
+    draws: NumPy's legacy RandomState.choice converts p to float64, builds cdf = cumsum(p),
+    normalises by cdf[-1] and returns cdf.searchsorted(random_sample(), side='right').
+    Pinned in tests/test_oracle.py against numpy.random.RandomState itself."""
+    cdf = np.asarray(p, np.float64).cumsum()
+    cdf /= cdf[-1]
+    return int(cdf.searchsorted(u, side='right'))
+
+
+def mol_sample_from_uniform(out, u, log_scale_min=-40.0):
+    """generate.py:113-133 for one step: out (n, 3*nr_mix) float32, u (n, nr_mix) float64 in (0,1)
+    (what xp.random.uniform(0, 1, shape) returned).  NOTE the reference does not pick a mixture
+    component: it averages one logistic sample per component with the softmax weights."""
+    nr = out.shape[1] // 3
+    logit_probs = out[:, :nr]
+    means = out[:, nr:2 * nr]
+    log_scales = np.maximum(out[:, 2 * nr:3 * nr], out.dtype.type(log_scale_min))
+    scales = np.exp(log_scales)
+    rand = means + scales * (np.log(u) - np.log(1 - u))               # float64
+    rand = rand * softmax_axis1(logit_probs)
+    value = rand.sum(axis=1).astype(np.float32)
+    value /= 127.5
+    return np.clip(value, -1, 1)
+
+
+def wavenet_generate(p, cond, uniforms, n_loop, n_layer, loss_kind='softmax', quantize=256,
+                     log_scale_min=-40.0, forced=None, n_steps=None):
+    """The sampling loop of generate.py:101-145 (n sequences in lockstep; the reference runs
+    n = 1).  cond (n, cond_dim, T); uniforms (T, n) [softmax] or (T, n, nr_mix) [mol] are the
+    doubles the reference would draw from numpy's global RNG.  ``forced`` (T, n) replaces the
+    fed-back sample (teacher forcing; -1 = all-zero input for the softmax kind).
+    Returns (output (n, T), logits (T, n, out_dim)); output[:, T-1] stays 0 (generate.py:103)."""
+    n, _, T = cond.shape
+    steps = T - 1 if n_steps is None else n_steps
+    input_dim = p['embed'][0].shape[1]
+    st = wavenet_initialize(p, n, n_loop, n_layer, cond.dtype)
+    x = np.zeros((n, input_dim, 1), cond.dtype)                       # generate.py:52
+    out_dim = p['proj2'][0].shape[0]
+    output = np.zeros((n, T), np.int32 if loss_kind == 'softmax' else np.float32)
+    logits = np.zeros((steps, n, out_dim), cond.dtype)
+    for i in range(steps):
+        y = wavenet_generate_step(p, st, x, cond[:, :, i:i + 1], n_loop, n_layer)[:, :, 0]
+        logits[i] = y
+        if loss_kind == 'softmax':
+            pr = softmax_axis1(y)
+            value = np.array([choice_from_uniform(pr[b], uniforms[i, b]) for b in range(n)])
+            output[:, i] = value
+            nxt = value if forced is None else forced[i]
+            x = np.zeros((n, input_dim, 1), cond.dtype)               # generate.py:139-141
+            for b in range(n):
+                if nxt[b] >= 0:
+                    x[b, nxt[b], 0] = 1
+        else:
+            value = mol_sample_from_uniform(y, uniforms[i], log_scale_min)
+            output[:, i] = value
+            nxt = value if forced is None else forced[i]
+            x = np.asarray(nxt, cond.dtype).reshape(n, 1, 1) * np.ones((1, input_dim, 1), cond.dtype)
+    return output, logits
+
+
+# --------------------------------------------------------------------------- #
 # optimizer / EMA
 # --------------------------------------------------------------------------- #
 def adam_update(param, grad, m, v, t, alpha, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -286,3 +286,86 @@ def test_preprocess_contract_golden():
                 np.testing.assert_array_equal(got, want)
     assert g['mulaw_short_x_dec'].shape == (256, 255, 1) and g['mulaw_short_t'].shape == (255, 1)
     assert g['mulaw_short_t'][-1, 0] == 128          # padded with bin quantize//2 (utils.py:74)
+
+
+# --------------------------------------------------------------------------- #
+# incremental generation
+# --------------------------------------------------------------------------- #
+GEN = dict(n_loop=2, n_layer=3, residual=16, dilated=16, skip=16, input_dim=12, out_dim=12,
+           local_dim=4, global_dim=4, d=4, k=8, n_speaker=3)
+
+
+def _gen_setup(T=24, n=2, seed=3, **over):
+    cfg = dict(GEN, **over)
+    rs = np.random.RandomState(seed)
+    p = O.make_params(rs, **cfg)['decoder']
+    for name in ('embed', 'proj1', 'proj2'):
+        p[name] = (p[name][0], rs.standard_normal(p[name][1].shape).astype(np.float32) * 0.1)
+    for blk in p['blocks']:
+        for name in blk:
+            blk[name] = (blk[name][0], rs.standard_normal(blk[name][1].shape).astype(np.float32) * 0.1)
+    cond = rs.standard_normal((n, cfg['local_dim'] + cfg['global_dim'], T)).astype(np.float32)
+    return cfg, p, cond, rs
+
+
+def test_generation_equals_training_forward_under_teacher_forcing():
+    """The queue arithmetic of modules.py:58-74/98-110/232-255 must reproduce the padded, cropped
+    convolutions of the training forward (modules.py:40-41, 151-152): feeding the same inputs,
+    step i of generate() equals column i of WaveNet.__call__.  The first generated step sees an
+    all-zero input vector (generate.py:52), not a one-hot."""
+    cfg, p, cond, rs = _gen_setup()
+    n, _, T = cond.shape
+    forced = rs.randint(0, cfg['input_dim'], (T, n)).astype(np.int32)
+    forced[5, 0] = -1                                      # an all-zero input mid-sequence
+    u = rs.random_sample((T, n))
+    out, logits = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], forced=forced)
+    x = np.zeros((n, cfg['input_dim'], T), np.float32)
+    for i in range(T - 1):
+        for b in range(n):
+            if forced[i, b] >= 0:
+                x[b, forced[i, b], i + 1] = 1
+    y, _ = O.wavenet_fwd(p, x, cond, cfg['n_loop'], cfg['n_layer'])
+    np.testing.assert_allclose(logits, y.transpose(2, 0, 1)[:T - 1], rtol=1e-4, atol=1e-5)
+    assert out.shape == (n, T) and (out[:, -1] == 0).all()          # generate.py:103-105
+
+
+def test_choice_from_uniform_is_numpy_choice():
+    """Pins the sampler restatement on NumPy itself (the third-party code generate.py:136 calls):
+    feeding the double RandomState would draw gives the index RandomState.choice returns."""
+    rs = np.random.RandomState(11)
+    for trial in range(200):
+        logits = (rs.standard_normal((1, 256)) * rs.uniform(0.5, 6)).astype(np.float32)
+        pr = O.softmax_axis1(logits)[0]
+        seed = int(rs.randint(1 << 30))
+        want = np.random.RandomState(seed).choice(256, p=pr)
+        u = np.random.RandomState(seed).random_sample()
+        assert O.choice_from_uniform(pr, u) == want
+    pr = np.array([0.25, 0.25, 0.5], np.float32)
+    assert [O.choice_from_uniform(pr, u) for u in (0.0, 0.2499, 0.25, 0.4999, 0.5, 0.999)] == [0, 0, 1, 1, 2, 2]
+
+
+def test_mol_sampler_known_answers():
+    """generate.py:113-133: one dominant component and u = 0.5 give mean/127.5; the result is
+    clipped to [-1, 1]; log-scales below log_scale_min are clamped."""
+    out = np.zeros((2, 6), np.float32)
+    out[:, 0] = 50.0                                        # softmax weight ~1 on component 0
+    out[0, 2], out[1, 2] = 63.75, 400.0                     # means
+    out[:, 4:] = -100.0                                     # clamped to -40
+    v = O.mol_sample_from_uniform(out, np.full((2, 2), 0.5))
+    np.testing.assert_allclose(v, [0.5, 1.0], atol=1e-6)
+    out[:, 4:] = 2.0
+    u = np.array([[0.9, 0.5], [0.1, 0.5]])
+    v = O.mol_sample_from_uniform(out, u)
+    want0 = (63.75 + np.exp(np.float32(2.0)) * (np.log(0.9) - np.log(0.1))) / 127.5
+    np.testing.assert_allclose(v[0], want0, rtol=1e-6)
+
+
+def test_mol_generation_feeds_back_the_sample():
+    cfg, p, cond, rs = _gen_setup(T=10, n=1, input_dim=1, out_dim=6)
+    u = rs.uniform(0.05, 0.95, (10, 1, 2))
+    out, logits = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+    assert out.dtype == np.float32 and np.abs(out).max() <= 1 and out[0, -1] == 0
+    x = np.zeros((1, 1, 10), np.float32)
+    x[0, 0, 1:] = out[0, :-1]
+    y, _ = O.wavenet_fwd(p, x, cond, cfg['n_loop'], cfg['n_layer'])
+    np.testing.assert_allclose(logits, y.transpose(2, 0, 1)[:9], rtol=1e-4, atol=1e-5)
