@@ -137,6 +137,8 @@ PROTOTYPES = {
     'vqvae_comm_allreduce_max_f32': (c_int, [P, P, c_size_t, P]),
     'vqvae_comm_destroy': (c_int, [P]),
     'vqvae_wavenet_gen_step': (c_int, [C.POINTER(GenDesc), P]),
+    'vqvae_wavenet_gen_run_workspace_bytes': (c_size_t, [C.POINTER(GenDesc)]),
+    'vqvae_wavenet_gen_run': (c_int, [C.POINTER(GenDesc), c_int, c_int, P, c_size_t, P]),
     'vqvae_graph_capture_begin': (c_int, [P]),
     'vqvae_graph_capture_end': (c_int, [P, C.POINTER(c_void_p)]),
     'vqvae_graph_launch': (c_int, [P, P]),

@@ -96,7 +96,7 @@ class GenerationState(object):
 
     # ---- the whole loop of generate.py:105-145 on the device ----------------------------------
     def run(self, condition, uniforms, mode, n_steps=None, forced=None, return_logits=False,
-            graph_steps=8):
+            graph_steps=8, persistent=False, chunk=4096):
         n = self.n
         if condition.ndim == 4:
             condition = condition.reshape(condition.shape[:3])
@@ -130,7 +130,28 @@ class GenerationState(object):
         if int(self.step.get()[0]) != 0:
             raise RuntimeError('generate_sequence starts from fresh queues: call initialize(n) first')
         d.max_steps = steps
-        if steps:
+        if steps and persistent:
+            # one persistent launch per `chunk` steps; queues + mailboxes live in its workspace
+            lib = _lib.load()
+            nbytes = lib.vqvae_wavenet_gen_run_workspace_bytes(C.byref(d))
+            if not nbytes:
+                raise ValueError('persistent generation: ' + lib.vqvae_last_error_string().decode())
+            ws = DeviceArray((nbytes // 4 + 1,), np.int32)
+            for t0 in range(0, steps, chunk):
+                _lib.call('vqvae_wavenet_gen_run', C.byref(d), t0, min(chunk, steps - t0), ws.ptr,
+                          ws.nbytes, _S())
+            backend.synchronize()
+            status = int(ws.flat_view(0, 1).get()[0])
+            self._last_ws = ws
+            if status:
+                raise RuntimeError('persistent generation kernel gave up waiting (status %d): are all '
+                                   'its workgroups resident?' % status)
+            self.step.set(np.array([steps], np.int32))
+        elif steps and not graph_steps:                # eager launches (profilers, debugging)
+            for _ in range(steps):
+                _lib.call('vqvae_wavenet_gen_step', C.byref(d), _S())
+            backend.synchronize()
+        elif steps:
             per = max(1, min(int(graph_steps), steps))
             graph = C.c_void_p()
             _lib.call('vqvae_graph_capture_begin', _S())

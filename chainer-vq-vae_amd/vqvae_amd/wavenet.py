@@ -450,17 +450,20 @@ class WaveNet(Chain):
         return Variable(self._gen_state().step_logits(xd, cd))
 
     def generate_sequence(self, condition, uniforms, n_steps=None, forced=None, return_logits=False,
-                          graph_steps=8):
+                          graph_steps=8, persistent=True):
         """The loop of generate.py:101-145 as one device-resident run from fresh queues:
         condition (n, condition_dim, T[, 1]) on the device; ``uniforms`` the host doubles NumPy's
         RNG would hand generate.py:117 / 136 -- (T, n) for the softmax output, (T, n, nr_mix) for
         the mixture of logistics.  Returns the device array ``output`` (n, T): int32 mu-law bins or
         float32 samples, last column 0 as in generate.py:103-105 (plus the per-step logits
         (steps, n, out_dim) when ``return_logits``).  ``forced`` (T, n) feeds these values back
-        instead of the samples (teacher forcing)."""
+        instead of the samples (teacher forcing).  ``persistent`` runs the loop as one persistent
+        kernel (csrc/generate.hip, channel counts <= 256); otherwise as a replayed hipGraph of
+        per-step kernels (``graph_steps`` steps per graph, 0 = eager launches)."""
         from .core import Variable
         cd = condition.data if isinstance(condition, Variable) else condition
         backend.require_device(cd)
         self.initialize(cd.shape[0])
         mode = _lib.GEN_MOL if self.use_logistic else _lib.GEN_SOFTMAX
-        return self._gen_state().run(cd, uniforms, mode, n_steps, forced, return_logits, graph_steps)
+        return self._gen_state().run(cd, uniforms, mode, n_steps, forced, return_logits, graph_steps,
+                                     persistent)

@@ -387,6 +387,17 @@ typedef struct {
 } vqvae_gen_desc;
 int vqvae_wavenet_gen_step(const vqvae_gen_desc* d, vqvae_stream_t s);
 
+/* The same loop (generate.py:105-145) as ONE persistent launch: steps [t0, t0+steps) for fresh
+ * queues at t0 == 0 (the call zero-fills `ws`: that is WaveNet.initialize) or continuing a
+ * previous call on the same `ws`, `out` and `forced_next`.  Uses the weights, cond, uniforms,
+ * forced_next, out, logits_out, sample_mode (SOFTMAX or MOL) fields of `d`; the device state
+ * fields are not used (queues and hand-off mailboxes live in `ws`).  Channel counts <= 256.
+ * After the stream has drained, the first int32 of `ws` is 0 on success, non-zero when a bounded
+ * device-side wait timed out (the launch then ended early).                                    */
+size_t vqvae_wavenet_gen_run_workspace_bytes(const vqvae_gen_desc* d);
+int vqvae_wavenet_gen_run(const vqvae_gen_desc* d, int t0, int steps, void* ws, size_t ws_bytes,
+                          vqvae_stream_t s);
+
 /* ---- hipGraph capture/replay of a launch sequence on one stream (launch-bound inner loops:
  *      the per-sample chain of generate.py:105-145)                                          */
 int vqvae_graph_capture_begin(vqvae_stream_t s);

@@ -57,7 +57,8 @@ def test_generate_step_api_matches_oracle(gpu):
             x[b, rs.randint(cfg['input_dim']), 0] = 1
 
 
-def test_generate_sequence_teacher_forced(gpu):
+@pytest.mark.parametrize('persistent', [False, True])
+def test_generate_sequence_teacher_forced(gpu, persistent):
     """Device-resident loop with the fed-back value forced: logits of every step against the
     oracle (1e-4), sampled bins bit-exact wherever the uniform is not within 1e-5 of a cdf edge."""
     cfg = dict(H.SMALL)
@@ -70,7 +71,7 @@ def test_generate_sequence_teacher_forced(gpu):
     u = rs.random_sample((T, n))
     want_out, want_logits = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], forced=forced)
     out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True,
-                                        graph_steps=5)
+                                        graph_steps=5, persistent=persistent)
     assert_close(logits.get(), want_logits, 1e-4, 'teacher-forced logits')
     got = out.get()
     assert got.shape == (n, T) and got.dtype == np.int32 and (got[:, -1] == 0).all()
@@ -91,21 +92,30 @@ def test_generate_sequence_free_running_equals_oracle(gpu):
     cond = _cond(cfg, 1, T, 7)
     u = np.random.RandomState(12).random_sample((T, 1))
     want_out, _ = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'])
-    got8 = dec.generate_sequence(gpu.to_device(cond), u, graph_steps=8).get()
-    got1 = dec.generate_sequence(gpu.to_device(cond), u, graph_steps=1).get()
+    got8 = dec.generate_sequence(gpu.to_device(cond), u, graph_steps=8, persistent=False).get()
+    got1 = dec.generate_sequence(gpu.to_device(cond), u, graph_steps=1, persistent=False).get()
+    got0 = dec.generate_sequence(gpu.to_device(cond), u, graph_steps=0, persistent=False).get()
+    gotp = dec.generate_sequence(gpu.to_device(cond), u, persistent=True).get()
     np.testing.assert_array_equal(got8, got1)
+    np.testing.assert_array_equal(got8, got0)
     np.testing.assert_array_equal(got8, want_out)
+    np.testing.assert_array_equal(gotp, want_out)
+    # the persistent launch continued in chunks (queues, mailboxes and feedback survive the seam)
+    dec.initialize(1)
+    gotc = dec._gen.run(gpu.to_device(cond), u, 1, persistent=True, chunk=7).get()
+    np.testing.assert_array_equal(gotc, want_out)
     assert len(np.unique(got8)) > 10                                   # not a degenerate stream
 
 
-def test_generate_partial_steps_and_restart(gpu):
+@pytest.mark.parametrize('persistent', [False, True])
+def test_generate_partial_steps_and_restart(gpu, persistent):
     cfg = dict(H.SMALL)
     p, dec = _decoder(cfg, 24)
     T = 30
     cond = _cond(cfg, 2, T, 8)
     u = np.random.RandomState(13).random_sample((T, 2))
-    full = dec.generate_sequence(gpu.to_device(cond), u).get()
-    part = dec.generate_sequence(gpu.to_device(cond), u, n_steps=11).get()
+    full = dec.generate_sequence(gpu.to_device(cond), u, persistent=persistent).get()
+    part = dec.generate_sequence(gpu.to_device(cond), u, n_steps=11, persistent=persistent).get()
     np.testing.assert_array_equal(part[:, :11], full[:, :11])
     assert (part[:, 11:] == 0).all()
     st = dec._gen
@@ -113,7 +123,8 @@ def test_generate_partial_steps_and_restart(gpu):
         st.run(gpu.to_device(cond), u, 1)
 
 
-def test_mol_generation_matches_oracle(gpu):
+@pytest.mark.parametrize('persistent', [False, True])
+def test_mol_generation_matches_oracle(gpu, persistent):
     """configs[4] output: generate.py:113-133 (softmax-weighted logistic samples, /127.5, clip),
     scalar feedback into the 1-channel embed."""
     cfg = dict(H.MOL)
@@ -125,19 +136,21 @@ def test_mol_generation_matches_oracle(gpu):
     forced = rs.uniform(-1, 1, (T, n)).astype(np.float32)
     want_out, want_logits = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], loss_kind='mol',
                                                forced=forced)
-    out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True)
+    out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True,
+                                        persistent=persistent)
     assert_close(logits.get(), want_logits, 1e-4, 'mol logits')
     got = out.get()
     assert got.dtype == np.float32
     np.testing.assert_allclose(got, want_out, rtol=0, atol=2e-5)
     # free running: the fed-back value is continuous, deviations stay at rounding level
     want_out, _ = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], loss_kind='mol', n_steps=48)
-    got = dec.generate_sequence(gpu.to_device(cond), u, n_steps=48).get()
+    got = dec.generate_sequence(gpu.to_device(cond), u, n_steps=48, persistent=persistent).get()
     np.testing.assert_allclose(got, want_out, rtol=0, atol=1e-3)
     assert np.abs(got).max() <= 1.0 and np.abs(got[:, :48]).max() > 0
 
 
-def test_generation_equals_training_forward_full_size(gpu):
+@pytest.mark.parametrize('persistent', [False, True])
+def test_generation_equals_training_forward_full_size(gpu, persistent):
     """Size-independent property at the BASELINE configs[1] decoder (20 blocks, 256 channels,
     dilations to 512): with the same inputs, step i of the incremental path equals column i of the
     training forward (modules.py:148-160) -- queues of every dilation wrap at least twice."""
@@ -150,7 +163,8 @@ def test_generation_equals_training_forward_full_size(gpu):
     rs = np.random.RandomState(15)
     forced = rs.randint(0, 256, (T, n)).astype(np.int32)
     u = rs.random_sample((T, n))
-    out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True)
+    out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True,
+                                        persistent=persistent)
     x = np.zeros((n, 256, T), np.float32)
     for i in range(T - 1):
         x[0, forced[i, 0], i + 1] = 1
