@@ -351,6 +351,15 @@ extern "C" int vqvae_wavenet_gen_step(const vqvae_gen_desc* d, vqvae_stream_t s)
 //   * Every block's queue (modules.py:58-62) is a ring of d+1 granule vectors: slot t % (d+1) is
 //     written at step t and read as the old tap at step t + d.
 //   * All spins are bounded: on timeout the status word is set and every wave leaves.
+//   * One edge per block instead of two.  The reference's chain is x_l -> z_l -> x_{l+1} -> z_{l+1}
+//     (two all-to-all hand-offs per block).  Because x_{l+1} = Wr_l z_l + br_l + x_l is linear, the
+//     new-tap term of block l+1 is  Wc1_{l+1} x_{l+1} = (Wc1_{l+1} Wr_l) z_l + Wc1_{l+1} x_l + Wc1_{l+1} br_l:
+//     the composite matrix M_l = Wc1_{l+1} Wr_l (256 x 128, built once in float64 by the pack kernel)
+//     takes z_l straight to the next gate, and the term in x_l -- already on its way while z_l is
+//     being computed -- is evaluated in the shadow of the z_l hand-off.  The critical path is
+//     z_0 -> z_1 -> ... -> z_{L-1}; x_{l+1} is still produced (queues, next block's shadow term) but
+//     nobody waits for it.  Same mathematics, different rounding order (~1e-6 relative on the
+//     pre-activations; the parity tests hold the 1e-4 fp32 bar against the oracle's plain order).
 // The global sequential dependency (nothing of step t+1 can be produced before the sample of step
 // t, which needs every workgroup's step-t rows) makes single-buffered mailboxes race-free.
 // =================================================================================================
@@ -489,31 +498,36 @@ __device__ __forceinline__ float mega_gate(float h0, float h1) {          // tan
 typedef const __attribute__((address_space(1))) float* gfp_t;    // pointers read from the block table are
 #define GF(p) ((gfp_t)(p))                                          // generic: make the loads global_load again
 
-struct MegaBlkW {
-  float wA[MEGA_PJ][2][MEGA_VI];     // conv tap 1 (new sample), gate pair rows p, p + half
+struct MegaBlkW {                    // record l: what the chain wave needs once z_l has arrived
+  float wU[2][MEGA_VI];              // conv tap 1 of block l+1, its gate pair rows (shadow term Wc1_{l+1} x_l)
+  float wM[2][2];                    // M_l = Wc1_{l+1} Wr_l, the same two rows, k = lane + 64 i
   float wR[MEGA_RJ][2], wS[MEGA_RJ][2];
-  float bR[MEGA_RJ], bS[MEGA_RJ];
+  float bR[MEGA_RJ], bS[MEGA_RJ], cb[2];   // cb = Wc1_{l+1} br_l
 };
+constexpr int MEGA_CREC = 5;         // float4 per lane in a chain record
 static_assert(MEGA_PJ == 1 && MEGA_RJ == 2 && MEGA_VI == 4, "the packed weight records are laid out for 1 pair / 2 rows / 4 elements per lane");
 __device__ __forceinline__ void mega_load_blk(MegaBlkW& w, const MegaArgs& a, int l, int g, int lane) {
-  const float4* rec = a.crec + ((size_t)(l * MEGA_G + g) * 64 + lane) * 4;
-  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-  const float4 bq = a.brec[(size_t)(l * MEGA_G + g) * 2];
-  w.wA[0][0][0] = r0.x; w.wA[0][0][1] = r0.y; w.wA[0][0][2] = r0.z; w.wA[0][0][3] = r0.w;
-  w.wA[0][1][0] = r1.x; w.wA[0][1][1] = r1.y; w.wA[0][1][2] = r1.z; w.wA[0][1][3] = r1.w;
-  w.wR[0][0] = r2.x; w.wR[0][1] = r2.y; w.wR[1][0] = r2.z; w.wR[1][1] = r2.w;
-  w.wS[0][0] = r3.x; w.wS[0][1] = r3.y; w.wS[1][0] = r3.z; w.wS[1][1] = r3.w;
+  const float4* rec = a.crec + ((size_t)(l * MEGA_G + g) * 64 + lane) * MEGA_CREC;
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+  const float4 bq = a.brec[(size_t)(l * MEGA_G + g) * 2], bc = a.brec[(size_t)(l * MEGA_G + g) * 2 + 1];
+  w.wU[0][0] = r0.x; w.wU[0][1] = r0.y; w.wU[0][2] = r0.z; w.wU[0][3] = r0.w;
+  w.wU[1][0] = r1.x; w.wU[1][1] = r1.y; w.wU[1][2] = r1.z; w.wU[1][3] = r1.w;
+  w.wM[0][0] = r2.x; w.wM[0][1] = r2.y; w.wM[1][0] = r2.z; w.wM[1][1] = r2.w;
+  w.wR[0][0] = r3.x; w.wR[0][1] = r3.y; w.wR[1][0] = r3.z; w.wR[1][1] = r3.w;
+  w.wS[0][0] = r4.x; w.wS[0][1] = r4.y; w.wS[1][0] = r4.z; w.wS[1][1] = r4.w;
   w.bR[0] = bq.x; w.bR[1] = bq.y; w.bS[0] = bq.z; w.bS[1] = bq.w;
+  w.cb[0] = bc.z; w.cb[1] = bc.w;
 }
 
-// One-off repack of the Chainer-layout weights into per-(block, workgroup, lane) records, so that
-// the step loop fetches a block's weights with four coalesced 16-byte loads per lane.
+// One-off repack of the Chainer-layout weights into per-(block, workgroup, lane) records (four or
+// five coalesced 16-byte loads per lane fetch a block), including the composite matrices.
 __global__ __launch_bounds__(64) void gen_mega_pack_kernel(const MegaBlock* blk, int L, int R, int half, int S, int Cc,
                                                            float4* crec, float4* hrec, float4* brec) {
   const int l = blockIdx.x / MEGA_G, g = blockIdx.x % MEGA_G, lane = threadIdx.x;
   const MegaBlock bk = blk[l];
   const bool last = l == L - 1;
-  float c[16], h[16];
+  const MegaBlock bn = blk[last ? l : l + 1];
+  float c[20], h[16];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = lane + 64 * i;
@@ -521,32 +535,80 @@ __global__ __launch_bounds__(64) void gen_mega_pack_kernel(const MegaBlock* blk,
     for (int hh = 0; hh < 2; ++hh) {
       const int row = g + hh * half;
       const bool ok = g < half && k < R;
-      c[hh * 4 + i] = ok ? bk.conv_W[((size_t)row * R + k) * 2 + 1] : 0.f;          // tap 1: new sample
-      h[hh * 4 + i] = ok ? bk.conv_W[((size_t)row * R + k) * 2] : 0.f;              // tap 0: old sample
+      c[hh * 4 + i] = (ok && !last) ? bn.conv_W[((size_t)row * R + k) * 2 + 1] : 0.f;   // tap 1 of block l+1
+      h[hh * 4 + i] = ok ? bk.conv_W[((size_t)row * R + k) * 2] : 0.f;                  // tap 0 of block l
       h[8 + hh * 4 + i] = (g < half && k < Cc) ? bk.cond_W[(size_t)row * Cc + k] : 0.f;
     }
+  }
+  double cbv[2] = {0.0, 0.0};
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = g + hh * half;
+    double m0 = 0.0, m1 = 0.0;
+    if (!last && g < half) {
+      for (int cc = 0; cc < R; ++cc) {
+        const double w = (double)bn.conv_W[((size_t)row * R + cc) * 2 + 1];
+        if (lane < half) m0 += w * (double)bk.res_W[(size_t)cc * half + lane];
+        if (lane + 64 < half) m1 += w * (double)bk.res_W[(size_t)cc * half + lane + 64];
+        cbv[hh] += w * (double)bk.res_b[cc];
+      }
+    }
+    c[8 + hh * 2] = (float)m0;
+    c[8 + hh * 2 + 1] = (float)m1;
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = g + MEGA_G * j, k = lane + 64 * i;
-      c[8 + j * 2 + i] = (!last && r < R && k < half) ? bk.res_W[(size_t)r * half + k] : 0.f;
-      c[12 + j * 2 + i] = (r < S && k < half) ? bk.skip_W[(size_t)r * half + k] : 0.f;
+      c[12 + j * 2 + i] = (!last && r < R && k < half) ? bk.res_W[(size_t)r * half + k] : 0.f;
+      c[16 + j * 2 + i] = (r < S && k < half) ? bk.skip_W[(size_t)r * half + k] : 0.f;
     }
-  float4* cr = crec + ((size_t)blockIdx.x * 64 + lane) * 4;
+  float4* cr = crec + ((size_t)blockIdx.x * 64 + lane) * MEGA_CREC;
   float4* hr = hrec + ((size_t)blockIdx.x * 64 + lane) * 4;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    cr[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-    hr[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
-  }
+  for (int q = 0; q < MEGA_CREC; ++q) cr[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hr[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
   if (lane == 0) {
     const int r0 = g, r1 = g + MEGA_G;
     brec[(size_t)blockIdx.x * 2] = make_float4((!last && r0 < R) ? bk.res_b[r0] : 0.f, (!last && r1 < R) ? bk.res_b[r1] : 0.f,
                                                r0 < S ? bk.skip_b[r0] : 0.f, r1 < S ? bk.skip_b[r1] : 0.f);
     brec[(size_t)blockIdx.x * 2 + 1] = make_float4(g < half ? bk.conv_b[g] + bk.cond_b[g] : 0.f,
-                                                   g < half ? bk.conv_b[g + half] + bk.cond_b[g + half] : 0.f, 0.f, 0.f);
+                                                   g < half ? bk.conv_b[g + half] + bk.cond_b[g + half] : 0.f,
+                                                   (float)cbv[0], (float)cbv[1]);
+  }
+}
+
+// All sequences' vectors of one mailbox in a single polling loop (element k = lane + 64 i of sequence b).
+template <int NB>
+__device__ __forceinline__ bool mega_gather_n(const gran_t* box, size_t bstride, int n, int K, uint32_t tag,
+                                              float (&v)[NB][MEGA_VI], int* status) {
+  const int lane = threadIdx.x & 63;
+  unsigned pending = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < MEGA_VI; ++i) { v[b][i] = 0.f; if (b < n && lane + 64 * i < K) pending |= 1u << (b * MEGA_VI + i); }
+  int spins = 0;
+  for (;;) {
+    gran_t gr[NB][MEGA_VI];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < MEGA_VI; ++i) if (pending & (1u << (b * MEGA_VI + i))) gr[b][i] = g_get(box + b * bstride + lane + 64 * i);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < MEGA_VI; ++i) {
+        const unsigned bit = 1u << (b * MEGA_VI + i);
+        if ((pending & bit) && (uint32_t)(gr[b][i] >> 32) == tag) { v[b][i] = __uint_as_float((uint32_t)gr[b][i]); pending &= ~bit; }
+      }
+    if (__all(pending == 0)) return true;
+    if ((++spins & 255) == 0) {
+      if (mega_aborted(status)) return false;
+      if (spins > MEGA_SPIN_LIMIT) { mega_abort(status, 1); return false; }
+    }
   }
 }
 
@@ -642,8 +704,18 @@ __global__ __launch_bounds__(MEGA_THREADS) void gen_mega_kernel(MegaArgs a) {
       if (back == 1) { ic[b] = iv; fc[b] = fv; } else { ip[b] = iv; fp[b] = fv; }
     }
   }
-  // step-invariant registers: embed bias, head weights and biases
-  float bE[MEGA_RJ], b1[MEGA_RJ], b2[MEGA_RJ], w1[MEGA_RJ][MEGA_VI], w2[MEGA_RJ][MEGA_VI];
+  // step-invariant registers: embed bias, head weights and biases, block 0's tap-1 rows
+  float bE[MEGA_RJ], b1[MEGA_RJ], b2[MEGA_RJ], w1[MEGA_RJ][MEGA_VI], w2[MEGA_RJ][MEGA_VI], wU0[2][MEGA_VI], bEf[MEGA_VI];
+  {
+    const MegaBlock bk0 = a.blk[0];
+#pragma unroll
+    for (int i = 0; i < MEGA_VI; ++i) {
+      const int k = lane + 64 * i;
+      bEf[i] = k < R ? a.embed_b[k] : 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wU0[h][i] = (g < half && k < R) ? GF(bk0.conv_W)[((size_t)(g + h * half) * R + k) * 2 + 1] : 0.f;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < MEGA_RJ; ++j) {
     const int r = g + MEGA_G * j;
@@ -662,103 +734,118 @@ __global__ __launch_bounds__(MEGA_THREADS) void gen_mega_kernel(MegaArgs a) {
 
   for (int t = a.t0; t < a.t0 + a.steps; ++t) {
     const uint32_t tag = (uint32_t)t + 1u;
-    float xown[MEGA_RJ][NB], sacc[MEGA_RJ][NB];
-    // ---- embed (modules.py:247-248): the queue holds [input(t-1), input(t)] ----
+    float xown[MEGA_RJ][NB], sacc[MEGA_RJ][NB], xf[NB][MEGA_VI];
+    // ---- embed (modules.py:247-248) on [input(t-1), input(t)]: a function of the two fed-back
+    //      values only, so every workgroup rebuilds the whole x_0 itself -- no hand-off ----
     {
       const MegaQ bk0 = a.qt[0];
       gran_t* q = a.xq + bk0.qoff + (size_t)(t % (bk0.dilation + 1)) * n * R;
-      float e0[MEGA_RJ][NB], e1[MEGA_RJ][NB];
 #pragma unroll
-      for (int j = 0; j < MEGA_RJ; ++j) {
-        const int r = g + MEGA_G * j;
+      for (int b = 0; b < NB; ++b) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          e0[j][b] = e1[j][b] = 0.f; sacc[j][b] = 0.f;
-          if (r >= R || b >= n) continue;
-          if (a.mode == VQVAE_GEN_SOFTMAX) {
-            if (ip[b] >= 0) e0[j][b] = a.embed_W[((size_t)r * a.input_dim + ip[b]) * 2];
-            if (ic[b] >= 0) e1[j][b] = a.embed_W[((size_t)r * a.input_dim + ic[b]) * 2 + 1];
-          } else {
-            for (int c = 0; c < a.input_dim; ++c) {
-              e0[j][b] += a.embed_W[((size_t)r * a.input_dim + c) * 2] * fp[b];
-              e1[j][b] += a.embed_W[((size_t)r * a.input_dim + c) * 2 + 1] * fc[b];
+        for (int i = 0; i < MEGA_VI; ++i) {
+          const int k = lane + 64 * i;
+          float e0 = 0.f, e1 = 0.f;
+          if (b < n && k < R) {
+            if (a.mode == VQVAE_GEN_SOFTMAX) {
+              if (ip[b] >= 0) e0 = a.embed_W[((size_t)k * a.input_dim + ip[b]) * 2];
+              if (ic[b] >= 0) e1 = a.embed_W[((size_t)k * a.input_dim + ic[b]) * 2 + 1];
+            } else {
+              for (int c = 0; c < a.input_dim; ++c) {
+                e0 += a.embed_W[((size_t)k * a.input_dim + c) * 2] * fp[b];
+                e1 += a.embed_W[((size_t)k * a.input_dim + c) * 2 + 1] * fc[b];
+              }
             }
           }
+          xf[b][i] = (b < n && k < R) ? (e0 + e1) + bEf[i] : 0.f;
         }
-      }
 #pragma unroll
-      for (int j = 0; j < MEGA_RJ; ++j) {
-        const int r = g + MEGA_G * j;
+        for (int j = 0; j < MEGA_RJ; ++j) {
+          const int r = g + MEGA_G * j;             // x_0[r] sits in lane r % 64, element r / 64
+          float v = 0.f;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          xown[j][b] = (e0[j][b] + e1[j][b]) + bE[j];
-          if (r < R && b < n && lane == 0) g_put(q + (size_t)b * R + r, xown[j][b], tag);
+          for (int i = 0; i < MEGA_VI; ++i) if (r / 64 == i) v = __shfl(xf[b][i], r & 63, 64);
+          xown[j][b] = v; sacc[j][b] = 0.f;
+          if (r < R && b < n && lane == 0) g_put(q + (size_t)b * R + r, v, tag);      // queue entry for the helpers
         }
       }
     }
+    // ---- z_0: gate of block 0 (modules.py:40-48) ----
+    if (!lds_wait_eq(&ready_s[0], t + 1, a.status)) return;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= n || g >= half) continue;
+      float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MEGA_VI; ++i) { h0 += wU0[0][i] * xf[b][i]; h1 += wU0[1][i] * xf[b][i]; }
+      h0 = mega_wave_sum(h0) + pre_s[0][0][0][b];
+      h1 = mega_wave_sum(h1) + pre_s[0][0][1][b];
+      if (lane == 0) g_put(a.zbox + (size_t)b * half + g, mega_gate(h0, h1), tag);
+    }
+    if (lane == 0) lds_post(&consumed_s[0], t + 1);
     MP_T(0);
-    // ---- residual blocks (modules.py:102-110) ----
+    // ---- residual blocks (modules.py:102-110), one critical hand-off each: z_l ----
     for (int l = 0; l < a.L; ++l) {
-      const MegaQ bk = a.qt[l];
-      const bool last = l == a.L - 1;
-      const gran_t* q = a.xq + bk.qoff + (size_t)(t % (bk.dilation + 1)) * n * R;
-      // A: new tap of the dilated conv + the helpers' part, gate (modules.py:40-48)
-      float xv[NB][MEGA_VI];
+      const bool has_next = l + 1 < a.L;
+      mega_load_blk(nxt, a, has_next ? l + 1 : 0, g, lane);       // lands while z_l is awaited
+      // shadow of the z_l hand-off: the x_l term of the next gate, u = Wc1_{l+1} x_l
+      float u[2][NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int i = 0; i < MEGA_VI; ++i) xv[b][i] = 0.f;
-        if (b < n && !mega_gather(q + (size_t)b * R, R, tag, xv[b], a.status)) return;
-      }
-      MP_T(1);
-      if (!lds_wait_eq(&ready_s[l], t + 1, a.status)) return;
-      MP_T(2);
-      gran_t* zb = a.zbox + (size_t)l * n * half;
-#pragma unroll
-      for (int j = 0; j < MEGA_PJ; ++j) {
-        const int p = g + MEGA_G * j;
+      for (int b = 0; b < NB; ++b) u[0][b] = u[1][b] = 0.f;
+      if (has_next) {
+        if (l > 0) {
+          const MegaQ bk = a.qt[l];
+          const gran_t* q = a.xq + bk.qoff + (size_t)(t % (bk.dilation + 1)) * n * R;
+          if (!mega_gather_n<NB>(q, R, n, R, tag, xf, a.status)) return;
+        }
+        MP_T(1);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          if (b >= n || p >= half) continue;
-          float h0 = 0.f, h1 = 0.f;
+          if (b >= n || g >= half) continue;
+          float u0 = 0.f, u1 = 0.f;
 #pragma unroll
-          for (int i = 0; i < MEGA_VI; ++i) { h0 += cur.wA[j][0][i] * xv[b][i]; h1 += cur.wA[j][1][i] * xv[b][i]; }
-          h0 = mega_wave_sum(h0) + pre_s[l][j][0][b];
-          h1 = mega_wave_sum(h1) + pre_s[l][j][1][b];
-          if (lane == 0) g_put(zb + (size_t)b * half + p, mega_gate(h0, h1), tag);
+          for (int i = 0; i < MEGA_VI; ++i) { u0 += cur.wU[0][i] * xf[b][i]; u1 += cur.wU[1][i] * xf[b][i]; }
+          u[0][b] = mega_wave_sum(u0);
+          u[1][b] = mega_wave_sum(u1);
         }
       }
-      if (lane == 0) lds_post(&consumed_s[l], t + 1);
-      // next block's weights: issued now, they land while this block's z is awaited
-      mega_load_blk(nxt, a, last ? 0 : l + 1, g, lane);
-      MP_T(3);
-      // B: res / skip 1x1 (modules.py:52-55), push into the next block's queue (71-74)
+      MP_T(2);
+      // the critical hand-off
       float zv[NB][MEGA_VI];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int i = 0; i < MEGA_VI; ++i) zv[b][i] = 0.f;
-        if (b < n && !mega_gather(zb + (size_t)b * half, half, tag, zv[b], a.status)) return;
-      }
-      MP_T(4);
-      gran_t* qn = nullptr;
-      if (!last) {
+      if (!mega_gather_n<NB>(a.zbox + (size_t)l * n * half, half, n, half, tag, zv, a.status)) return;
+      MP_T(3);
+      if (has_next) {
+        // own rows of x_{l+1} = Wr z + br + x_l (modules.py:52-54): published first, they are cheap
+        // and every workgroup needs them for its next shadow term; also the queue push (71-74)
         const MegaQ bn = a.qt[l + 1];
-        qn = a.xq + bn.qoff + (size_t)(t % (bn.dilation + 1)) * n * R;
-      }
+        gran_t* qn = a.xq + bn.qoff + (size_t)(t % (bn.dilation + 1)) * n * R;
 #pragma unroll
-      for (int j = 0; j < MEGA_RJ; ++j) {
-        const int r = g + MEGA_G * j;
+        for (int j = 0; j < MEGA_RJ; ++j) {
+          const int r = g + MEGA_G * j;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          if (b >= n) continue;
-          if (!last && r < R) {
+          for (int b = 0; b < NB; ++b) {
+            if (b >= n || r >= R) continue;
             const float dot = mega_wave_sum(cur.wR[j][0] * zv[b][0] + cur.wR[j][1] * zv[b][1]);
             xown[j][b] = (dot + cur.bR[j]) + xown[j][b];
             if (lane == 0) g_put(qn + (size_t)b * R + r, xown[j][b], tag);
           }
         }
+        // z_{l+1} through the composite matrix
+        if (!lds_wait_eq(&ready_s[l + 1], t + 1, a.status)) return;
+        gran_t* zb = a.zbox + (size_t)(l + 1) * n * half;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b >= n || g >= half) continue;
+          float h0 = mega_wave_sum(cur.wM[0][0] * zv[b][0] + cur.wM[0][1] * zv[b][1]);
+          float h1 = mega_wave_sum(cur.wM[1][0] * zv[b][0] + cur.wM[1][1] * zv[b][1]);
+          h0 = ((h0 + u[0][b]) + cur.cb[0]) + pre_s[l + 1][0][0][b];
+          h1 = ((h1 + u[1][b]) + cur.cb[1]) + pre_s[l + 1][0][1][b];
+          if (lane == 0) g_put(zb + (size_t)b * half + g, mega_gate(h0, h1), tag);
+        }
+        if (lane == 0) lds_post(&consumed_s[l + 1], t + 1);
       }
+      MP_T(4);
+      // skip rows (modules.py:55, 105-109): nobody waits for them before the head
 #pragma unroll
       for (int j = 0; j < MEGA_RJ; ++j) {
         const int r = g + MEGA_G * j;
@@ -781,12 +868,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void gen_mega_kernel(MegaArgs a) {
         if (r < S && b < n && lane == 0) g_put(a.sbox + (size_t)b * S + r, fmaxf(sacc[j][b], 0.f), tag);
     }
     float sv[NB][MEGA_VI];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int i = 0; i < MEGA_VI; ++i) sv[b][i] = 0.f;
-      if (b < n && !mega_gather(a.sbox + (size_t)b * S, S, tag, sv[b], a.status)) return;
-    }
+    if (!mega_gather_n<NB>(a.sbox, S, n, S, tag, sv, a.status)) return;
     MP_T(6);
 #pragma unroll
     for (int j = 0; j < MEGA_RJ; ++j) {
@@ -801,12 +883,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void gen_mega_kernel(MegaArgs a) {
         if (lane == 0) g_put(a.s1box + (size_t)b * S + r, fmaxf(acc, 0.f), tag);
       }
     }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-      for (int i = 0; i < MEGA_VI; ++i) sv[b][i] = 0.f;
-      if (b < n && !mega_gather(a.s1box + (size_t)b * S, S, tag, sv[b], a.status)) return;
-    }
+    if (!mega_gather_n<NB>(a.s1box, S, n, S, tag, sv, a.status)) return;
     MP_T(7);
 #pragma unroll
     for (int j = 0; j < MEGA_RJ; ++j) {
@@ -936,7 +1013,7 @@ static size_t mega_layout(const vqvae_gen_desc* d, size_t* off_tab, size_t* off_
   *off_idx = o; o += 256;
   *off_qt = o; o += vq::align_up(sizeof(vq::MegaQ) * d->n_blocks, 256);
   const size_t recs = (size_t)d->n_blocks * vq::MEGA_G;
-  *off_crec = o; o += recs * 64 * 64;
+  *off_crec = o; o += recs * 64 * 16 * vq::MEGA_CREC;
   *off_hrec = o; o += recs * 64 * 64;
   *off_brec = o; o += vq::align_up(recs * 32, 256);
   return o;

@@ -18,8 +18,8 @@ u = rs.uniform(0.01, 0.99, (steps + 1, n))
 dec.generate_sequence(cond, u, persistent=True)
 ws = dec._gen._last_ws
 prof = ws.flat_view(16, 32).get().view(np.int64)
-names = ['embed + publish x0', 'A: gather x', 'A: wait helpers', 'A: compute + publish z + issue next weights', 'B: gather z',
-         'B: compute + publish x', 'head: publish s + gather', 'proj1 + gather s1', 'proj2 + publish', 'sampler (wg 0)', 'feedback gather']
+names = ['embed + z_0 publish', 'shadow: gather x_l', 'shadow: u = Wc1 x_l', 'critical: gather z_l', 'x rows + z_{l+1} publish',
+         'skip rows + weight hand-over', 'head: publish s + gather', 'proj1 + gather s1', 'proj2 + publish', 'sampler (wg 0)', 'feedback gather']
 tot = prof[:11].sum()
 for i, nm in enumerate(names):
     print('%-52s %8.2f us/step' % (nm, prof[i] * 0.01 / steps))
