@@ -9,3 +9,4 @@ from .updaters import (VQVAE_ParallelUpdater, VQVAE_StandardUpdater,  # noqa: F4
                        concat_examples)
 from .utils import VQ, ExponentialMovingAverage, MuLaw, StraightThrough, straight_through  # noqa: F401
 from .wavenet import ResidualBlock, ResidualNet, WaveNet  # noqa: F401
+from .synthesis import synthesize  # noqa: F401

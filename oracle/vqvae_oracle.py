@@ -1,4 +1,5 @@
-"""CPU oracle: a NumPy restatement of the reference's training hot path.
+"""CPU oracle: a NumPy restatement of the reference's training hot path (and of
+its incremental generation loop).
 
 THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
@@ -14,6 +15,10 @@ Parity pin status
 * ``vq_forward`` / ``vq_backward`` / ``MuLaw``: PINNED against golden vectors
   produced by executing the reference's own ``utils.py`` bodies
   (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``).
+* ``choice_from_uniform`` (the sampler of generate.py:136): PINNED against
+  ``numpy.random.RandomState.choice`` itself (tests/test_oracle.py); the queue
+  arithmetic of incremental generation is checked against the training
+  forward (same inputs, step i == column i).
 * conv / resize / softmax-CE / MoL / Adam / EMA: the arithmetic lives in
   Chainer 4.0.0b3 (README.md:21), a third-party dependency that is NOT vendored
   under /root/reference and is not installed.  The reference has no tests or

@@ -191,3 +191,27 @@ def test_generation_argument_errors(gpu):
         dec.generate(np.zeros((1, 256, 1, 1), np.float32), gpu.zeros((1, 64, 1, 1)))   # host array
     with pytest.raises(ValueError):
         dec.generate_sequence(gpu.zeros((1, 64, 8)), np.zeros(3))      # too few uniforms
+
+
+def test_synthesize_matches_oracle_pipeline(gpu):
+    """generate.py:94-149 end to end: encoder -> VQ -> condition embed (other speaker) -> sampling
+    loop -> mu-law expansion, against the same pipeline composed from the oracle's parts."""
+    import vqvae_amd as V
+    cfg = dict(H.SMALL)
+    P, model = H.build_model(cfg, seed=31, tweak=_random_biases(32))
+    model.to_gpu()
+    x_enc, _, spk, _ = O.synth_batch(1, length=128, n_speaker=cfg['n_speaker'], seed=5)
+    speaker = np.array([(int(spk[0]) + 1) % cfg['n_speaker']], np.int32)        # convert to another voice
+    z, _ = O.encoder_fwd(P['encoder'], x_enc)
+    e4, idx = O.vq_forward(O.expand4(z), P['vq'])
+    cond, _ = O.cond_embed_fwd(P['condition_embed'], np.ascontiguousarray(O.squeeze4(e4)), speaker)
+    T = cond.shape[2]
+    u = np.random.RandomState(77).random_sample((T - 1, 1))
+    want_out, _ = O.wavenet_generate(P['decoder'], cond, u, cfg['n_loop'], cfg['n_layer'])
+    want_wave = O.MuLaw(256).itransform(want_out)
+    wave, out = V.synthesize(model.encoder, model.vq, model.decoder, model.condition_embed,
+                             x_enc[..., None], speaker, rng=np.random.RandomState(77))
+    assert T == 128 and out.shape == (1, T)
+    np.testing.assert_array_equal(out, want_out)
+    np.testing.assert_allclose(wave, want_wave, rtol=0, atol=1e-7)
+    assert wave.dtype == want_wave.dtype
