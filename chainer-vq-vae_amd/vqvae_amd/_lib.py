@@ -173,6 +173,9 @@ def load():
             'libvqvae_hip.so not found at %s -- build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
             'There is no CPU fallback.' % LIB_PATH)
+    # the host driver only supports dmabuf IPC: RCCL's peer-memory exchange fails with the legacy mode.
+    # Must be in the environment before the HSA runtime initialises (first HIP call).
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is missing

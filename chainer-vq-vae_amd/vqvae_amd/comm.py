@@ -73,7 +73,15 @@ class RcclCommunicator(object):
             os.rename(tmp, path)
         else:
             t0 = time.time()
-            while not os.path.exists(path):
+
+            def fresh():
+                # a file left behind by a crashed earlier job with the same key is not ours: ranks of
+                # one job start within seconds of each other, rank 0's file cannot be minutes old
+                try:
+                    return os.path.getmtime(path) > t0 - 120.0
+                except OSError:
+                    return False
+            while not fresh():
                 if time.time() - t0 > timeout:
                     raise RuntimeError('RCCL rendezvous timed out waiting for %s' % path)
                 time.sleep(0.05)
