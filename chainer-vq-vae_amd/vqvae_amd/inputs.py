@@ -6,6 +6,8 @@ step (updaters.py:8).  Here the host ships only the normalised waveform crops (0
 GPU bins them (bit-exact with utils.py:18-23) and the decoder's embed conv consumes the bin
 INDICES directly (a 2-column gather, bit-identical to the dense conv on the one-hot tensor).
 """
+import random
+
 import numpy as np
 
 from . import _lib, backend
@@ -39,6 +41,22 @@ def mulaw_thresholds(mu=256):
         hi = np.where(ge, mid, hi)
         lo = np.where(ge, lo, mid)
     return _key_f32(hi).astype(np.float32)
+
+
+def crop_or_pad(wave, length, start=None, rng=random):
+    """The padding / trimming branch of Preprocess.__call__ (utils.py:57-58, 65-81) for one loaded
+    and silence-trimmed waveform: peak-normalise, then zero-pad to ``length + 1`` samples or take
+    ``length + 1`` samples from ``start`` (default: ``rng.randint(0, len - (length+1) - 1)``, the
+    reference's unseeded ``random``).  Zero padding of the waveform IS the reference's padding of
+    the bins with quantize // 2, because MuLaw.transform(0.0) == quantize // 2 (utils.py:74)."""
+    L = length + 1                                                 # utils.py:47
+    raw = np.asarray(wave, np.float32)
+    raw = (raw / np.abs(raw).max()).astype(np.float32)             # utils.py:58-59
+    if len(raw) <= L:
+        return np.concatenate((raw, np.zeros(L - len(raw), np.float32)))
+    if start is None:
+        start = rng.randint(0, len(raw) - L - 1)                   # utils.py:78
+    return raw[start:start + L]
 
 
 class IndexInput(DeviceArray):
@@ -75,6 +93,13 @@ class DeviceInputPipeline(object):
         _lib.call('vqvae_mulaw_bins', x.ptr, x.size, self._thr.ptr, self._thr.size, q.ptr,
                   backend.stream())
         return q
+
+    def from_waveforms(self, waves, speaker, length, starts=None, rng=random):
+        """Variable-length waveforms -> minibatch: crop_or_pad each (host, a few KB), then bin on
+        the device.  ``starts``: optional explicit crop offsets (None entries draw from ``rng``)."""
+        starts = [None] * len(waves) if starts is None else starts
+        raw = np.stack([crop_or_pad(w, length, s, rng) for w, s in zip(waves, starts)])
+        return self(raw, speaker)
 
     def __call__(self, raw, speaker):
         raw = np.ascontiguousarray(raw, np.float32)

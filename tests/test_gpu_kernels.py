@@ -422,3 +422,20 @@ def test_conv1d_bf16_operands(gpu, bf16_mode, case):
     assert_close_scaled(vx.grad.get(), gx_ref, 1e-4, 'gx (bf16 operands)')
     assert_close_scaled(vW.grad.get(), gW_ref, 1e-4, 'gW (bf16 operands)')
     assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'gb')
+
+
+def test_device_input_pipeline_from_waveforms_golden(gpu):
+    """Padding and trimming branches of Preprocess.__call__ (utils.py:57-110) through the device
+    pipeline against the vectors produced by running the reference itself (tests/golden/
+    make_golden.py): raw, the bins behind the one-hot x_dec, and t, bit for bit."""
+    from vqvae_amd.inputs import DeviceInputPipeline
+    g = np.load(os.path.join(GOLD, 'preprocess.npz'))
+    pipe = DeviceInputPipeline(256)
+    x_enc, x_dec, spk, t = pipe.from_waveforms([g['wave_short'], g['wave_long']], np.array([1, 2], np.int32),
+                                               255, starts=[None, int(g['crop_start'])])
+    assert x_enc.shape == (2, 1, 256, 1) and x_dec.shape == (2, 255) and t.shape == (2, 255, 1)
+    for i, name in enumerate(('short', 'long')):
+        np.testing.assert_array_equal(x_enc.get()[i], g['mulaw_%s_raw' % name])
+        np.testing.assert_array_equal(x_dec.get()[i], g['mulaw_%s_x_dec' % name][:, :, 0].argmax(axis=0))
+        np.testing.assert_array_equal(t.get()[i], g['mulaw_%s_t' % name])
+    assert x_dec.get()[0, -1] == 128 and t.get()[0, -1, 0] == 128       # zero padding == bin quantize//2

@@ -240,3 +240,19 @@ def test_mulaw_thresholds_reproduce_transform():
     np.testing.assert_array_equal(got, f(x))
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'mulaw.npz'))
     np.testing.assert_array_equal(np.searchsorted(thr, g['x'], side='right'), g['q'])
+
+
+def test_crop_or_pad_follows_preprocess_golden():
+    """utils.py:57-81 (normalise, pad / trim) against the waveforms the reference produced."""
+    import os
+    from vqvae_amd.inputs import crop_or_pad
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess.npz'))
+    np.testing.assert_array_equal(crop_or_pad(g['wave_short'], 255), g['mulaw_short_raw'][0, :, 0])
+    np.testing.assert_array_equal(crop_or_pad(g['wave_long'], 255, start=int(g['crop_start'])),
+                                  g['mulaw_long_raw'][0, :, 0])
+
+    class _Rng(object):
+        def randint(self, lo, hi):                     # utils.py:78: random.randint(0, len - length - 1)
+            assert (lo, hi) == (0, 700 - 256 - 1)
+            return int(g['crop_start'])
+    np.testing.assert_array_equal(crop_or_pad(g['wave_long'], 255, rng=_Rng()), g['mulaw_long_raw'][0, :, 0])
