@@ -173,6 +173,8 @@ def main():
     ap.add_argument('--index-input', action='store_true',
                     help='feed x_dec as mu-law bin indices produced on the device (device-side input '
                          'pipeline) instead of the reference\'s one-hot float tensor')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='single stream: no side-stream overlap of the weight-gradient kernels (per-kernel timing)')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -195,6 +197,8 @@ def main():
     backend.init(local)
     if args.bf16:
         backend.set_matmul_dtype('bfloat16')
+    if args.no_overlap:
+        backend.set_overlap(False)
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
 
     model, opt = build(cfg, n)

@@ -22,6 +22,7 @@
 //   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A^T
 //                           slabs the GEMM wants ([k][m], m contiguous, zero padded).
 #include "common.h"
+#include <type_traits>
 
 namespace vq {
 
@@ -79,12 +80,12 @@ struct GemmArgs {
 // tanhf in the epilogue of the hottest kernel.
 __device__ __forceinline__ float fast_tanhf_(float x) {
   const float e = __expf(-2.f * fabsf(x));
-  const float r = __fdividef(1.f - e, 1.f + e);
+  const float r = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);     // v_rcp_f32: 1 ulp; __fdividef expands to a full division here
   return copysignf(r, x);
 }
 __device__ __forceinline__ float sigmoidf_(float x) {
   const float e = __expf(-fabsf(x));
-  const float r = __fdividef(1.f, 1.f + e);      // sigmoid(|x|)
+  const float r = __builtin_amdgcn_rcpf(1.f + e);      // sigmoid(|x|)
   return x >= 0.f ? r : 1.f - r;
 }
 
@@ -125,112 +126,255 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   int nk = 0;
   for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
 
-  float4 ra0, ra1;
-  float4 rb0, rb1;
-  bool rvec = false;
+  if constexpr (WM == 4) {
+    float4 ra0, ra1;
+    float4 rb0, rb1;
+    bool rvec = false;
 
-  // thread roles for the staging loads (per K step: A = 16 x BM, B = 16 x 128 floats)
-  constexpr int ACOLS4 = BM / 4;                        // float4 per A row
-  const int a_k = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;    // A: rows a_k, a_k + 8
-  const int v_k = tid >> 5, v_col = (tid & 31) * 4;     // vector B: row v_k (+8 when WM == 2)
-  constexpr int BROWS = NT / 128;                        // scalar B: rows b_k + BROWS*i
-  const int b_n = tid & 127, b_k = tid >> 7;
+    // thread roles for the staging loads (per K step: A = 16 x BM, B = 16 x 128 floats)
+    constexpr int ACOLS4 = BM / 4;                        // float4 per A row
+    const int a_k = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;    // A: rows a_k, a_k + 8
+    const int v_k = tid >> 5, v_col = (tid & 31) * 4;     // vector B: row v_k (+8 when WM == 2)
+    constexpr int BROWS = NT / 128;                        // scalar B: rows b_k + BROWS*i
+    const int b_n = tid & 127, b_k = tid >> 7;
 
-  auto load_tiles = [&](int s, int c0) {
-    const Seg& sg = a.seg[s];
-    const float* wp = sg.w + (long)(c0 + a_k) * sg.ldw + m0 + a_col;
-    ra0 = *reinterpret_cast<const float4*>(wp);
-    ra1 = *reinterpret_cast<const float4*>(wp + 8L * sg.ldw);
-    const float* xb = sg.x + (long)b * sg.x_bstride;
-    const int tw = t0 * sg.tmul + sg.toff;   // window start (when tmul==1,tdiv==1)
-    rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
-    if (rvec) {
-      const int ci0 = c0 + v_k, ci1 = c0 + v_k + 8;
-      rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ci0 < sg.cin) rb0 = *reinterpret_cast<const float4*>(xb + (long)ci0 * sg.x_cstride + tw + v_col);
-      if (WM == 2 && ci1 < sg.cin) rb1 = *reinterpret_cast<const float4*>(xb + (long)ci1 * sg.x_cstride + tw + v_col);
-    } else {
-      const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
-      bool ok = tnum >= 0;
-      int tin = tnum;
-      if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
-      ok = ok && tin < sg.Tin;
-      const float* xp = xb + (long)(c0 + b_k) * sg.x_cstride + tin;
-      const long csr = (long)BROWS * sg.x_cstride;
-      const int cb = c0 + b_k;
-      rb0.x = (ok && cb + 0 * BROWS < sg.cin) ? xp[0 * csr] : 0.f;
-      rb0.y = (ok && cb + 1 * BROWS < sg.cin) ? xp[1 * csr] : 0.f;
-      rb0.z = (ok && cb + 2 * BROWS < sg.cin) ? xp[2 * csr] : 0.f;
-      rb0.w = (ok && cb + 3 * BROWS < sg.cin) ? xp[3 * csr] : 0.f;
-      if (WM == 2) {
-        rb1.x = (ok && cb + 4 * BROWS < sg.cin) ? xp[4 * csr] : 0.f;
-        rb1.y = (ok && cb + 5 * BROWS < sg.cin) ? xp[5 * csr] : 0.f;
-        rb1.z = (ok && cb + 6 * BROWS < sg.cin) ? xp[6 * csr] : 0.f;
-        rb1.w = (ok && cb + 7 * BROWS < sg.cin) ? xp[7 * csr] : 0.f;
+    // Staging state of the NEXT K step, advanced incrementally: a VALU instruction issued beside
+    // the MFMA stream costs ~4 % of an MFMA slot (tools/ubench/mfma_coexec.hip), so the per-step
+    // address arithmetic is two pointer bumps; everything else is set up once per segment.
+    int s_n = 0, c_n = 0, cin_n = 0;
+    const float* wp = nullptr;       // A: row a_k of the chunk (+ wrow8 for row a_k + 8)
+    const float* xp = nullptr;       // B: vector path row v_k at the window start, scalar path row b_k at tin
+    long wrow8 = 0, wadv = 0, xadv = 0, xrow = 0;
+    bool rvec_n = false, ok_n = false;
+    auto seg_setup = [&](int s) {
+      const Seg& sg = a.seg[s];
+      cin_n = sg.cin; c_n = 0;
+      wp = sg.w + (long)a_k * sg.ldw + m0 + a_col;
+      wrow8 = 8L * sg.ldw; wadv = (long)BK * sg.ldw; xadv = (long)BK * sg.x_cstride;
+      const float* xb = sg.x + (long)b * sg.x_bstride;
+      const int tw = t0 * sg.tmul + sg.toff;   // window start (when tmul==1,tdiv==1)
+      rvec_n = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
+      if (rvec_n) {
+        xp = xb + (long)v_k * sg.x_cstride + tw + v_col;
+        xrow = 8L * sg.x_cstride;
+      } else {
+        const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
+        bool ok = tnum >= 0;
+        int tin = tnum;
+        if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+        ok_n = ok && tin < sg.Tin;
+        xp = xb + (long)b_k * sg.x_cstride + (ok_n ? tin : 0);
+        xrow = (long)BROWS * sg.x_cstride;
       }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    *reinterpret_cast<float4*>(&As[buf][a_k][a_col]) = ra0;
-    *reinterpret_cast<float4*>(&As[buf][a_k + 8][a_col]) = ra1;
-    if (rvec) {
-      *reinterpret_cast<float4*>(&Bs[buf][v_k][v_col]) = rb0;
-      if (WM == 2) *reinterpret_cast<float4*>(&Bs[buf][v_k + 8][v_col]) = rb1;
-    } else {
-      Bs[buf][b_k + 0 * BROWS][b_n] = rb0.x;  Bs[buf][b_k + 1 * BROWS][b_n] = rb0.y;
-      Bs[buf][b_k + 2 * BROWS][b_n] = rb0.z;  Bs[buf][b_k + 3 * BROWS][b_n] = rb0.w;
-      if (WM == 2) {
-        Bs[buf][b_k + 4 * BROWS][b_n] = rb1.x;  Bs[buf][b_k + 5 * BROWS][b_n] = rb1.y;
-        Bs[buf][b_k + 6 * BROWS][b_n] = rb1.z;  Bs[buf][b_k + 7 * BROWS][b_n] = rb1.w;
-      }
-    }
-  };
-
-  int s = 0, c0 = 0;
-  load_tiles(s, c0);
-  store_tiles(0);
-  __syncthreads();
-
-  for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
-    const bool more = (it + 1) < nk;
-    if (more) {
-      c0 += BK;
-      if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
-      load_tiles(s, c0);
-    }
-    if (BF16) {
-      // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
-      // k-group = lk) supplies k = 8*lk .. 8*lk+7
-      bf16x8 af[2], bf[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
-          bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
+    };
+    auto load_next = [&]() {          // chunk (s_n, c_n) -> ra*, rb*; then step to the following chunk
+      ra0 = *reinterpret_cast<const float4*>(wp);                 // packed slabs are zero padded to 16 rows
+      ra1 = *reinterpret_cast<const float4*>(wp + wrow8);
+      rvec = rvec_n;
+      const bool full = c_n + BK <= cin_n;
+      if (rvec_n) {
+        if (full) {
+          rb0 = *reinterpret_cast<const float4*>(xp);
+          if (WM == 2) rb1 = *reinterpret_cast<const float4*>(xp + xrow);
+        } else {
+          rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+          rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c_n + v_k < cin_n) rb0 = *reinterpret_cast<const float4*>(xp);
+          if (WM == 2 && c_n + v_k + 8 < cin_n) rb1 = *reinterpret_cast<const float4*>(xp + xrow);
         }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-    } else {
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
-      const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
-      const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
-      const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    }
-    if (more) store_tiles(cur ^ 1);
+      } else {
+        const int cb = c_n + b_k;
+        rb0.x = (ok_n && (full || cb + 0 * BROWS < cin_n)) ? xp[0 * xrow] : 0.f;
+        rb0.y = (ok_n && (full || cb + 1 * BROWS < cin_n)) ? xp[1 * xrow] : 0.f;
+        rb0.z = (ok_n && (full || cb + 2 * BROWS < cin_n)) ? xp[2 * xrow] : 0.f;
+        rb0.w = (ok_n && (full || cb + 3 * BROWS < cin_n)) ? xp[3 * xrow] : 0.f;
+        if (WM == 2) {
+          rb1.x = (ok_n && (full || cb + 4 * BROWS < cin_n)) ? xp[4 * xrow] : 0.f;
+          rb1.y = (ok_n && (full || cb + 5 * BROWS < cin_n)) ? xp[5 * xrow] : 0.f;
+          rb1.z = (ok_n && (full || cb + 6 * BROWS < cin_n)) ? xp[6 * xrow] : 0.f;
+          rb1.w = (ok_n && (full || cb + 7 * BROWS < cin_n)) ? xp[7 * xrow] : 0.f;
+        }
+      }
+      c_n += BK;
+      if (c_n >= cin_n) {
+        if (++s_n < a.nseg) seg_setup(s_n);
+      } else {
+        wp += wadv; xp += xadv;
+      }
+    };
+    auto store_tiles = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      *reinterpret_cast<float4*>(&As[buf][a_k][a_col]) = ra0;
+      *reinterpret_cast<float4*>(&As[buf][a_k + 8][a_col]) = ra1;
+      if (rvec) {
+        *reinterpret_cast<float4*>(&Bs[buf][v_k][v_col]) = rb0;
+        if (WM == 2) *reinterpret_cast<float4*>(&Bs[buf][v_k + 8][v_col]) = rb1;
+      } else {
+        Bs[buf][b_k + 0 * BROWS][b_n] = rb0.x;  Bs[buf][b_k + 1 * BROWS][b_n] = rb0.y;
+        Bs[buf][b_k + 2 * BROWS][b_n] = rb0.z;  Bs[buf][b_k + 3 * BROWS][b_n] = rb0.w;
+        if (WM == 2) {
+          Bs[buf][b_k + 4 * BROWS][b_n] = rb1.x;  Bs[buf][b_k + 5 * BROWS][b_n] = rb1.y;
+          Bs[buf][b_k + 6 * BROWS][b_n] = rb1.z;  Bs[buf][b_k + 7 * BROWS][b_n] = rb1.w;
+        }
+      }
+    };
+    // one K step on LDS buffer `cur` (compile-time: every LDS address is base + immediate)
+    auto k_step = [&](auto curc, bool more) {
+      constexpr int cur = decltype(curc)::value;
+      if (more) load_next();
+      if (BF16) {
+        // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
+        // k-group = lk) supplies k = 8*lk .. 8*lk+7
+        bf16x8 af[2], bf[2];
+  #pragma unroll
+        for (int h = 0; h < 2; ++h)
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
+            bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
+          }
+  #pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+  #pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      } else {
+  #pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+          const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
+          const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
+          const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
+          const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+      if (more) store_tiles(std::integral_constant<int, cur ^ 1>{});
+      __syncthreads();
+    };
+
+    seg_setup(0);
+    load_next();
+    store_tiles(std::integral_constant<int, 0>{});
     __syncthreads();
+
+    for (int it = 0; it < nk; it += 2) {
+      k_step(std::integral_constant<int, 0>{}, it + 1 < nk);
+      if (it + 1 < nk) k_step(std::integral_constant<int, 1>{}, it + 2 < nk);
+    }
+
+  } else {
+    // 128-row tiles (4 workgroups per CU): the plain per-step staging measured faster here
+    float4 ra0, ra1;
+    float4 rb0, rb1;
+    bool rvec = false;
+
+    // thread roles for the staging loads (per K step: A = 16 x BM, B = 16 x 128 floats)
+    constexpr int ACOLS4 = BM / 4;                        // float4 per A row
+    const int a_k = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;    // A: rows a_k, a_k + 8
+    const int v_k = tid >> 5, v_col = (tid & 31) * 4;     // vector B: row v_k (+8 when WM == 2)
+    constexpr int BROWS = NT / 128;                        // scalar B: rows b_k + BROWS*i
+    const int b_n = tid & 127, b_k = tid >> 7;
+
+    auto load_tiles = [&](int s, int c0) {
+      const Seg& sg = a.seg[s];
+      const float* wp = sg.w + (long)(c0 + a_k) * sg.ldw + m0 + a_col;
+      ra0 = *reinterpret_cast<const float4*>(wp);
+      ra1 = *reinterpret_cast<const float4*>(wp + 8L * sg.ldw);
+      const float* xb = sg.x + (long)b * sg.x_bstride;
+      const int tw = t0 * sg.tmul + sg.toff;   // window start (when tmul==1,tdiv==1)
+      rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
+      if (rvec) {
+        const int ci0 = c0 + v_k, ci1 = c0 + v_k + 8;
+        rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci0 < sg.cin) rb0 = *reinterpret_cast<const float4*>(xb + (long)ci0 * sg.x_cstride + tw + v_col);
+        if (WM == 2 && ci1 < sg.cin) rb1 = *reinterpret_cast<const float4*>(xb + (long)ci1 * sg.x_cstride + tw + v_col);
+      } else {
+        const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
+        bool ok = tnum >= 0;
+        int tin = tnum;
+        if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+        ok = ok && tin < sg.Tin;
+        const float* xp = xb + (long)(c0 + b_k) * sg.x_cstride + tin;
+        const long csr = (long)BROWS * sg.x_cstride;
+        const int cb = c0 + b_k;
+        rb0.x = (ok && cb + 0 * BROWS < sg.cin) ? xp[0 * csr] : 0.f;
+        rb0.y = (ok && cb + 1 * BROWS < sg.cin) ? xp[1 * csr] : 0.f;
+        rb0.z = (ok && cb + 2 * BROWS < sg.cin) ? xp[2 * csr] : 0.f;
+        rb0.w = (ok && cb + 3 * BROWS < sg.cin) ? xp[3 * csr] : 0.f;
+        if (WM == 2) {
+          rb1.x = (ok && cb + 4 * BROWS < sg.cin) ? xp[4 * csr] : 0.f;
+          rb1.y = (ok && cb + 5 * BROWS < sg.cin) ? xp[5 * csr] : 0.f;
+          rb1.z = (ok && cb + 6 * BROWS < sg.cin) ? xp[6 * csr] : 0.f;
+          rb1.w = (ok && cb + 7 * BROWS < sg.cin) ? xp[7 * csr] : 0.f;
+        }
+      }
+    };
+    auto store_tiles = [&](int buf) {
+      *reinterpret_cast<float4*>(&As[buf][a_k][a_col]) = ra0;
+      *reinterpret_cast<float4*>(&As[buf][a_k + 8][a_col]) = ra1;
+      if (rvec) {
+        *reinterpret_cast<float4*>(&Bs[buf][v_k][v_col]) = rb0;
+        if (WM == 2) *reinterpret_cast<float4*>(&Bs[buf][v_k + 8][v_col]) = rb1;
+      } else {
+        Bs[buf][b_k + 0 * BROWS][b_n] = rb0.x;  Bs[buf][b_k + 1 * BROWS][b_n] = rb0.y;
+        Bs[buf][b_k + 2 * BROWS][b_n] = rb0.z;  Bs[buf][b_k + 3 * BROWS][b_n] = rb0.w;
+        if (WM == 2) {
+          Bs[buf][b_k + 4 * BROWS][b_n] = rb1.x;  Bs[buf][b_k + 5 * BROWS][b_n] = rb1.y;
+          Bs[buf][b_k + 6 * BROWS][b_n] = rb1.z;  Bs[buf][b_k + 7 * BROWS][b_n] = rb1.w;
+        }
+      }
+    };
+
+    int s = 0, c0 = 0;
+    load_tiles(s, c0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = (it + 1) < nk;
+      if (more) {
+        c0 += BK;
+        if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
+        load_tiles(s, c0);
+      }
+      if (BF16) {
+        // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
+        // k-group = lk) supplies k = 8*lk .. 8*lk+7
+        bf16x8 af[2], bf[2];
+  #pragma unroll
+        for (int h = 0; h < 2; ++h)
+  #pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
+            bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
+          }
+  #pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+  #pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      } else {
+  #pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
+        const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
+        const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
+        const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      }
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
+
   }
 
   // ---- epilogue ----------------------------------------------------------
