@@ -381,57 +381,128 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int T = a.Tout;
   if (EPI == EPI_LINEAR) {
-    // All loads of a 32x32 sub-tile (bias, residual, old value) are issued before its
-    // first store, so they overlap instead of serialising behind may-alias stores.
+    // ---- interior tiles: software-pipelined epilogue --------------------------------------------
+    // VMEM operations retire through one in-order counter, so "load sub-tile q+1, then store
+    // sub-tile q" lets the next operands travel while the previous results drain; the plain
+    // load/store/load/store order exposed one load AND one store latency per sub-tile, which is
+    // what bounded the K = 128 projections (315 MB of traffic per launch, 8 GFLOP).
+    bool fast = (t0 + BN <= T);
+    {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int mb = m0 + wm * 64 + mi * 32;
-      // the host guarantees out[0].rows % 32 == 0 when two ranges exist: wave-uniform
-      const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-      const OutR& od = a.out[o];
-      const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
-      const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
-      float bias[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mr = mrb + (r & 3) + 8 * (r >> 2);
-        bias[r] = (od.bias && mr < rows_left) ? od.bias[mr] : 0.f;
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        const int o = (mb < a.out[0].rows) ? 0 : 1;
+        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
+        const int mr0 = o ? mb - a.out[0].rows : mb;
+        fast = fast && (mr0 + 32 <= rows_left) && !(a.out[o].add && a.out[o].accumulate);
       }
+    }
+    if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
+      // bias first, one row group at a time (the registers are needed for the operand pipeline)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int t = t0 + wn * 64 + ni * 32 + li;
-        const bool tok = t < T;
-        float addv[16], oldv[16];
-        const long boff = (long)mrb * T + t;
-        if (od.add) {
-          const float* ap = od.add + (long)b * od.add_bstride + boff;
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+        const OutR& od = a.out[o];
+        if (od.bias) {
+          const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
+          float bias[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bias[r] = od.bias[mrb + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][n2][r] += bias[r];
+        }
+      }
+      float pv[2][16];
+#pragma unroll
+      for (int q = 0; q <= 4; ++q) {
+        if (q < 4) {                 // request the operands of sub-tile q
+          const int mi = q >> 1, ni = q & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned off0 = (unsigned)(((o ? mb - a.out[0].rows : mb) + 4 * lk) * T + t0 + wn * 64 + ni * 32 + li);
+          const float* src = od.add ? od.add + (long)b * od.add_bstride
+                                    : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
+          if (src) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[q & 1][r] = src[off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * T)];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
+          }
+        }
+        if (q > 0) {                 // finish sub-tile q - 1
+          const int p = q - 1, mi = p >> 1, ni = p & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned off0 = (unsigned)(((o ? mb - a.out[0].rows : mb) + 4 * lk) * T + t0 + wn * 64 + ni * 32 + li);
+          float* yp = od.y + (long)b * od.y_bstride;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            addv[r] = (tok && mrb + dr < rows_left) ? ap[(long)dr * T] : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) addv[r] = 0.f;
-        }
-        float* yp = od.y + (long)b * od.y_bstride + boff;
-        if (od.accumulate) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            oldv[r] = (tok && mrb + dr < rows_left) ? yp[(long)dr * T] : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          if (tok && mrb + dr < rows_left) {
-            float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
+            float v = acc[mi][ni][r] + pv[p & 1][r];
             if (od.relu) v = fmaxf(v, 0.f);
-            yp[(long)dr * T] = v;
+            yp[off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * T)] = v;
+          }
+        }
+      }
+    } else {
+    // ---- edge tiles: fully predicated ---------------------------------------------------------
+      // All loads of a 32x32 sub-tile (bias, residual, old value) are issued before its
+      // first store, so they overlap instead of serialising behind may-alias stores.
+  #pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        // the host guarantees out[0].rows % 32 == 0 when two ranges exist: wave-uniform
+        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+        const OutR& od = a.out[o];
+        const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
+        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
+        float bias[16];
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mr = mrb + (r & 3) + 8 * (r >> 2);
+          bias[r] = (od.bias && mr < rows_left) ? od.bias[mr] : 0.f;
+        }
+  #pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          const bool tok = t < T;
+          float addv[16], oldv[16];
+          const long boff = (long)mrb * T + t;
+          if (od.add) {
+            const float* ap = od.add + (long)b * od.add_bstride + boff;
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              addv[r] = (tok && mrb + dr < rows_left) ? ap[(long)dr * T] : 0.f;
+            }
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) addv[r] = 0.f;
+          }
+          float* yp = od.y + (long)b * od.y_bstride + boff;
+          if (od.accumulate) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              oldv[r] = (tok && mrb + dr < rows_left) ? yp[(long)dr * T] : 0.f;
+            }
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
+          }
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (tok && mrb + dr < rows_left) {
+              float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
+              if (od.relu) v = fmaxf(v, 0.f);
+              yp[(long)dr * T] = v;
+            }
           }
         }
       }
@@ -443,6 +514,20 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
     const int g = (m0 + wm * 64) >> 6;
     const OutR& og = a.out[0];   // gates (B, 2Ch, T)
     const OutR& oz = a.out[1];   // z (B, Ch, T)
+    // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
+    // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
+    // (a load behind a may-alias store would wait for the store's acknowledgement: one in-order counter).
+    int tt[2], vv[2];
+    float w0v[2], w1v[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      tt[ni] = t0 + wn * 64 + ni * 32 + li;
+      const bool tok = tt[ni] < T;
+      vv[ni] = (tok && a.lerp.P) ? a.lerp.v0[tt[ni]] : 0;
+      w0v[ni] = (tok && a.lerp.P) ? a.lerp.w0[tt[ni]] : 0.f;
+      w1v[ni] = (tok && a.lerp.P) ? a.lerp.w1[tt[ni]] : 0.f;
+    }
+    const float* Pb = a.lerp.P ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -452,23 +537,33 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       if (og.bias2) { ba += og.bias2[ch]; bb += og.bias2[Ch + ch]; }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int t = t0 + wn * 64 + ni * 32 + li;
-        if (t >= T) continue;
         float pa = 0.f, pb = 0.f;
-        if (a.lerp.P) {      // h += upsample(P)[t]: condition projected at latent rate
-          const int v = a.lerp.v0[t];
-          const float w0 = a.lerp.w0[t], w1 = a.lerp.w1[t];
-          const float* pp = a.lerp.P + (long)b * a.lerp.p_bstride + (long)ch * a.lerp.Tl + v;
-          const float* pq = pp + (long)Ch * a.lerp.Tl;
-          pa = w0 * pp[0] + w1 * pp[1];
-          pb = w0 * pq[0] + w1 * pq[1];
+        if (Pb) {      // h += upsample(P)[t]: condition projected at latent rate
+          const unsigned o1 = (unsigned)(ch * a.lerp.Tl + vv[ni]);
+          const unsigned o2 = o1 + (unsigned)(Ch * a.lerp.Tl);
+          pa = w0v[ni] * Pb[o1] + w1v[ni] * Pb[o1 + 1];
+          pb = w0v[ni] * Pb[o2] + w1v[ni] * Pb[o2 + 1];
         }
-        const float ta = fast_tanhf_(acc[0][ni][r] + ba + pa);
-        const float sb = sigmoidf_(acc[1][ni][r] + bb + pb);
-        float* gp = og.y + (long)b * og.y_bstride;
-        gp[(long)ch * T + t] = ta;
-        gp[(long)(Ch + ch) * T + t] = sb;
-        oz.y[(long)b * oz.y_bstride + (long)ch * T + t] = ta * sb;
+        acc[0][ni][r] = (acc[0][ni][r] + ba) + pa;
+        acc[1][ni][r] = (acc[1][ni][r] + bb) + pb;
+      }
+    }
+    // Phase 2 -- gate and the three stores per element
+    float* gp = og.y + (long)b * og.y_bstride;
+    float* zp = oz.y + (long)b * oz.y_bstride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (ch >= Ch) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (tt[ni] >= T) continue;
+        const float ta = fast_tanhf_(acc[0][ni][r]);
+        const float sb = sigmoidf_(acc[1][ni][r]);
+        const unsigned o1 = (unsigned)(ch * T + tt[ni]);
+        gp[o1] = ta;
+        gp[o1 + (unsigned)(Ch * T)] = sb;
+        zp[o1] = ta * sb;
       }
     }
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)

@@ -25,3 +25,10 @@ for r in rows:
 for k, v in sorted(h.items(), key=lambda kv: -sum(kv[1])):
     print(k, 'n/step %.1f' % (len(v) / 13), 'avg %.1f us' % (sum(v) / len(v)), 'ms/step %.2f' % (sum(v) / 13 / 1e3))
 PY
+python - "$t" <<'PY'
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'conv_gemm_kernel<0, 4' in r['Kernel_Name']]
+d = sorted((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows)
+h = collections.Counter(int(x // 20) * 20 for x in d)
+print('conv_gemm<0,4> duration histogram (us bucket: launches/step):', {k: round(v / 13, 1) for k, v in sorted(h.items())})
+PY
