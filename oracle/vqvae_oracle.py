@@ -25,7 +25,9 @@ Parity pin status
   golden vectors for it.  These functions restate Chainer's published
   algorithms ("[chainer-recalled]" in SURVEY.md) and are checked by analytic
   known-answer tests and fp64 finite-difference gradient checks
-  (tests/test_oracle.py): **parity unpinned** for these parts.
+  (tests/test_oracle.py) and cross-checked against PyTorch-CPU's implementations of
+  the same operators (tests/test_oracle_torch.py): **parity unpinned** for these
+  parts -- no vector produced by Chainer itself exists to pin them on.
 
 All functions are dtype-generic (float32 for parity, float64 for gradient
 checks).  Internal layout is (B, C, T); the Chainer boundary layout (B, C, T, 1)
