@@ -89,6 +89,20 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return x >= 0.f ? r : 1.f - r;
 }
 
+// Buffer-resource addressing for the epilogues: base in four SGPRs, one 32-bit VGPR byte offset per
+// lane and a wave-uniform SGPR offset per row -- no per-element 64-bit address arithmetic on the VALU
+// (flat global_load/store cost a v_lshl_add_u64 and friends per access, ~40 % of the epilogue VALU).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+
 // WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
 // halves the activation-tile loads per FLOP and is used whenever M >= 256.
 template <int EPI, int WM, bool BF16>
@@ -423,12 +437,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
           const int mb = m0 + wm * 64 + mi * 32;
           const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
           const OutR& od = a.out[o];
-          const unsigned off0 = (unsigned)(((o ? mb - a.out[0].rows : mb) + 4 * lk) * T + t0 + wn * 64 + ni * 32 + li);
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
           const float* src = od.add ? od.add + (long)b * od.add_bstride
                                     : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
           if (src) {
+            const rsrc_t rs = make_rsrc(src);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q & 1][r] = src[off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * T)];
+            for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
@@ -439,13 +455,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
           const int mb = m0 + wm * 64 + mi * 32;
           const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
           const OutR& od = a.out[o];
-          const unsigned off0 = (unsigned)(((o ? mb - a.out[0].rows : mb) + 4 * lk) * T + t0 + wn * 64 + ni * 32 + li);
-          float* yp = od.y + (long)b * od.y_bstride;
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+          const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float v = acc[mi][ni][r] + pv[p & 1][r];
             if (od.relu) v = fmaxf(v, 0.f);
-            yp[off0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * T)] = v;
+            buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
           }
         }
       }
@@ -528,42 +545,52 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       w1v[ni] = (tok && a.lerp.P) ? a.lerp.w1[tt[ni]] : 0.f;
     }
     const float* Pb = a.lerp.P ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;
+    const rsrc_t rP = make_rsrc(Pb);
+    const int chl = 32 * g + 4 * lk;            // this lane's first channel; row r adds (r&3) + 8*(r>>2)
+    unsigned vP[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) vP[ni] = 4u * (unsigned)(chl * a.lerp.Tl + vv[ni]);
+    const unsigned sPq = 4u * (unsigned)(Ch * a.lerp.Tl);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ch = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int dr = (r & 3) + 8 * (r >> 2);
+      const int ch = chl + dr;
       if (ch >= Ch) continue;
       float ba = 0.f, bb = 0.f;
       if (og.bias) { ba += og.bias[ch]; bb += og.bias[Ch + ch]; }
       if (og.bias2) { ba += og.bias2[ch]; bb += og.bias2[Ch + ch]; }
+      const unsigned sP = 4u * (unsigned)(dr * a.lerp.Tl);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         float pa = 0.f, pb = 0.f;
         if (Pb) {      // h += upsample(P)[t]: condition projected at latent rate
-          const unsigned o1 = (unsigned)(ch * a.lerp.Tl + vv[ni]);
-          const unsigned o2 = o1 + (unsigned)(Ch * a.lerp.Tl);
-          pa = w0v[ni] * Pb[o1] + w1v[ni] * Pb[o1 + 1];
-          pb = w0v[ni] * Pb[o2] + w1v[ni] * Pb[o2 + 1];
+          pa = w0v[ni] * buf_ld(rP, vP[ni], sP) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP);
+          pb = w0v[ni] * buf_ld(rP, vP[ni], sP + sPq) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP + sPq);
         }
         acc[0][ni][r] = (acc[0][ni][r] + ba) + pa;
         acc[1][ni][r] = (acc[1][ni][r] + bb) + pb;
       }
     }
     // Phase 2 -- gate and the three stores per element
-    float* gp = og.y + (long)b * og.y_bstride;
-    float* zp = oz.y + (long)b * oz.y_bstride;
+    const rsrc_t rG = make_rsrc(og.y + (long)b * og.y_bstride);
+    const rsrc_t rZ = make_rsrc(oz.y + (long)b * oz.y_bstride);
+    unsigned vT[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) vT[ni] = 4u * (unsigned)(chl * T + tt[ni]);
+    const unsigned sGq = 4u * (unsigned)(Ch * T);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ch = 32 * g + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (ch >= Ch) continue;
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (chl + dr >= Ch) continue;
+      const unsigned sT = 4u * (unsigned)(dr * T);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         if (tt[ni] >= T) continue;
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
-        const unsigned o1 = (unsigned)(ch * T + tt[ni]);
-        gp[o1] = ta;
-        gp[o1 + (unsigned)(Ch * T)] = sb;
-        zp[o1] = ta * sb;
+        buf_st(ta, rG, vT[ni], sT);
+        buf_st(sb, rG, vT[ni], sT + sGq);
+        buf_st(ta * sb, rZ, vT[ni], sT);
       }
     }
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
