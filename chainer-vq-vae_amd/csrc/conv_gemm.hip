@@ -28,6 +28,7 @@ namespace vq {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
 // 0: fp32 operands on v_mfma_f32_32x32x2_f32 (default); 1: operands rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) when they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
@@ -666,6 +667,7 @@ __global__ void pack_kernel(const PackArgs pa) {
 // bwd-weight: gW[co, (seg,ci)] = sum_{b,t} gy[b,co,t] * x_seg[b,ci,tin(t)]
 // ---------------------------------------------------------------------------
 constexpr int WBK = 32, WP = WBK + 1;
+constexpr int WPB = 40;     // bf16 image of the wgrad tiles: 32 k + 8 pad = 80 B per row
 
 struct WSeg {
   const float* x; long x_bstride; int x_cstride; int cin; int Tin;
@@ -783,6 +785,37 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   if (tbeg < tend) load(tbeg);
   for (int tb = tbeg; tb < tend; tb += WBK) {
     __syncthreads();
+    if (BF16) {
+      // bf16 image, k contiguous: row pitch WPB elements (80 B, 16-byte aligned rows, conflict-optimal
+      // for the 16-byte fragment reads); operands are rounded (RNE) once, here, instead of per fragment
+      __bf16* Ab = reinterpret_cast<__bf16*>(&As[0][0]);
+      __bf16* Bb = reinterpret_cast<__bf16*>(&Bs[0][0]);
+      if (avec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bf16x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (__bf16)ra[4 * i + j];
+          *reinterpret_cast<bf16x4*>(Ab + (v_row + 32 * i) * WPB + v_c4) = v;
+          bsum[i] += (ra[4 * i] + ra[4 * i + 1]) + (ra[4 * i + 2] + ra[4 * i + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { Ab[(l_r + 8 * i) * WPB + l_k] = (__bf16)ra[i]; bsum[i] += ra[i]; }
+      }
+      if (bvec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bf16x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (__bf16)rbv[4 * i + j];
+          *reinterpret_cast<bf16x4*>(Bb + (v_row + 32 * i) * WPB + v_c4) = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Bb[(l_r + 8 * i) * WPB + l_k] = (__bf16)rbv[i];
+      }
+    } else {
     if (avec) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -803,19 +836,20 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) Bs[l_r + 8 * i][l_k] = rbv[i];
     }
+    }
     __syncthreads();
     if (tb + WBK < tend) load(tb + WBK);
     if (BF16) {
 #pragma unroll
       for (int k16 = 0; k16 < WBK / 16; ++k16) {
+        const __bf16* Ab = reinterpret_cast<const __bf16*>(&As[0][0]);
+        const __bf16* Bb = reinterpret_cast<const __bf16*>(&Bs[0][0]);
         bf16x8 af[2], bf[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            af[h][j] = (__bf16)As[wm * 64 + h * 32 + li][k16 * 16 + 8 * lk + j];
-            bf[h][j] = (__bf16)Bs[wn * 64 + h * 32 + li][k16 * 16 + 8 * lk + j];
-          }
+        for (int h = 0; h < 2; ++h) {        // one 16-byte LDS read per fragment
+          af[h] = *reinterpret_cast<const bf16x8*>(Ab + (wm * 64 + h * 32 + li) * WPB + k16 * 16 + 8 * lk);
+          bf[h] = *reinterpret_cast<const bf16x8*>(Bb + (wn * 64 + h * 32 + li) * WPB + k16 * 16 + 8 * lk);
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
