@@ -64,6 +64,17 @@ def side_stream():
     return _state['side']
 
 
+def pool_stream(i):
+    """i-th stream of a small pool for independent concurrent launches (batched generation)."""
+    pool = _state.setdefault('pool_streams', [])
+    while len(pool) <= i:
+        stream()
+        s = C.c_void_p()
+        _lib.call('vqvae_stream_create', C.byref(s))
+        pool.append(s)
+    return pool[i]
+
+
 def overlap_enabled():
     return _state['overlap']
 
@@ -109,6 +120,8 @@ def synchronize():
     _lib.call('vqvae_stream_synchronize', stream())
     if _state['side'] is not None:
         _lib.call('vqvae_stream_synchronize', _state['side'])
+    for s in _state.get('pool_streams', []):
+        _lib.call('vqvae_stream_synchronize', s)
 
 
 def device_info():

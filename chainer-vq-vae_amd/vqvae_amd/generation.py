@@ -168,3 +168,55 @@ class GenerationState(object):
                 _lib.call('vqvae_graph_destroy', graph)
         d.max_steps = _INT_MAX
         return (out, logits_out) if return_logits else out
+
+
+def run_many(wavenet, condition, uniforms, mode, n_steps=None, group=_lib.GEN_MAX_N, max_streams=8,
+             chunk=4096):
+    """Batched serving form of the loop: N sequences = ceil(N / group) independent persistent
+    launches of <= ``group`` lockstep sequences each, spread over ``max_streams`` HIP streams so
+    they run concurrently (a launch occupies 128 two-wave workgroups: a fraction of the GPU).
+    condition (N, condition_dim, T) on the device, uniforms (T, N[, nr_mix]) on the host.
+    Returns the host array (N, T) of sampled bins / values."""
+    if condition.ndim == 4:
+        condition = condition.reshape(condition.shape[:3])
+    N, Cc, T = condition.shape
+    steps = T - 1 if n_steps is None else int(n_steps)
+    softmax = mode == _lib.GEN_SOFTMAX
+    u = np.asarray(uniforms, np.float64)
+    u = u.reshape(u.shape[0], N, -1)
+    lib = _lib.load()
+    jobs = []
+    for g0 in range(0, N, group):
+        n = min(group, N - g0)
+        st = GenerationState(wavenet, n)
+        d = st.desc
+        n_uniform = 1 if softmax else st.out_dim // 3
+        if u.shape[0] < steps or u.shape[2] < n_uniform:
+            raise ValueError('generate_batch: need (steps, N, %d) uniform doubles, got %s' % (n_uniform, u.shape))
+        u_dev = backend.to_device(np.ascontiguousarray(u[:max(steps, 1), g0:g0 + n, :n_uniform]).reshape(-1))
+        out = backend.zeros((n, T), np.int32 if softmax else np.float32)
+        cview = condition.flat_view(g0 * Cc * T, n * Cc * T, (n, Cc, T))
+        d.sample_mode = mode
+        d.cond, d.cond_bstride, d.cond_cstride, d.cond_follows_step = cview.ptr, Cc * T, T, 1
+        d.uniforms, d.n_uniform = u_dev.ptr, n_uniform
+        d.forced_next = d.logits_out = None
+        d.out, d.out_bstride = out.ptr, T
+        d.max_steps = steps
+        nbytes = lib.vqvae_wavenet_gen_run_workspace_bytes(C.byref(d))
+        if not nbytes:
+            raise ValueError('persistent generation: ' + lib.vqvae_last_error_string().decode())
+        ws = DeviceArray((nbytes // 4 + 1,), np.int32)
+        jobs.append((st, d, out, ws, u_dev, cview))
+    backend.synchronize()                  # buffers above were prepared on the main stream
+    for t0 in range(0, steps, chunk):
+        for i, (st, d, out, ws, _, _) in enumerate(jobs):
+            _lib.call('vqvae_wavenet_gen_run', C.byref(d), t0, min(chunk, steps - t0), ws.ptr, ws.nbytes,
+                      backend.pool_stream(i % max_streams))
+    backend.synchronize()
+    res = []
+    for st, d, out, ws, _, _ in jobs:
+        status = int(ws.flat_view(0, 1).get()[0])
+        if status:
+            raise RuntimeError('persistent generation kernel gave up waiting (status %d)' % status)
+        res.append(out.get())
+    return np.concatenate(res, axis=0)

@@ -467,3 +467,15 @@ class WaveNet(Chain):
         mode = _lib.GEN_MOL if self.use_logistic else _lib.GEN_SOFTMAX
         return self._gen_state().run(cd, uniforms, mode, n_steps, forced, return_logits, graph_steps,
                                      persistent)
+
+    def generate_batch(self, condition, uniforms, n_steps=None, group=4, max_streams=8):
+        """Serving form: N sequences generated as concurrent groups of <= ``group`` lockstep sequences,
+        one persistent launch per group on its own stream.  condition (N, condition_dim, T[, 1]) on the
+        device, uniforms (T, N[, nr_mix]) host doubles; returns the host array (N, T).  Every sequence
+        gets exactly the samples generate_sequence would give it alone with its column of uniforms."""
+        from .core import Variable
+        from .generation import run_many
+        cd = condition.data if isinstance(condition, Variable) else condition
+        backend.require_device(cd)
+        mode = _lib.GEN_MOL if self.use_logistic else _lib.GEN_SOFTMAX
+        return run_many(self, cd, uniforms, mode, n_steps, group, max_streams)

@@ -215,3 +215,17 @@ def test_synthesize_matches_oracle_pipeline(gpu):
     np.testing.assert_array_equal(out, want_out)
     np.testing.assert_allclose(wave, want_wave, rtol=0, atol=1e-7)
     assert wave.dtype == want_wave.dtype
+
+
+def test_generate_batch_equals_individual_sequences(gpu):
+    """Concurrent groups on separate streams: each of the 7 sequences gets exactly what it gets alone."""
+    cfg = dict(H.SMALL)
+    p, dec = _decoder(cfg, 41)
+    N, T = 7, 40
+    cond = _cond(cfg, N, T, 17)
+    u = np.random.RandomState(18).random_sample((T, N))
+    got = dec.generate_batch(gpu.to_device(cond), u, group=3, max_streams=2)
+    assert got.shape == (N, T)
+    for i in range(N):
+        alone = dec.generate_sequence(gpu.to_device(cond[i:i + 1]), u[:, i:i + 1]).get()
+        np.testing.assert_array_equal(got[i:i + 1], alone)

@@ -17,6 +17,9 @@ def main():
     ap.add_argument('--n', type=int, default=1)
     ap.add_argument('--steps', type=int, default=16000)
     ap.add_argument('--graph-steps', type=int, default=8)
+    ap.add_argument('--group', type=int, default=4)
+    ap.add_argument('--streams', type=int, default=8)
+    ap.add_argument('--batch', type=int, default=0, help='N sequences through generate_batch (concurrent groups of 4)')
     ap.add_argument('--per-step-kernels', action='store_true', help='hipGraph of per-step kernels instead of the persistent kernel')
     a = ap.parse_args()
     from vqvae_amd import backend
@@ -33,6 +36,17 @@ def main():
     dec.to_gpu()
     dec(Variable(x), Variable(c))
     T = a.steps + 1
+    if a.batch:
+        rs = np.random.RandomState(0)
+        cond = backend.to_device(rs.standard_normal((a.batch, 192, T)).astype(np.float32))
+        u = rs.uniform(0.01, 0.99, (T, a.batch, 10 if mol else 1))
+        dec.generate_batch(cond, u, n_steps=64, group=a.group, max_streams=a.streams)
+        t0 = time.time()
+        o = dec.generate_batch(cond, u, group=a.group, max_streams=a.streams)
+        dt = time.time() - t0
+        print('group %d streams %d: ' % (a.group, a.streams) + 'batch of %d sequences x %d steps in %.3f s = %.0f samples/s aggregate (%.1f sequences in real time at 16 kHz)'
+              % (a.batch, a.steps, dt, a.batch * a.steps / dt, a.batch * a.steps / dt / 16000))
+        return
     rs = np.random.RandomState(0)
     cond = backend.to_device(rs.standard_normal((a.n, 192, T)).astype(np.float32))
     u = rs.uniform(0.01, 0.99, (T, a.n, 10 if mol else 1))
