@@ -597,8 +597,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
     const int Ch = a.M;
     const OutR& od = a.out[0];
-    const float* gates_b = od.add + (long)b * od.add_bstride;
-    float* gh_b = od.y + (long)b * od.y_bstride;
+    const rsrc_t rGt = make_rsrc(od.add + (long)b * od.add_bstride);
+    const rsrc_t rGh = make_rsrc(od.y + (long)b * od.y_bstride);
+    const unsigned sQ = 4u * (unsigned)(Ch * T);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -606,22 +607,25 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
         const int t = t0 + wn * 64 + ni * 32 + li;
         const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
         const bool tok = t < T;
+        const unsigned voff = 4u * (unsigned)(mb * T + t);
         // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
         float ta[16], sb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          const bool ok = tok && m < Ch;
-          ta[r] = ok ? gates_b[(long)m * T + t] : 0.f;
-          sb[r] = ok ? gates_b[(long)(Ch + m) * T + t] : 0.f;
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = tok && mb + dr < Ch;
+          const unsigned so = 4u * (unsigned)(dr * T);
+          ta[r] = ok ? buf_ld(rGt, voff, so) : 0.f;
+          sb[r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (tok && m < Ch) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (tok && mb + dr < Ch) {
             const float gz = acc[mi][ni][r];
-            gh_b[(long)m * T + t] = gz * sb[r] * (1.f - ta[r] * ta[r]);
-            gh_b[(long)(Ch + m) * T + t] = gz * ta[r] * sb[r] * (1.f - sb[r]);
+            const unsigned so = 4u * (unsigned)(dr * T);
+            buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
+            buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
           }
         }
       }
