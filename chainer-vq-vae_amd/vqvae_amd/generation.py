@@ -130,12 +130,13 @@ class GenerationState(object):
         if int(self.step.get()[0]) != 0:
             raise RuntimeError('generate_sequence starts from fresh queues: call initialize(n) first')
         d.max_steps = steps
+        nbytes = 0
         if steps and persistent:
+            # shapes outside the persistent kernel's limits (> 256 channels per vector) run on the
+            # per-step kernels below -- same results, more launches
+            nbytes = _lib.load().vqvae_wavenet_gen_run_workspace_bytes(C.byref(d))
+        if steps and persistent and nbytes:
             # one persistent launch per `chunk` steps; queues + mailboxes live in its workspace
-            lib = _lib.load()
-            nbytes = lib.vqvae_wavenet_gen_run_workspace_bytes(C.byref(d))
-            if not nbytes:
-                raise ValueError('persistent generation: ' + lib.vqvae_last_error_string().decode())
             ws = DeviceArray((nbytes // 4 + 1,), np.int32)
             for t0 in range(0, steps, chunk):
                 _lib.call('vqvae_wavenet_gen_run', C.byref(d), t0, min(chunk, steps - t0), ws.ptr,

@@ -229,3 +229,18 @@ def test_generate_batch_equals_individual_sequences(gpu):
     for i in range(N):
         alone = dec.generate_sequence(gpu.to_device(cond[i:i + 1]), u[:, i:i + 1]).get()
         np.testing.assert_array_equal(got[i:i + 1], alone)
+
+
+def test_wide_model_runs_on_the_per_step_kernels(gpu):
+    """More than 256 residual channels exceed the persistent kernel's per-vector limit: the same call
+    silently uses the per-step kernels and still matches the oracle."""
+    cfg = dict(H.SMALL, residual=320, skip=288)
+    p, dec = _decoder(cfg, 51)
+    T = 24
+    cond = _cond(cfg, 1, T, 19)
+    rs = np.random.RandomState(20)
+    forced = rs.randint(0, cfg['input_dim'], (T, 1)).astype(np.int32)
+    u = rs.random_sample((T, 1))
+    want_out, want_logits = O.wavenet_generate(p, cond, u, cfg['n_loop'], cfg['n_layer'], forced=forced)
+    out, logits = dec.generate_sequence(gpu.to_device(cond), u, forced=forced, return_logits=True)
+    assert_close(logits.get(), want_logits, 1e-4, 'wide model logits')
