@@ -29,6 +29,7 @@ namespace vq {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
 // 0: fp32 operands on v_mfma_f32_32x32x2_f32 (default); 1: operands rounded to bf16 (RNE,
 // v_cvt_pk_bf16_f32) when they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
@@ -90,6 +91,12 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return x >= 0.f ? r : 1.f - r;
 }
 
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // RNE, v_cvt_pk_bf16_f32
+  bf16x2 v;
+  v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
 // Buffer-resource addressing for the epilogues: base in four SGPRs, one 32-bit VGPR byte offset per
 // lane and a wave-uniform SGPR offset per row -- no per-element 64-bit address arithmetic on the VALU
 // (flat global_load/store cost a v_lshl_add_u64 and friends per access, ~40 % of the epilogue VALU).
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   int nk = 0;
   for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
 
-  if constexpr (WM == 4) {
+  if constexpr (WM == 4 && !BF16) {
     float4 ra0, ra1;
     float4 rb0, rb1;
     bool rvec = false;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       if (it + 1 < nk) k_step(std::integral_constant<int, 1>{}, it + 2 < nk);
     }
 
-  } else {
+  } else if constexpr (!BF16) {
     // 128-row tiles (4 workgroups per CU): the plain per-step staging measured faster here
     float4 ra0, ra1;
     float4 rb0, rb1;
@@ -390,6 +397,94 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       __syncthreads();
     }
 
+  } else {
+    // bf16 operands (configs[4] precision): both LDS images hold 32-bit words = (k even, k odd) pairs,
+    // rounded (RNE) once at staging; a fragment (8 consecutive k) is four ds_read_b32 and the K step is
+    // one 32x32x16 MFMA per sub-tile.  The weight slabs arrive pair-packed from pack_kernel.
+    unsigned (*Ap)[8][BM] = reinterpret_cast<unsigned (*)[8][BM]>(&As[0][0][0]);
+    unsigned (*Bp)[8][BN] = reinterpret_cast<unsigned (*)[8][BN]>(&Bs[0][0][0]);
+    constexpr int ACOLS4 = BM / 4;
+    const int a_kp = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;       // A: pair-row a_kp (NT / ACOLS4 == 8)
+    const int p_k = tid >> 5, v_col = (tid & 31) * 4;                 // vector B: pair-row p_k, threads < 256
+    constexpr int BROWS = NT / 128, PR = 8 / BROWS;                   // scalar B: pair-rows b_k + BROWS*i
+    const int b_n = tid & 127, b_k = tid >> 7;
+    uint4 ra;
+    float4 rbe, rbo;          // vector path: channels 2*p_k (even) and 2*p_k + 1 (odd)
+    float rbs[2 * PR];        // scalar path
+    bool rvec = false;
+
+    auto load_tiles = [&](int s, int c0) {
+      const Seg& sg = a.seg[s];
+      ra = *reinterpret_cast<const uint4*>(sg.w + (long)(c0 / 2 + a_kp) * sg.ldw + m0 + a_col);
+      const float* xb = sg.x + (long)b * sg.x_bstride;
+      const int tw = t0 * sg.tmul + sg.toff;
+      rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
+      if (rvec) {
+        rbe = make_float4(0.f, 0.f, 0.f, 0.f);
+        rbo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 256) {
+          const int ce = c0 + 2 * p_k;
+          if (ce < sg.cin) rbe = *reinterpret_cast<const float4*>(xb + (long)ce * sg.x_cstride + tw + v_col);
+          if (ce + 1 < sg.cin) rbo = *reinterpret_cast<const float4*>(xb + (long)(ce + 1) * sg.x_cstride + tw + v_col);
+        }
+      } else {
+        const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
+        bool ok = tnum >= 0;
+        int tin = tnum;
+        if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+        ok = ok && tin < sg.Tin;
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+          const int ce = c0 + 2 * (b_k + BROWS * i);
+          rbs[2 * i] = (ok && ce < sg.cin) ? xb[(long)ce * sg.x_cstride + tin] : 0.f;
+          rbs[2 * i + 1] = (ok && ce + 1 < sg.cin) ? xb[(long)(ce + 1) * sg.x_cstride + tin] : 0.f;
+        }
+      }
+    };
+    auto store_tiles = [&](int buf) {
+      *reinterpret_cast<uint4*>(&Ap[buf][a_kp][a_col]) = ra;
+      if (rvec) {
+        if (tid < 256) {
+          uint4 w;
+          w.x = pack_bf16x2(rbe.x, rbo.x); w.y = pack_bf16x2(rbe.y, rbo.y);
+          w.z = pack_bf16x2(rbe.z, rbo.z); w.w = pack_bf16x2(rbe.w, rbo.w);
+          *reinterpret_cast<uint4*>(&Bp[buf][p_k][v_col]) = w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PR; ++i) Bp[buf][b_k + BROWS * i][b_n] = pack_bf16x2(rbs[2 * i], rbs[2 * i + 1]);
+      }
+    };
+
+    int s = 0, c0 = 0;
+    load_tiles(s, c0);
+    store_tiles(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = (it + 1) < nk;
+      if (more) {
+        c0 += BK;
+        if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
+        load_tiles(s, c0);
+      }
+      uint4 af[2], bf[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        af[h].x = Ap[cur][4 * lk + 0][wm * 64 + h * 32 + li]; af[h].y = Ap[cur][4 * lk + 1][wm * 64 + h * 32 + li];
+        af[h].z = Ap[cur][4 * lk + 2][wm * 64 + h * 32 + li]; af[h].w = Ap[cur][4 * lk + 3][wm * 64 + h * 32 + li];
+        bf[h].x = Bp[cur][4 * lk + 0][wn * 64 + h * 32 + li]; bf[h].y = Bp[cur][4 * lk + 1][wn * 64 + h * 32 + li];
+        bf[h].z = Bp[cur][4 * lk + 2][wn * 64 + h * 32 + li]; bf[h].w = Bp[cur][4 * lk + 3][wn * 64 + h * 32 + li];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]),
+                                                                acc[mi][ni], 0, 0, 0);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------
@@ -644,26 +739,37 @@ struct PackJob {
   int Rpad, ldw, m_off;
   int mspan;             // columns of dst this job owns (multiple of 4, zero filled)
 };
-struct PackArgs { PackJob job[MAXSEG]; int njob; };
+struct PackArgs { PackJob job[MAXSEG]; int njob; int bf16; };
 
 __global__ void pack_kernel(const PackArgs pa) {
   const PackJob& j = pa.job[blockIdx.y];
-  const long total = (long)j.K * j.Rpad * j.mspan;
+  // bf16 mode: one 32-bit word holds the pair (k even, k odd); pair-row k/2 sits at row k/2 of the same
+  // slab (the slab keeps its fp32 size and offsets, only its first half is used)
+  const int rows = pa.bf16 ? j.Rpad / 2 : j.Rpad;
+  const long total = (long)j.K * rows * j.mspan;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int mp = (int)(i % j.mspan);
     const long rest = i / j.mspan;
-    const int k = (int)(rest % j.Rpad);
-    const int tap = (int)(rest / j.Rpad);
+    const int kr = (int)(rest % rows);
+    const int tap = (int)(rest / rows);
     int m = mp;
     if (j.gate_half) {
       const int g = mp >> 6, r = mp & 63;
       m = (r < 32) ? (32 * g + r) : (j.gate_half + 32 * g + (r - 32));
       if (32 * g + (r & 31) >= j.gate_half) m = j.Cm;   // beyond the real channels
     }
-    float v = 0.f;
-    if (k < j.R && m < j.Cm) v = j.src[(long)k * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap];
-    j.dst[((long)tap * j.Rpad + k) * j.ldw + j.m_off + mp] = v;
+    float* d = j.dst + ((long)tap * j.Rpad + kr) * j.ldw + j.m_off + mp;
+    if (pa.bf16) {
+      const int k0 = 2 * kr, k1 = 2 * kr + 1;
+      const float v0 = (k0 < j.R && m < j.Cm) ? j.src[(long)k0 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
+      const float v1 = (k1 < j.R && m < j.Cm) ? j.src[(long)k1 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
+      *reinterpret_cast<unsigned*>(d) = pack_bf16x2(v0, v1);
+    } else {
+      float v = 0.f;
+      if (kr < j.R && m < j.Cm) v = j.src[(long)kr * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap];
+      *d = v;
+    }
   }
 }
 
@@ -1021,6 +1127,7 @@ static int launch_pack(PackArgs& pa, hipStream_t st) {
   int nb = (int)((mx + 255) / 256);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
+  pa.bf16 = g_matmul_dtype == 1 ? 1 : 0;
   hipLaunchKernelGGL(pack_kernel, dim3(nb, pa.njob), dim3(256), 0, st, pa);
   VQ_LAUNCH_CHECK();
   return 0;
