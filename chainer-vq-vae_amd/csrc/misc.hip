@@ -219,26 +219,45 @@ __global__ void embed_scatter_kernel(const float* __restrict__ rs, const int32_t
 }
 
 // ---- softmax cross entropy -------------------------------------------------
-// thread per (b,t); channel stride T keeps every load coalesced along t.
+// 64 positions (b,t) x 4 class groups per workgroup: lanes run along t (every load coalesced, channel
+// stride T), the four waves split the class axis and combine max / sum-exp through LDS -- four times
+// the parallelism of one thread per position for the 2 x q dependent strided loads.
 __global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ y,
                                                        const int32_t* __restrict__ tg, int B, int q,
                                                        int T, float* __restrict__ lse,
                                                        float* __restrict__ partial) {
   __shared__ float sh[4];
+  __shared__ float red[4][64];
   const long N = (long)B * T;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c0 = (int)(((long)q * grp) / 4), c1 = (int)(((long)q * (grp + 1)) / 4);
   float lacc = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N;
-       i += (long)gridDim.x * blockDim.x) {
-    const long b = i / T;
-    const int t = (int)(i % T);
+  for (long base = (long)blockIdx.x * 64; base < N; base += (long)gridDim.x * 64) {
+    const long i = base + lane;
+    const bool ok = i < N;
+    const long b = ok ? i / T : 0;
+    const int t = ok ? (int)(i % T) : 0;
     const float* yp = y + b * (long)q * T + t;
     float m = -INFINITY;
-    for (int c = 0; c < q; ++c) m = fmaxf(m, yp[(long)c * T]);
+    if (ok)
+#pragma unroll 8
+      for (int c = c0; c < c1; ++c) m = fmaxf(m, yp[(long)c * T]);
+    red[grp][lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+    __syncthreads();
     float ssum = 0.f;
-    for (int c = 0; c < q; ++c) ssum += expf(yp[(long)c * T] - m);
-    const float l = logf(ssum) + m;
-    lse[i] = l;
-    lacc += l - yp[(long)tg[i] * T];
+    if (ok)
+#pragma unroll 8
+      for (int c = c0; c < c1; ++c) ssum += expf(yp[(long)c * T] - m);
+    red[grp][lane] = ssum;
+    __syncthreads();
+    if (grp == 0 && ok) {
+      const float l = logf((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + m;
+      lse[i] = l;
+      lacc += l - yp[(long)tg[i] * T];
+    }
+    __syncthreads();
   }
   const float tot = block_sum_256(lacc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -531,7 +550,7 @@ int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T
   VQ_REQUIRE(y && t && lse && loss && ws, "softmax_xent_fwd: null pointer");
   if (ws_bytes < 4096 * 4) { set_error("softmax_xent_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   const size_t N = (size_t)B * T;
-  const int np = grid_for(N, 256, 1024);
+  const int np = grid_for(N, 64, 1024);
   hipLaunchKernelGGL(xent_fwd_kernel, dim3(np), dim3(256), 0, (hipStream_t)s, y, t, B, q, T, lse, (float*)ws);
   VQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, (float)(1.0 / (double)N), loss);
