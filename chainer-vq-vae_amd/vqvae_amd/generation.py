@@ -209,6 +209,10 @@ def run_many(wavenet, condition, uniforms, mode, n_steps=None, group=_lib.GEN_MA
         ws = DeviceArray((nbytes // 4 + 1,), np.int32)
         jobs.append((st, d, out, ws, u_dev, cview))
     backend.synchronize()                  # buffers above were prepared on the main stream
+    # every workgroup of a launch must be resident at once (its waves wait for each other): a launch
+    # holds 128 two-wave workgroups and a CU takes ~12 such waves (VGPR-limited) -- stay well inside
+    resident = backend.device_info()['n_cu'] * 12 // (128 * 2)
+    max_streams = max(1, min(max_streams, resident * 2 // 3))
     for t0 in range(0, steps, chunk):
         for i, (st, d, out, ws, _, _) in enumerate(jobs):
             _lib.call('vqvae_wavenet_gen_run', C.byref(d), t0, min(chunk, steps - t0), ws.ptr, ws.nbytes,
