@@ -184,7 +184,7 @@ def main():
         cfg.update(n_loop=4, input_dim=1, use_logistic=True, n_mixture=30)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('VQVAE_LOCAL_DEVICE', os.environ.get('LOCAL_RANK', 0)))   # override: multi-rank dry runs on one GPU
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d '
