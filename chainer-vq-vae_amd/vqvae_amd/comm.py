@@ -97,6 +97,10 @@ class RcclCommunicator(object):
         try:
             _lib.call('vqvae_comm_init', C.byref(comm), self.size, self.rank, idbuf)
         finally:
+            try:
+                C.CDLL(None).fflush(None)      # the banner sits in libc's stdout buffer: push it out NOW,
+            except Exception:                  # while fd 1 still points at stderr
+                pass
             os.dup2(saved, 1)
             os.close(saved)
         self._comm = comm
