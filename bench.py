@@ -9,9 +9,15 @@ the timed region.  Inputs are resident in HBM before the timed region starts.
 
 Workload (N=1): BASELINE.json configs[1] -- batch 16, length 7680, mu-law q=256,
 d=64, k=512, n_loop=2, n_layer=10, residual=dilated=skip=256, condition 64+128,
-fp32.  N>1: weak scaling, 16 samples per GPU (configs[2]), one process per GPU
-launched by `python -m torch.distributed.run` (only RANK/WORLD_SIZE/MASTER_* are
-used; torch is not imported: it bundles its own HIP runtime).
+fp32.  N>1: weak scaling, 16 samples per GPU (configs[2]), one process per GPU.
+`python bench.py --gpus N` spawns its own N ranks (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment); when it finds itself
+already launched (`python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N`, WORLD_SIZE set) it is one of the ranks.  torch is never imported.
+
+--workload c4 is BASELINE configs[3] (VQ stress, k=8192 d=128; SURVEY 8d inputs):
+a "step" is one nearest-codebook search + gather over N latent rows; the line
+reports the expansion-form MFMA rate and the algorithmic HBM GB/s side by side.
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- the dominant kernel (ResidualBlock forward: dilated conv +
@@ -36,6 +42,15 @@ CFG = dict(d=64, k=512, n_loop=2, n_layer=10, filter_size=2, input_dim=256, quan
            residual=256, dilated=256, skip=256, local_dim=64, global_dim=128, n_speaker=109,
            length=7680, beta=0.25, lr=2e-4, ema_mu=0.9999, batch_per_gpu=16)
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+# The dominant kernel and what one launch of it computes.  While the
+# residual 1x1 conv is a separate launch the extra term is 0.
+ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
+                   '+ latent-rate condition lerp + tanh*sigmoid gate)')
+
+
+def FUSED_RES_FLOP_PER_POS(cfg):
+    return 0.0
 
 
 def synth_examples(B, cfg, seed):
@@ -132,8 +147,8 @@ def cpu_baseline(cfg):
     candidates = sorted({c for c in (cores, 64, 32, 16) if c <= cores}, reverse=True)
     if threadpool_limits is None:
         candidates = [cores]
-    best = None
-    for nthr in candidates:
+
+    def timed(nthr, n_timed):
         state = {}
         ctx = threadpool_limits(limits=nthr) if threadpool_limits else None
         try:
@@ -141,21 +156,191 @@ def cpu_baseline(cfg):
                 ctx.__enter__()
             O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])    # warm-up
             times = []
-            for _ in range(2):
+            for _ in range(n_timed):
                 t0 = time.time()
                 O.train_step(P, state, batch, cfg['n_loop'], cfg['n_layer'])
                 times.append(time.time() - t0)
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
-        med = float(np.median(times))
-        if best is None or med < best[0]:
-            best = (med, nthr, len(times))
-    med, nthr, n = best
+        return times
+    # pick the thread count on one timed step each, then 1 warm-up + 3 timed steps at the best
+    # (median of >= 3 steps after a warm-up)
+    probe = {nthr: timed(nthr, 1)[0] for nthr in candidates}
+    nthr = min(probe, key=probe.get)
+    times = timed(nthr, 3)
+    med = float(np.median(times))
     return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': nthr, 'kind': 'port',
-            'sample': '%d full training steps (fwd + 3-loss bwd + Adam) at batch 1, length %d, '
-                      'median %.2f s/step with %d BLAS threads (best of %s tried; %d cores visible)'
-                      % (n, cfg['length'], med, nthr, candidates, cores)}
+            'sample': '%d full training steps (fwd + 3-loss bwd + Adam + EMA) at batch 1, length %d '
+                      '(BASELINE configs[0]) after 1 warm-up, median %.2f s/step with %d BLAS threads '
+                      '(thread count chosen from %s on one step each; %d cores visible); NumPy '
+                      'restatement of the Chainer-CPU algorithm'
+                      % (len(times), cfg['length'], med, nthr, candidates, cores)}
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources whose kernels the roofline/traffic figures describe."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('conv_gemm.hip', 'common.h'):
+        with open(os.path.join(ROOT, 'chainer-vq-vae_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/roofline_traffic.json, written by tools/pmc_traffic.py from the counter CSVs of
+    THIS command).  PMC counters cannot be read from inside the process, so the figure is only
+    reported while the summary was taken on the same kernel sources (hash stamp); otherwise null."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')) as fh:
+            rec = json.load(fh)[key]
+    except Exception:
+        return None, 'no rocprofv3 --pmc summary for this workload under profiles/'
+    if rec.get('kernel_source_sha256_16') != kernel_source_hash():
+        return None, ('profiles/roofline_traffic.json[%s] was measured on other kernel sources '
+                      '(stale): re-run tools/pmc_run.sh + tools/pmc_traffic.py' % key)
+    return rec['hbm_traffic_bytes_per_launch'], rec.get('source', 'profiles/roofline_traffic.json')
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` from a bare shell: start N ranks of this script (one per GPU),
+    hand them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a private rendezvous id, relay their
+    output, and fail if any rank fails.  No torch, no external launcher."""
+    import socket
+    import subprocess
+    import uuid
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    rdzv = uuid.uuid4().hex
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VQVAE_RDZV_ID=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in pending:           # one rank died: the others would hang in the collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def vq_stress_inputs(N, d, k):
+    """SURVEY 8d C4 inputs: half the rows N(0,1), half W[j] + 0.5 N(0,1); W ~ N(0, 1/d); seeds 1/2."""
+    rw = np.random.RandomState(2)
+    W = (rw.standard_normal((k, d)) / np.sqrt(d)).astype(np.float32)
+    rz = np.random.RandomState(1)
+    rows = rz.standard_normal((N, d)).astype(np.float32)
+    j = rz.randint(0, k, size=N - N // 2)
+    rows[N // 2:] = W[j] + np.float32(0.5) * rz.standard_normal((N - N // 2, d)).astype(np.float32)
+    return rows, W
+
+
+def run_c4(args, rank, n, local):
+    """BASELINE configs[3]: large-codebook VQ stress, k=8192 d=128.  One step = one
+    StraightThrough.forward (nearest code + gather, utils.py:176-211) over N latent rows laid out
+    (B, d, T'=120) like the encoder output.  Ranks are independent (each quantises its own rows)."""
+    import ctypes as C
+    from vqvae_amd import _lib, backend
+    from vqvae_amd.backend import DeviceArray
+    from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
+    backend.init(local)
+    comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
+    d, k, T = 128, 8192, 120
+    N = args.vq_rows
+    if N % T:
+        raise SystemExit('--vq-rows must be a multiple of 120 (latents per 7680-sample crop)')
+    B = N // T
+    rows, W = vq_stress_inputs(N, d, k)
+    z = np.ascontiguousarray(rows.reshape(B, T, d).transpose(0, 2, 1))
+    dz, dW = backend.to_device(z), backend.to_device(W)
+    idx = DeviceArray((B, T), np.int32)
+    e = DeviceArray((B, d, T), np.float32)
+    nre = DeviceArray((1,), np.int32)
+    ws = backend.workspace(_lib.load().vqvae_vq_workspace_bytes(B, d, T, k))
+
+    def step():
+        _lib.call('vqvae_vq_nearest_fwd', dz.ptr, dW.ptr, B, d, T, k, 0, idx.ptr, e.ptr, nre.ptr,
+                  ws.ptr, ws.nbytes, backend.stream())
+    for _ in range(args.warmup):
+        step()
+    backend.synchronize()
+    lib = _lib.load()
+    tag = _lib.PROF_VQ_NEAREST
+    lib.vqvae_prof_reset()
+    lib.vqvae_prof_enable(1 << tag)
+    comm.barrier()
+    backend.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    backend.synchronize()
+    comm.barrier()
+    dt = comm.max_scalar(time.perf_counter() - t0)
+    lib.vqvae_prof_enable(0)
+    tot, cnt = C.c_double(0), C.c_int(0)
+    _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
+    seen = comm.ranks_seen()
+    if rank == 0:
+        flop = 2.0 * N * k * d                              # SURVEY 8d: expansion form, re-check not counted
+        byts = 4.0 * (N * d + k * d + N + N * d)            # z read, codebook once, idx write, e write
+        avg_ms = tot.value / max(cnt.value, 1)
+        ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
+        gbs = byts / (avg_ms * 1e-3) / 1e9 if cnt.value else None
+        traffic, tsrc = measured_traffic('c4_N%d' % N)
+        # sanity of the result itself on a bounded sample: exact reference distances for 64 rows
+        got = idx.get().reshape(-1)
+        pick = np.linspace(0, N - 1, 64).astype(np.int64)
+        ok = True
+        for r in pick:
+            dist = np.zeros(k, np.float32)
+            for c in range(d):
+                dist = dist + (rows[r, c] - W[:, c]) ** 2   # utils.py:189-203 summation order
+            ok = ok and int(np.argmin(dist)) == int(got[r])
+        out = {
+            'metric': 'VQ nearest-codebook lookups/sec (k=8192, d=128), whole job',
+            'value': n * N * args.steps / dt, 'unit': 'latent rows/s', 'n_gpus': n,
+            'ranks_seen_by_rccl': seen, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[3]: VQ stress k=8192 d=128, N=%d latent rows/GPU '
+                                   '(B=%d x T\'=120), half N(0,1) half near-codebook rows' % (N, B),
+                       'parallelism': 'dp%d (independent rows per rank, no data-path collective)' % n},
+            'rows_rechecked_exactly': int(nre.get()[0]),
+            'indices_match_reference_order_distance_on_64_rows': bool(ok),
+            'roofline': {'bound': 'mfma', 'kernel': 'vqvae_vq_nearest_fwd (vq_wnorm + vq_mfma_reg_kernel '
+                         '+ vq_exact_batched_kernel + gather): MFMA pairwise distance, wavefront argmin, '
+                         'exact re-check of ambiguous rows',
+                         'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
+                         'traffic': traffic, 'traffic_source': tsrc,
+                         'launches': cnt.value, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop,
+                         'hbm': {'achieved_algorithmic': gbs, 'peak': 8000.0, 'unit': 'GB/s',
+                                 'frac': (gbs / 8000.0) if gbs else None,
+                                 'algorithmic_bytes_per_launch': byts}},
+        }
+        print(json.dumps(out))
+    if n > 1 or args.force_comm:
+        comm.barrier()
+        comm.close()
 
 
 def main():
@@ -165,9 +350,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=CFG['batch_per_gpu'])
-    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
+    ap.add_argument('--workload', choices=['c2', 'c4', 'c5'], default='c2',
                     help='c2: BASELINE configs[1]/[2] (softmax, 20 blocks, fp32) -- the metric config; '
+                         'c4: configs[3] (VQ stress k=8192 d=128; see --vq-rows); '
                          'c5: configs[4] (mixture of logistics, input_dim=1, n_loop=4 -> 40 blocks)')
+    ap.add_argument('--vq-rows', type=int, default=1048560,
+                    help='c4: latent rows N per GPU (multiple of 120); SURVEY 8d sizes are 1920 (training '
+                         'shape, latency-bound) and ~1 M (default 8738 x 120 = 1 048 560)')
     ap.add_argument('--bf16', action='store_true',
                     help='bf16 MFMA operands with fp32 accumulation (configs[4] precision)')
     ap.add_argument('--index-input', action='store_true',
@@ -178,18 +367,21 @@ def main():
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
+    world_env = os.environ.get('WORLD_SIZE')
+    if args.gpus > 1 and world_env is None:
+        spawn_ranks(args.gpus, sys.argv[1:])           # does not return
     cfg = dict(CFG)
     cfg['batch_per_gpu'] = args.batch
     if args.workload == 'c5':
         cfg.update(n_loop=4, input_dim=1, use_logistic=True, n_mixture=30)
     rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    world = int(world_env or 1)
     local = int(os.environ.get('VQVAE_LOCAL_DEVICE', os.environ.get('LOCAL_RANK', 0)))   # override: multi-rank dry runs on one GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d '
-                             'bench.py --gpus %d ...' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     n = world
+    if args.workload == 'c4':
+        return run_c4(args, rank, n, local)
 
     import vqvae_amd as V
     from vqvae_amd import _lib, backend
@@ -201,6 +393,9 @@ def main():
         backend.set_overlap(False)
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
 
+    # train.py's order (train.py:76-102): construct -> to_gpu -> optimizer.setup -> train.  The
+    # condition embed's lazily shaped convs (net.py:34-43) appear at the first forward and are
+    # adopted by the optimizer there (optimizers.Adam.adopt_new_params) -- the warm-up steps.
     model, opt = build(cfg, n)
     model.to_gpu(local)
     opt.setup(model)
@@ -218,9 +413,12 @@ def main():
     it = ResidentIterator(shards)
     upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         upd.update()
     backend.synchronize()
+    if opt.uninitialized_params():
+        raise SystemExit('bench: parameters without storage after warm-up: %s' % opt.uninitialized_params())
+    n_params = opt.n_train
 
     tag = _lib.PROF_RESBLOCK_GATE
     lib = _lib.load()
@@ -242,29 +440,27 @@ def main():
     cnt = C.c_int(0)
     _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
     losses = [float(l.data.get()) for l in upd.last_losses]
+    seen = comm.ranks_seen()
 
     if rank == 0:
         T = cfg['length']
         samples = n * B * T * args.steps
         value = samples / dt
-        # algorithmic FLOPs of one launch of the dilated-conv + gate kernel: SURVEY 8(d)
-        # `dilconv1d` fwd = 2*B*T*Cout*Cin*K (the condition projection is no longer in this
-        # kernel's contraction: it is computed once at the latent rate and lerped in the epilogue)
-        flop = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
+        # algorithmic FLOPs of one launch of the dominant kernel (ResidualBlock forward), SURVEY 8(d):
+        # `dilconv1d` fwd = 2*B*T*Cout*Cin*K, plus -- now that the residual 1x1 conv runs inside the
+        # same launch -- its 2*B*T*Cr*(Cd/2); the condition projection is not in this kernel's
+        # contraction (computed once at the latent rate and lerped in the epilogue)
+        flop_conv = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
+        flop = flop_conv + FUSED_RES_FLOP_PER_POS(cfg) * B * T
         peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS      # dense bf16 MFMA peak
         avg_ms = tot.value / max(cnt.value, 1)
         ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
-        # HBM bytes per launch of the same kernel: PMC counters cannot be read from inside this
-        # process, so the figure comes from the committed rocprofv3 --pmc summary of this command
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r1_roofline.json')) as fh:
-                traffic = json.load(fh)['per_launch']['hbm_traffic_bytes']
-        except Exception:
-            pass
+        key = ('c2' if args.workload == 'c2' else 'c5') + ('_bf16' if args.bf16 else '') + '_B%d' % B
+        traffic, tsrc = measured_traffic(key)
         out = {
             'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
-            'value': value, 'unit': 'samples/s', 'n_gpus': n, 'steps': args.steps,
+            'value': value, 'unit': 'samples/s', 'n_gpus': n, 'ranks_seen_by_rccl': seen,
+            'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16 operands, f32 accumulate' if args.bf16 else 'f32',
@@ -278,18 +474,15 @@ def main():
                         '10 logistics), n_loop=4 n_layer=10 (40 blocks), batch %d/GPU, length 7680' % B),
                        'global_batch': n * B, 'length': T,
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
+            'trainable_params': int(n_params),
             'losses_last_step': losses,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: '
-                         'dilated causal conv k=2 as MFMA GEMM + latent-rate condition lerp + '
-                         'tanh*sigmoid gate)',
+            'roofline': {'bound': 'mfma', 'kernel': ROOFLINE_KERNEL,
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': (ach / peak) if ach else None,
-                         'traffic': traffic, 'traffic_source': 'profiles/r1_roofline.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)',
+                         'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms,
-                         'flop_per_launch': flop},
+                         'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
         }
-        if args.bf16 or args.workload != 'c2':
-            out['roofline']['traffic'] = None
         if n == 1 and not args.no_cpu_baseline and args.workload == 'c2' and not args.bf16:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))

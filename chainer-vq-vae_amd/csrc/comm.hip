@@ -19,6 +19,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_api;
@@ -33,6 +34,7 @@ int load_rccl() {
   g_api.CommInitRank = (decltype(g_api.CommInitRank))dlsym(h, "ncclCommInitRank");
   g_api.AllReduce = (decltype(g_api.AllReduce))dlsym(h, "ncclAllReduce");
   g_api.CommDestroy = (decltype(g_api.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_api.CommCount = (decltype(g_api.CommCount))dlsym(h, "ncclCommCount");
   g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_api.GetUniqueId || !g_api.CommInitRank || !g_api.AllReduce || !g_api.CommDestroy) {
     vq::set_error("librccl: missing symbols");
@@ -87,6 +89,14 @@ int vqvae_comm_allreduce_max_f32(void* comm, float* buf, size_t n, vqvae_stream_
   VQ_REQUIRE(comm && buf, "comm_allreduce_max: null");
   ncclResult_t r = g_api.AllReduce(buf, buf, n, ncclFloat32, ncclMax, (ncclComm_t)comm, (hipStream_t)s);
   if (r != ncclSuccess) return nccl_fail("ncclAllReduce(max)", r);
+  return 0;
+}
+
+int vqvae_comm_count(void* comm, int* nranks) {
+  VQ_REQUIRE(comm && nranks, "comm_count: null");
+  VQ_REQUIRE(g_api.CommCount, "comm_count: librccl has no ncclCommCount");
+  ncclResult_t r = g_api.CommCount((ncclComm_t)comm, nranks);
+  if (r != ncclSuccess) return nccl_fail("ncclCommCount", r);
   return 0;
 }
 

@@ -135,6 +135,7 @@ PROTOTYPES = {
     'vqvae_comm_init': (c_int, [C.POINTER(c_void_p), c_int, c_int, c_char_p]),
     'vqvae_comm_allreduce_sum_f32': (c_int, [P, P, c_size_t, P]),
     'vqvae_comm_allreduce_max_f32': (c_int, [P, P, c_size_t, P]),
+    'vqvae_comm_count': (c_int, [P, C.POINTER(c_int)]),
     'vqvae_comm_destroy': (c_int, [P]),
     'vqvae_wavenet_gen_step': (c_int, [C.POINTER(GenDesc), P]),
     'vqvae_wavenet_gen_run_workspace_bytes': (c_size_t, [C.POINTER(GenDesc)]),

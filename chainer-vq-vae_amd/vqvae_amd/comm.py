@@ -5,10 +5,11 @@ RCCL all-reduce(sum) of the flat gradient arena over xGMI (C ABI
 vqvae_comm_*).  Replaces Link.addgrads + Link.copyparams of the reference's
 single-process multi-GPU updater (updaters.py:71-77).
 
-Rendezvous: rank 0 creates the ncclUniqueId and publishes it through a file
-keyed by the launcher's (MASTER_PORT, parent pid); the launcher
-(`python -m torch.distributed.run`) only supplies RANK/WORLD_SIZE/MASTER_* --
-torch itself is never imported in a GPU process (it bundles its own HIP runtime).
+Rendezvous (single node): rank 0 creates the ncclUniqueId and publishes it
+through a file in a per-user 0700 directory, keyed by the job (VQVAE_RDZV_ID from bench.py's
+own spawner, or MASTER_PORT + launcher pid under `python -m torch.distributed.run`).  Either
+launcher only supplies RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* -- torch itself is never
+imported in a GPU process (it bundles its own HIP runtime).
 
 The world_size-2 CPU tests drive the same shard / sum / lr logic through a
 gloo-backed communicator with this interface that lives in tests/dp_worker.py
@@ -36,6 +37,9 @@ def scaled_alpha(lr, size):
 class SingleCommunicator(object):
     rank, size = 0, 1
 
+    def ranks_seen(self):
+        return 1
+
     def allreduce_grad(self, flat):
         return flat
 
@@ -46,11 +50,53 @@ class SingleCommunicator(object):
         return v
 
 
+def _rendezvous_dir():
+    """Per-user 0700 directory for the id hand-off (not a world-writable /tmp name: another local
+    user could otherwise pre-create or symlink the file the ranks trust)."""
+    base = os.environ.get('XDG_RUNTIME_DIR') or '/tmp'
+    d = os.path.join(base, 'vqvae_rccl_%d' % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError('rendezvous directory %s is not a private directory of this user' % d)
+    return d
+
+
 def _rendezvous_path():
-    port = os.environ.get('MASTER_PORT', '0')
-    run = os.environ.get('TORCHELASTIC_RUN_ID', 'none')
-    restart = os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
-    return '/tmp/vqvae_rccl_uid_%s_%s_%s_%d' % (port, run, restart, os.getppid())
+    """One file per job: keyed by VQVAE_RDZV_ID when the launcher sets one (bench.py's own
+    spawner does), else by what `python -m torch.distributed.run` provides."""
+    key = os.environ.get('VQVAE_RDZV_ID')
+    if not key:
+        key = '%s_%s_%s_%d' % (os.environ.get('MASTER_PORT', '0'),
+                               os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+                               os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), os.getppid())
+    key = ''.join(c if (c.isalnum() or c in '-_') else '_' for c in key)
+    return os.path.join(_rendezvous_dir(), 'uid_' + key)
+
+
+def _publish(path, raw):
+    """Atomic, exclusive creation (a stale file of the same name is replaced, never followed)."""
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+    try:
+        os.write(fd, raw)
+    finally:
+        os.close(fd)
+    os.rename(tmp, path)
+
+
+def _read_owned(path):
+    fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    try:
+        if os.fstat(fd).st_uid != os.getuid():
+            raise RuntimeError('rendezvous file %s is not owned by this user' % path)
+        return os.read(fd, 128)
+    finally:
+        os.close(fd)
 
 
 class RcclCommunicator(object):
@@ -67,10 +113,7 @@ class RcclCommunicator(object):
         idbuf = C.create_string_buffer(128)
         if self.rank == 0:
             _lib.call('vqvae_comm_unique_id', idbuf)
-            tmp = path + '.tmp'
-            with open(tmp, 'wb') as f:
-                f.write(idbuf.raw)
-            os.rename(tmp, path)
+            _publish(path, idbuf.raw)
         else:
             t0 = time.time()
 
@@ -85,8 +128,7 @@ class RcclCommunicator(object):
                 if time.time() - t0 > timeout:
                     raise RuntimeError('RCCL rendezvous timed out waiting for %s' % path)
                 time.sleep(0.05)
-            with open(path, 'rb') as f:
-                raw = f.read()
+            raw = _read_owned(path)
             idbuf = C.create_string_buffer(raw, 128)
         comm = C.c_void_p()
         # RCCL prints a version banner on first init; keep stdout clean for callers that
@@ -129,6 +171,16 @@ class RcclCommunicator(object):
         self._lib.call('vqvae_comm_allreduce_max_f32', self._comm, self._scalar.ptr, 1,
                        self._backend.stream())
         return float(self._scalar.get()[0])
+
+    def ranks_seen(self):
+        """(ncclCommCount, all-reduced sum of ones): how many ranks RCCL itself reports and how
+        many actually contributed to a collective."""
+        n = C.c_int(0)
+        self._lib.call('vqvae_comm_count', self._comm, C.byref(n))
+        self._scalar.set(np.array([1.0], np.float32))
+        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, self._scalar.ptr, 1,
+                       self._backend.stream())
+        return n.value, int(round(float(self._scalar.get()[0])))
 
     def close(self):
         if self._comm is not None:

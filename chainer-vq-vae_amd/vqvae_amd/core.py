@@ -60,6 +60,10 @@ def force_backprop_mode():
 # reporter (chainer.reporter.report, net.py:93-95)
 # --------------------------------------------------------------------------- #
 class Reporter(object):
+    """chainer.Reporter: observers report into the CURRENT observation dict.  ``scope`` swaps
+    the dict for the duration of a block, which is how Chainer's Evaluator keeps a validation
+    pass from overwriting the training observations ('main/loss*', net.py:93-95)."""
+
     def __init__(self):
         self.observation = {}
         self._names = {}
@@ -74,6 +78,15 @@ class Reporter(object):
         for k, v in values.items():
             self.observation[prefix + k] = v
 
+    @contextlib.contextmanager
+    def scope(self, observation):
+        old = self.observation
+        self.observation = observation
+        try:
+            yield observation
+        finally:
+            self.observation = old
+
 
 _reporter = Reporter()
 
@@ -84,6 +97,30 @@ def report(values, observer=None):
 
 def get_current_reporter():
     return _reporter
+
+
+def report_scope(observation):
+    """chainer.reporter.report_scope."""
+    return _reporter.scope(observation)
+
+
+# Parameter life-cycle epochs.  'init' advances whenever a Parameter gets (new) host/device
+# storage outside an optimizer arena -- lazily shaped convs (net.py:34-43 builds
+# DilatedConvolution2D(None, ...)) are created at the first forward, AFTER optimizer.setup in
+# train.py's order (train.py:76-102) -- so an optimizer can notice parameters it has not
+# adopted yet.  'load' advances when a serializer overwrites parameter values, so value-keyed
+# caches (VQ search reuse, packed generation weights) drop what they hold.  'layout' advances
+# when an optimizer moves parameters into (new) arenas: raw device pointers captured before
+# that (GenerationState) are stale.
+_epochs = {'init': 0, 'load': 0, 'layout': 0}
+
+
+def param_epoch(kind):
+    return _epochs[kind]
+
+
+def bump_param_epoch(kind):
+    _epochs[kind] += 1
 
 
 # --------------------------------------------------------------------------- #
@@ -265,6 +302,7 @@ class Parameter(Variable):
         else:
             arr = np.ascontiguousarray(init(shape), np.float32)
         self._data = arr
+        bump_param_epoch('init')
 
     def grad_buffer(self):
         """Where a backward kernel may write this parameter's gradient directly

@@ -18,7 +18,9 @@ class Evaluator(object):
         reference's PrintReport keys."""
         sums = {}
         n = 0
-        with core.using_config('train', False), core.no_backprop_mode():
+        # the model reports 'main/loss*' on every call (net.py:93-95); Chainer's Evaluator runs it
+        # inside its own reporter scope so the training observations are not overwritten
+        with core.using_config('train', False), core.no_backprop_mode(), core.report_scope({}):
             while max_batches is None or n < max_batches:
                 try:
                     batch = self.iterator.next()

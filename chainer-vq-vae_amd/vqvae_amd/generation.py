@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib, backend
+from . import _lib, backend, core
 from .backend import DeviceArray
 
 _S = backend.stream
@@ -36,6 +36,10 @@ class GenerationState(object):
         if b0.filter_size != 2:
             raise NotImplementedError('incremental generation supports filter_size == 2 (params.py:31)')
         self.n = n
+        # the state holds raw device pointers of the weights: keep their buffers alive and
+        # remember which parameter layout / contents they belong to
+        self._weights = [p.data for p in wavenet.params()]
+        self._epochs = (core.param_epoch('layout'), core.param_epoch('load'))
         self.input_dim = wavenet.embed.W.shape[1]
         self.residual = wavenet.embed.W.shape[0]
         self.dilated = b0.conv.W.shape[0]

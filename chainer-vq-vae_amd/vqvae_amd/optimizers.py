@@ -6,6 +6,16 @@ slot in one contiguous gradient arena.  ``update()`` is then a single fused Adam
 kernel, ``cleargrads()`` a single memset, and the data-parallel exchange a single
 RCCL all-reduce of the gradient arena (updaters.py:71-77 replaced).
 
+Lazily shaped parameters.  The reference builds ``ConditionEmbed`` with
+``DilatedConvolution2D(None, ...)`` (net.py:34-43) and calls ``optimizer.setup``
+before the first forward (train.py:76-102), so five conv weights do not exist at
+setup time; Chainer creates them at the first call and trains them like any other
+parameter.  Here ``adopt_new_params()`` -- run by the updaters between backward and
+the gradient exchange, and by ``update()`` -- notices parameters created since the
+last layout (core.param_epoch('init')), rebuilds the arenas with them in
+namedparams order and carries over every value, gradient and Adam moment, so the
+first step already updates (and all-reduces) them.
+
 Parameters whose gradient is None at update time (the EMA copies; the last
 block's ``res`` conv, modules.py:89-96) are skipped by Chainer's update rule;
 here their gradient slots are zero and their Adam moments stay exactly zero, so
@@ -13,7 +23,7 @@ the update is the identity on them -- the same result.
 """
 import numpy as np
 
-from . import _lib, backend
+from . import _lib, backend, core
 from .backend import DeviceArray
 
 
@@ -25,6 +35,8 @@ class Adam(object):
         self.eps = eps
         self.t = 0
         self.target = None
+        self._layout = []
+        self._epoch = -1
 
     @property
     def lr(self):
@@ -34,39 +46,80 @@ class Adam(object):
 
     def setup(self, link):
         self.target = link
-        named = [(n, p) for n, p in link.namedparams() if p.data is not None]
+        self._layout = []
+        self.params = self.grads = self.m = self.v = None
+        self._build()
+        return self
+
+    # ------------------------------------------------------------------ #
+    def _build(self):
+        """(Re)builds the flat arenas over every parameter that has storage now."""
+        self._epoch = core.param_epoch('init')
+        named = [(n, p) for n, p in self.target.namedparams() if p.data is not None]
         for n, p in named:
             if not isinstance(p.data, DeviceArray):
                 raise ValueError('optimizer.setup: parameter %s is on the host; call '
                                  'model.to_gpu() first (there is no CPU update path)' % n)
         train = [(n, p) for n, p in named if not p._shadow]
         shadow = [(n, p) for n, p in named if p._shadow]
-        self._layout = []
+        old = {n: (off, size) for n, off, size in self._layout}
+        old_m, old_v, old_n_train = self.m, self.v, getattr(self, 'n_train', 0)
         n_train = sum(p.size for _, p in train)
         n_all = n_train + sum(p.size for _, p in shadow)
-        self.params = backend.empty((n_all,), np.float32)
-        self.grads = backend.zeros((n_train,), np.float32)
-        self.m = backend.zeros((n_train,), np.float32)
-        self.v = backend.zeros((n_train,), np.float32)
+        params = backend.empty((n_all,), np.float32)
+        grads = backend.zeros((n_train,), np.float32)
+        m = backend.zeros((n_train,), np.float32)
+        v = backend.zeros((n_train,), np.float32)
+        layout = []
         off = 0
         for n, p in train + shadow:
-            view = self.params.flat_view(off, p.size, p.data.shape)
-            view.copy_from(p.data)
+            view = params.flat_view(off, p.size, p.data.shape)
+            view.copy_from(p.data)            # from the old arena or from the parameter's own buffer
             p.data = view
             if not p._shadow:
-                p._grad_slot = self.grads.flat_view(off, p.size, view.shape)
-                p.grad = None
+                slot = grads.flat_view(off, p.size, view.shape)
+                if p.grad is not None:        # gradient accumulated before adoption / re-layout
+                    slot.copy_from(p.grad.reshape(view.shape) if isinstance(p.grad, DeviceArray)
+                                   else p.grad.data.reshape(view.shape))
+                    p.grad = slot
+                p._grad_slot = slot
+                if n in old and old[n][0] + old[n][1] <= old_n_train:
+                    o, sz = old[n]
+                    m.flat_view(off, sz).copy_from(old_m.flat_view(o, sz))
+                    v.flat_view(off, sz).copy_from(old_v.flat_view(o, sz))
             p._owner_step = self._step_count        # lets caches notice parameter updates
-            self._layout.append((n, off, p.size))
+            layout.append((n, off, p.size))
             off += p.size
+        self.params, self.grads, self.m, self.v = params, grads, m, v
+        self._layout = layout
         self.n_train = n_train
-        return self
+        core.bump_param_epoch('layout')
+
+    def adopt_new_params(self):
+        """Re-lays the arenas when parameters were created since the last layout (lazily
+        shaped links at their first forward).  Cheap when nothing changed: one integer compare."""
+        if self._epoch == core.param_epoch('init'):
+            return False
+        known = {n for n, _, _ in self._layout}
+        fresh = [n for n, p in self.target.namedparams() if p.data is not None and n not in known]
+        if not fresh:
+            self._epoch = core.param_epoch('init')
+            return False
+        for n, p in self.target.namedparams():
+            if n in fresh:
+                p.to_gpu()
+        self._build()
+        return True
+
+    def uninitialized_params(self):
+        return [n for n, p in self.target.namedparams() if p.data is None]
 
     def _step_count(self):
         return self.t
 
     def update(self):
         """One Adam step on every trainable parameter (chainer Adam update rule)."""
+        self.adopt_new_params()
         self.t += 1
         _lib.call('vqvae_adam_step', self.params.ptr, self.grads.ptr, self.m.ptr, self.v.ptr,
                   self.n_train, float(self.lr), float(self.beta1), float(self.beta2),

@@ -16,6 +16,7 @@ a snapshot written here loads in the reference's generate.py and vice versa.
 """
 import numpy as np
 
+from . import core
 from .backend import DeviceArray
 from .core import Link
 
@@ -68,6 +69,7 @@ def load_npz(file, obj, path='', strict=True):
             return
         opt = obj.get_optimizer('main')
         _load_link(f, opt.target, MODEL_PREFIX, strict)
+        opt.adopt_new_params()
         m, v = opt.m.get(), opt.v.get()
         for name, off, size in opt.layout():
             key = OPT_PREFIX + name.strip('/') + '/'
@@ -83,6 +85,10 @@ def load_npz(file, obj, path='', strict=True):
 
 
 def _load_link(f, link, prefix, strict):
+    # a model that already lives on the device gets lazily shaped parameters (net.py:34-43:
+    # DilatedConvolution2D(None, ...)) created ON the device, and the 'init' epoch tells an
+    # optimizer that was set up before to adopt them (optimizers.Adam.adopt_new_params)
+    on_device = any(isinstance(p.data, DeviceArray) for p in link.params())
     for name, p in link.namedparams():
         key = prefix + name.strip('/')
         if key not in f:
@@ -96,4 +102,10 @@ def _load_link(f, link, prefix, strict):
         if isinstance(p.data, DeviceArray):
             p.data.set(arr)
         else:
+            created = p.data is None
             p.data = np.ascontiguousarray(arr, np.float32)
+            if on_device:
+                p.to_gpu()
+            if created:
+                core.bump_param_epoch('init')
+    core.bump_param_epoch('load')       # value-keyed caches (VQ search reuse, generation state) are stale

@@ -6,7 +6,7 @@ that provide the attributes the reference's ``update_core`` bodies use
 import numpy as np
 
 from . import backend, core
-from .comm import SingleCommunicator
+from .comm import SingleCommunicator, shard as strided_shard
 
 
 def concat_examples(batch, device=None):
@@ -87,13 +87,18 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         optimizer = self.get_optimizer('main')
         model = optimizer.target
         n = self.comm.size
-        shard = self.get_iterator('main').next()[self.comm.rank::n]      # strided split
+        shard = strided_shard(self.get_iterator('main').next(), self.comm.rank, n)   # batch[rank::n]
         in_arrays = self.converter(shard, self.device)
 
         with core.force_backprop_mode():
             self.last_losses = (self.loss_func or model)(*in_arrays)
         three_loss_backward(model, self.last_losses)
 
+        # parameters created during this forward (lazily shaped links, net.py:34-43) join the
+        # flat arenas BEFORE the exchange, so their gradients are summed like everyone else's
+        adopt = getattr(optimizer, 'adopt_new_params', None)
+        if adopt is not None:
+            adopt()
         if n > 1 or getattr(self.comm, 'always_reduce', False):
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place
         optimizer.update()

@@ -199,4 +199,4 @@ class VQ(Link):
 
     def _w_version(self):
         opt = getattr(self.W, '_owner_step', None)
-        return opt() if opt is not None else 0
+        return (opt() if opt is not None else 0, core.param_epoch('load'))

@@ -438,6 +438,10 @@ class WaveNet(Chain):
         st = getattr(self, '_gen', None)
         if st is None:
             raise RuntimeError('call WaveNet.initialize(n) before generate (generate.py:100)')
+        from . import core
+        if st._epochs != (core.param_epoch('layout'), core.param_epoch('load')):
+            raise RuntimeError('parameters were moved (optimizer.setup) or re-loaded (load_npz) since '
+                               'WaveNet.initialize(n): call initialize(n) again')
         return st
 
     def generate(self, x, condition):

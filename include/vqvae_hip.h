@@ -327,6 +327,7 @@ int vqvae_comm_unique_id(char id[VQVAE_COMM_ID_BYTES]);          /* host buffer 
 int vqvae_comm_init(void** comm, int nranks, int rank, const char id[VQVAE_COMM_ID_BYTES]);
 int vqvae_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, vqvae_stream_t s);
 int vqvae_comm_allreduce_max_f32(void* comm, float* buf, size_t n, vqvae_stream_t s);
+int vqvae_comm_count(void* comm, int* nranks);   /* ranks RCCL sees in this communicator (ncclCommCount) */
 int vqvae_comm_destroy(void* comm);
 
 /* ---- incremental generation: WaveNet.initialize / WaveNet.generate /
