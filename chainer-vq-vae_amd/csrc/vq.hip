@@ -364,16 +364,161 @@ __global__ void vq_gather_kernel(const float* __restrict__ W, const int32_t* __r
   }
 }
 
-__global__ void vq_scatter64_kernel(const int32_t* __restrict__ idx, const float* __restrict__ gy,
-                                    int B, int d, int T, double* g64) {
-  const long total = (long)B * d * T;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % T);
-    const long r = i / T;
-    const int c = (int)(r % d);
-    const long bb = r / d;
-    atomicAdd(&g64[(long)idx[bb * T + t] * d + c], (double)gy[i]);
+// ---------------------------------------------------------------------------
+// Large-N codebook gradient (B*T' beyond the scan kernel's reach, e.g. the configs[3] stress
+// shape): gW = onehot(idx)^T gy accumulated in float64, rounded once (utils.py:222-229).
+// Deterministic by construction -- no floating-point atomics: a STABLE counting sort of the row
+// ids by code (per-chunk histograms -> chunk-major offsets -> one wave per chunk places its rows
+// in ascending order), then every code sums its rows in ascending row order; a long row list is
+// cut into VQ_GW_SPLIT fixed pieces whose float64 partials are combined in piece order.
+// ---------------------------------------------------------------------------
+constexpr int VQ_GW_CHUNK = 16384;     // rows per sort chunk (one wave places a chunk)
+constexpr int VQ_GW_SPLIT = 8;         // max pieces of one code's row list
+constexpr int VQ_GW_PIECE = 2048;      // rows per piece before a list is cut further
+
+__global__ __launch_bounds__(256) void vq_gw_hist_kernel(const int32_t* __restrict__ idx, long N, int k,
+                                                         int32_t* __restrict__ hist) {
+  // hist[chunk][j] = rows of this chunk quantised to j (integer atomics: exact, order-free)
+  int32_t* h = hist + (long)blockIdx.x * k;
+  const long lo = (long)blockIdx.x * VQ_GW_CHUNK;
+  const long hi = lo + VQ_GW_CHUNK < N ? lo + VQ_GW_CHUNK : N;
+  for (long n = lo + threadIdx.x; n < hi; n += blockDim.x) atomicAdd(&h[idx[n]], 1);
+}
+
+__global__ __launch_bounds__(1024) void vq_gw_offsets_kernel(int32_t* __restrict__ hist, int nchunk, int k,
+                                                             int32_t* __restrict__ base) {
+  // in place: hist[chunk][j] -> first slot of (chunk, j) in the sorted list; base[j], base[k] = N
+  __shared__ int32_t part[1024];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < k; j0 += 1024) {
+    const int j = j0 + threadIdx.x;
+    int32_t tot = 0;
+    if (j < k)
+      for (int c = 0; c < nchunk; ++c) tot += hist[(long)c * k + j];
+    part[threadIdx.x] = tot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {       // inclusive scan of the 1024 totals
+      const int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int32_t start = carry + part[threadIdx.x] - tot;
+    if (j < k) {
+      base[j] = start;
+      int32_t run = start;
+      for (int c = 0; c < nchunk; ++c) {
+        const int32_t h = hist[(long)c * k + j];
+        hist[(long)c * k + j] = run;
+        run += h;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) base[k] = carry;
+}
+
+__global__ __launch_bounds__(64) void vq_gw_place_kernel(const int32_t* __restrict__ idx, long N, int k,
+                                                         int32_t* __restrict__ cursor_all,
+                                                         int32_t* __restrict__ sorted) {
+  // one wave owns one chunk and its cursor row: rows are visited in ascending order, 64 at a
+  // time; lanes holding the same code take consecutive slots in lane (= row) order
+  // volatile: a wave-uniform address would otherwise be read through the scalar cache, which
+  // does not see this wave's own vector stores
+  volatile int32_t* cursor = cursor_all + (long)blockIdx.x * k;
+  const int lane = threadIdx.x;
+  const long lo = (long)blockIdx.x * VQ_GW_CHUNK;
+  const long hi = lo + VQ_GW_CHUNK < N ? lo + VQ_GW_CHUNK : N;
+  for (long g = lo; g < hi; g += 64) {
+    const long n = g + lane;
+    const bool live = n < hi;
+    const int32_t c = live ? idx[n] : -1;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int32_t c0 = __shfl(c, leader);
+      const unsigned long long m = __ballot(live && c == c0) & todo;
+      const int32_t start = cursor[c0];                 // same address in every lane: one broadcast load
+      if (live && c == c0 && ((todo >> lane) & 1ull))
+        sorted[start + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)n;
+      __builtin_amdgcn_s_waitcnt(0);                    // the load above precedes the owner's store below
+      if (lane == leader) cursor[c0] = start + __popcll(m);
+      __builtin_amdgcn_s_waitcnt(0);                    // ... and is complete before the next group's load
+      todo &= ~m;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_gw_sum_kernel(const int32_t* __restrict__ sorted,
+                                                        const int32_t* __restrict__ base,
+                                                        const float* __restrict__ gy, int d, int T,
+                                                        double* __restrict__ part64,
+                                                        float* __restrict__ gW, int accumulate) {
+  // block (j, s): piece s of code j's ascending row list
+  const int j = blockIdx.x, s = blockIdx.y;
+  const int beg = base[j], cnt = base[j + 1] - beg;
+  int S = (cnt + VQ_GW_PIECE - 1) / VQ_GW_PIECE;
+  if (S > VQ_GW_SPLIT) S = VQ_GW_SPLIT;
+  if (S < 1) S = 1;
+  if (s >= S) return;
+  const int L = (cnt + S - 1) / S;
+  const int lo = beg + s * L;
+  int hi = lo + L;
+  if (hi > beg + cnt) hi = beg + cnt;
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  const int dch = d < 256 ? d : 256;
+  const int P = 256 / dch;
+  for (int c0 = 0; c0 < d; c0 += dch) {
+    const int c = c0 + tid % dch;
+    const int g = tid / dch;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (g < P && c < d) {
+      const float* gc = gy + (long)c * T;
+      int q = lo + g;
+      for (; q + 3 * P < hi; q += 4 * P) {
+        const int n0 = sorted[q], n1 = sorted[q + P], n2 = sorted[q + 2 * P], n3 = sorted[q + 3 * P];
+        a0 += (double)gc[(long)(n0 / T) * d * T + n0 % T];
+        a1 += (double)gc[(long)(n1 / T) * d * T + n1 % T];
+        a2 += (double)gc[(long)(n2 / T) * d * T + n2 % T];
+        a3 += (double)gc[(long)(n3 / T) * d * T + n3 % T];
+      }
+      for (; q < hi; q += P) { const int n = sorted[q]; a0 += (double)gc[(long)(n / T) * d * T + n % T]; }
+    }
+    __syncthreads();
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && c < d) {
+      double acc = red[tid];
+      for (int gg = 1; gg < P; ++gg) acc += red[gg * dch + tid];
+      if (S == 1) {
+        const float v = (float)acc;
+        float* dst = gW + (long)j * d + c;
+        *dst = accumulate ? __fadd_rn(*dst, v) : v;
+      } else {
+        part64[((long)j * VQ_GW_SPLIT + s) * d + c] = acc;
+      }
+    }
+  }
+}
+
+__global__ void vq_gw_combine_kernel(const int32_t* __restrict__ base, const double* __restrict__ part64,
+                                     int k, int d, float* __restrict__ gW, int accumulate) {
+  const long total = (long)k * d;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / d), c = (int)(i % d);
+    const int cnt = base[j + 1] - base[j];
+    int S = (cnt + VQ_GW_PIECE - 1) / VQ_GW_PIECE;
+    if (S > VQ_GW_SPLIT) S = VQ_GW_SPLIT;
+    if (S <= 1) continue;                               // written by the sum kernel itself
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += part64[((long)j * VQ_GW_SPLIT + s) * d + c];
+    const float v = (float)acc;
+    gW[i] = accumulate ? __fadd_rn(gW[i], v) : v;
   }
 }
 
@@ -440,14 +585,6 @@ __global__ __launch_bounds__(256) void vq_gradw_scan_kernel(const int32_t* __res
   }
 }
 
-__global__ void vq_cast64_kernel(const double* __restrict__ g64, long n, float* gW, int accumulate) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x) {
-    const float v = (float)g64[i];
-    gW[i] = accumulate ? __fadd_rn(gW[i], v) : v;
-  }
-}
-
 static int vq_cols_per_block(int dpad) {
   // LDS: dpad*NC + 32*(dpad+1) floats <= ~150 KB
   for (int nw = 4; nw >= 1; nw >>= 1) {
@@ -464,7 +601,10 @@ using namespace vq;
 extern "C" size_t vqvae_vq_workspace_bytes(int B, int d, int T, int k) {
   const size_t N = (size_t)B * T;
   size_t fwd = align_up((size_t)k * 4, 256) + 256 /*wmax+nflag*/ + align_up(N * 4, 256);
-  size_t bwd = align_up((size_t)k * d * 8, 256);
+  // large-N codebook gradient: part64[k][SPLIT][d] | base[k+1] | cursor[nchunk][k] | sorted[N]
+  const size_t nchunk = (N + VQ_GW_CHUNK - 1) / VQ_GW_CHUNK;
+  size_t bwd = align_up((size_t)k * VQ_GW_SPLIT * d * 8, 256) + align_up(((size_t)k + 1) * 4, 256) +
+               align_up(nchunk * k * 4, 256) + align_up(N * 4, 256);
   return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -549,24 +689,34 @@ extern "C" int vqvae_vq_grad_w(const int32_t* idx, const float* gy, int B, int d
                                float* gW, int accumulate, void* ws, size_t ws_bytes,
                                vqvae_stream_t s) {
   VQ_REQUIRE(idx && gy && gW && ws, "vq_grad_w: null pointer");
-  if (ws_bytes < (size_t)k * d * 8) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
   if ((long)B * T <= 8192 && (long)B * T * k <= (1L << 26)) {   // small problem: scan form
     hipLaunchKernelGGL(vq_gradw_scan_kernel, dim3(k), dim3(256), (size_t)B * T * 4, st, idx, gy, B, d, T, k, gW, accumulate);
     VQ_LAUNCH_CHECK();
     return 0;
   }
-  double* g64 = (double*)ws;
-  VQ_CHECK_HIP(hipMemsetAsync(g64, 0, (size_t)k * d * 8, st));
-  const long total = (long)B * d * T;
-  int nb = (int)((total + 255) / 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(vq_scatter64_kernel, dim3(nb), dim3(256), 0, st, idx, gy, B, d, T, g64);
+  const long N = (long)B * T;
+  VQ_REQUIRE(N < (1L << 31), "vq_grad_w: B*T too large");
+  if (ws_bytes < vqvae_vq_workspace_bytes(B, d, T, k)) { set_error("vq_grad_w: workspace too small"); return VQVAE_E_WORKSPACE; }
+  const int nchunk = (int)((N + VQ_GW_CHUNK - 1) / VQ_GW_CHUNK);
+  char* wp = (char*)ws;
+  double* part64 = (double*)wp; wp += align_up((size_t)k * VQ_GW_SPLIT * d * 8, 256);
+  int32_t* base = (int32_t*)wp; wp += align_up(((size_t)k + 1) * 4, 256);
+  int32_t* cursor = (int32_t*)wp; wp += align_up((size_t)nchunk * k * 4, 256);
+  int32_t* sorted = (int32_t*)wp;
+  VQ_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)nchunk * k * 4, st));
+  hipLaunchKernelGGL(vq_gw_hist_kernel, dim3(nchunk), dim3(256), 0, st, idx, N, k, cursor);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_gw_offsets_kernel, dim3(1), dim3(1024), 0, st, cursor, nchunk, k, base);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_gw_place_kernel, dim3(nchunk), dim3(64), 0, st, idx, N, k, cursor, sorted);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_gw_sum_kernel, dim3(k, VQ_GW_SPLIT), dim3(256), 0, st, sorted, base, gy, d, T, part64, gW, accumulate);
   VQ_LAUNCH_CHECK();
   const long n = (long)k * d;
   int nb2 = (int)((n + 255) / 256);
   if (nb2 > 4096) nb2 = 4096;
-  hipLaunchKernelGGL(vq_cast64_kernel, dim3(nb2), dim3(256), 0, st, g64, n, gW, accumulate);
+  hipLaunchKernelGGL(vq_gw_combine_kernel, dim3(nb2), dim3(256), 0, st, base, part64, k, d, gW, accumulate);
   VQ_LAUNCH_CHECK();
   return 0;
 }

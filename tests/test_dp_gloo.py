@@ -1,7 +1,8 @@
-"""Data-parallel logic on CPU (-m "not gpu"): two gloo ranks running the strided
-shard + gradient SUM + lr/n update must (a) stay bit-identical replicas and (b)
-equal a single process that sums the two shards' gradients itself
-(updaters.py:37-38, 71-77; train.py:101)."""
+"""Data-parallel step on CPU (-m "not gpu"): two gloo ranks, each running the PRODUCT's
+``VQVAE_ParallelUpdater.update_core`` (tests/dp_worker.py drives it over host shims of the oracle),
+must (a) stay bit-identical replicas without any parameter broadcast, (b) hold the SUM of the two
+shard gradients in their gradient arenas, and (c) equal a single process that sums the two strided
+shards' gradients itself and steps with lr/2 (updaters.py:37-38, 71-77; train.py:101)."""
 import os
 import socket
 import subprocess
@@ -34,6 +35,7 @@ def test_two_rank_gloo_step_matches_single_process(tmp_path):
         assert p.wait(timeout=600) == 0
     a, b = np.load(out % 0), np.load(out % 1)
     np.testing.assert_array_equal(a, b)             # replicas identical without a broadcast
+    np.testing.assert_array_equal(np.load((out % 0) + '.grads.npy'), np.load((out % 1) + '.grads.npy'))
 
     # single-process emulation: per-shard grads summed, alpha = lr/2
     from vqvae_amd.comm import scaled_alpha, shard

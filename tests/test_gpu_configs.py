@@ -1,0 +1,354 @@
+"""GPU parity at the BASELINE configurations AS CONFIGURED (north_star's acceptance test: "checked
+against the reference Chainer CPU path on identical inputs").
+
+  configs[0]  batch 1, length 7680, d=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256,
+              EMA on: one whole VQVAE_StandardUpdater.update() against oracle.train_step --
+              indices bit-exact, three losses 1e-4, every gradient 2e-4 of its scale, every
+              parameter after Adam 1e-4, EMA copy 1e-5  (updaters.py:6-19, net.py:79-96).
+  configs[4]  use_logistic=True, input_dim=1, n_mixture=30 (10 logistics), n_loop=4 n_layer=10
+              (40 blocks), full channel widths, bf16 MFMA operands: a whole step against the
+              operand-rounding oracle at the length the oracle affords, and the full-size run
+              (batch 16, length 7680) through size-independent properties.
+  configs[3]  the large-N codebook-gradient path (B*T' > 8192 rows) bit-exact and deterministic.
+  train.py's construction order (lazily shaped condition convs created after optimizer.setup).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+import vqvae_oracle as O
+from helpers import assert_close, assert_close_scaled
+from test_gpu_model import _Iter, _grads_by_name
+
+pytestmark = pytest.mark.gpu
+
+CFG0 = dict(d=64, k=512, n_loop=2, n_layer=10, filter_size=2, input_dim=256, residual=256,
+            dilated=256, skip=256, out_dim=256, local_dim=64, global_dim=128, n_speaker=109)
+CFG4 = dict(d=64, k=512, n_loop=4, n_layer=10, filter_size=2, input_dim=1, residual=256,
+            dilated=256, skip=256, out_dim=30, local_dim=64, global_dim=128, n_speaker=109)
+
+
+def _limit_blas(n=16):
+    """The oracle's mid-sized GEMMs are fastest on ~16 BLAS threads (bench.py cpu_baseline)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n)
+    except ImportError:
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def test_config0_whole_step_matches_oracle(gpu):
+    import copy
+    import vqvae_amd as V
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(CFG0)
+    T = 7680
+    P, model = H.build_model(cfg, seed=0, ema_decay=0.9999)
+    P_ema = copy.deepcopy(P['decoder'])
+    model.to_gpu()
+    opt = Adam(2e-4)
+    opt.setup(model)
+    batch = O.synth_batch(1, length=T, n_speaker=cfg['n_speaker'], seed=71)
+    assert batch[0].shape == (1, 1, T + 1) and batch[1].shape == (1, 256, T)
+    upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+    upd.update()
+    with _limit_blas():
+        losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], ema=P_ema,
+                                        ema_decay=0.9999)
+    # argmin indices: bit-exact (the model's own search, reused for both quantiser applications)
+    idx_dev = model.vq._cache[3][0].get()
+    np.testing.assert_array_equal(idx_dev.reshape(cache['idx'].shape), cache['idx'])
+    assert cache['idx'].size == 120
+    l_dev = [float(l.data.get()) for l in upd.last_losses]
+    for i, (a, b) in enumerate(zip(l_dev, losses)):
+        assert_close(a, float(b), 1e-4, 'configs[0] loss%d' % (i + 1))
+    g_dev = _grads_by_name(model, opt, True)
+    assert len(G) > 150
+    for name, arr in G.items():
+        dn = H._dev_name(name, True)
+        assert dn in g_dev, 'missing grad for ' + dn
+        assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 2e-4, 'configs[0] grad ' + dn)
+    named = dict(model.namedparams())
+    for name, arr in O.flatten_params(P):
+        dn = H._dev_name(name, True)
+        assert_close(named[dn].data.get().reshape(arr.shape), arr, 1e-4, 'configs[0] param ' + dn)
+    for name, arr in O.flatten_params(P_ema):
+        dn = '/decoder/ema' + name.replace('/blocks/', '/resnet/')
+        assert_close(named[dn].data.get().reshape(arr.shape), arr, 1e-5, 'configs[0] ema ' + dn)
+
+
+def _mol_conditioned(P):
+    # random-init outputs put most logistics deep in saturation (cdf_delta ~ 1e-12), where the loss
+    # is a step function of fp32 noise; give the output layer trained-like statistics
+    W, b = P['decoder']['proj2']
+    W[10:20] *= 30.0          # means spread over the sample range
+    b[20:30] = 2.5            # log-scales ~ 2.5 -> inv_std ~ 0.08
+
+
+def _rel_l2(got, want):
+    got = np.asarray(got, np.float64).reshape(-1)
+    want = np.asarray(want, np.float64).reshape(-1)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def test_config4_as_configured_bf16_step_vs_oracle(gpu):
+    """Mixture-of-logistics decoder, input_dim=1, 30 output channels, n_loop=4 x n_layer=10 = 40
+    blocks, 256 channels everywhere, bf16 operands / fp32 accumulate (modules.py:169-230).  Length
+    2048 (every dilation up to 512 acts) is what the operand-rounding oracle affords.  Rounding is
+    discontinuous, so two bf16 implementations agree to a few bf16 epsilons (2^-8) in relative
+    L2, not to 1e-4: (a) the full-rate condition path rounds the same operands as the oracle;
+    (b) the default latent-rate condition path rounds the condition projection's operands at the
+    latent rate instead -- same bar."""
+    import vqvae_amd as V
+    from vqvae_amd import functions as F
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(CFG4)
+    T = 2048
+    batch = O.synth_batch_raw(1, length=T, n_speaker=cfg['n_speaker'], seed=19)
+
+    def device_step(lazy):
+        F.LAZY_CONDITION = lazy
+        gpu.set_matmul_dtype('bfloat16')
+        try:
+            P, model = H.build_model(cfg, seed=13, use_logistic=True, tweak=_mol_conditioned)
+            model.to_gpu()
+            opt = Adam(2e-4)
+            opt.setup(model)
+            upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+            upd.update()
+            idx = model.vq._cache[3][0].get()
+            return P, idx, [float(l.data.get()) for l in upd.last_losses], _grads_by_name(model, opt, False)
+        finally:
+            F.LAZY_CONDITION = True
+            gpu.set_matmul_dtype('float32')
+    P, idx_a, l_a, g_a = device_step(lazy=False)
+    O.set_bf16(True)
+    try:
+        with _limit_blas():
+            losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+    finally:
+        O.set_bf16(False)
+    assert len(G) > 300                       # 40 blocks x 8 + encoder, vq, condition embed, embed/proj
+    _, idx_b, l_b, g_b = device_step(lazy=True)
+    worst = {}
+    for tag, idx, l_dev, g_dev in (('full-rate', idx_a, l_a, g_a), ('latent-rate', idx_b, l_b, g_b)):
+        # the encoder ahead of the quantiser runs on bf16 operands too: a latent may sit within a
+        # bf16 epsilon of a cell boundary, so allow a stray index flip, no more
+        flips = int((idx.reshape(cache['idx'].shape) != cache['idx']).sum())
+        assert flips <= max(1, cache['idx'].size // 16), (tag, flips)
+        for i, (a, b) in enumerate(zip(l_dev, losses)):
+            assert_close(a, float(b), 2e-3, 'configs[4] %s loss%d' % (tag, i + 1))
+        errs = {name: _rel_l2(g_dev[H._dev_name(name, False)], arr) for name, arr in G.items()}
+        name = max(errs, key=errs.get)
+        worst[tag] = (name, errs[name])
+        assert errs[name] < 3e-2, 'configs[4] %s: grad %s relative L2 error %.3e' % (tag, name, errs[name])
+    print('configs[4] bf16 worst gradient relative L2:', worst)
+
+
+def test_config4_full_size_properties_bf16(gpu):
+    """configs[4] at its full size (batch 16, length 7680, 40 blocks, bf16 operands): finite
+    losses with loss3 = beta*loss2, bit-identical repeat (the bf16 path is deterministic), batch
+    elements independent (sample 5 alone == sample 5 in the batch, bit for bit), and the
+    16-example gradient equal to the mean of the two strided 8-example shard gradients
+    (updaters.py:37-38, 71-72) to bf16-accumulation tolerance."""
+    import vqvae_amd as V
+    from vqvae_amd.core import Variable
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(CFG4)
+    B, T = 16, 7680
+    batch = O.synth_batch_raw(B, length=T, n_speaker=cfg['n_speaker'], seed=23)
+    gpu.set_matmul_dtype('bfloat16')
+    try:
+        def grads(sub):
+            P, model = H.build_model(cfg, seed=17, use_logistic=True, tweak=_mol_conditioned)
+            model.to_gpu()
+            opt = Adam(2e-4)
+            opt.setup(model)
+            upd = V.VQVAE_StandardUpdater(_Iter([tuple(a[sub] for a in batch)]), opt, device=0)
+            upd.update()
+            return model, [float(l.data.get()) for l in upd.last_losses], opt.grads.get(), \
+                _grads_by_name(model, opt, False)
+        model, l_all, flat_all, g_all = grads(slice(0, B))
+        assert np.isfinite(l_all).all(), l_all
+        assert abs(l_all[2] - 0.25 * l_all[1]) <= 1e-6 * max(1.0, abs(l_all[1]))
+        _, l_rep, flat_rep, _ = grads(slice(0, B))
+        assert l_rep == l_all
+        np.testing.assert_array_equal(flat_rep, flat_all)
+        _, _, _, g_a = grads(slice(0, B, 2))
+        _, _, _, g_b = grads(slice(1, B, 2))
+        for name, g in g_all.items():
+            assert_close_scaled(g, 0.5 * (g_a[name] + g_b[name]), 2e-4, 'configs[4] shard sum ' + name)
+        x_enc, x_dec, spk, t = batch
+        with V.using_config('train', False), V.core.no_backprop_mode():
+            def outputs(sl):
+                z = model.encoder(Variable(gpu.to_device(np.ascontiguousarray(x_enc[sl][..., None]))))
+                e = model.vq(z)
+                cond = model.condition_embed(e, Variable(gpu.to_device(np.ascontiguousarray(spk[sl]))))
+                return model.decoder(Variable(gpu.to_device(np.ascontiguousarray(x_dec[sl][..., None]))), cond).data.get()
+            y_all = outputs(slice(0, B))
+            assert y_all.shape == (B, 30, T, 1)
+            np.testing.assert_array_equal(y_all[5:6], outputs(slice(5, 6)))
+    finally:
+        gpu.set_matmul_dtype('float32')
+
+
+@pytest.mark.parametrize('shape', [(80, 120, 128, 8192), (300, 120, 64, 512), (70, 120, 64, 16)])
+def test_vq_grad_w_large_n_bitexact_and_deterministic(gpu, shape):
+    """utils.py:222-229 beyond the scan kernel's reach (B*T' > 8192 rows -- the configs[3] stress
+    regime): gW = onehot(idx)^T gy in float64, rounded once, equals a float64 scatter-add bit for
+    bit; three runs are identical (the path has no floating-point atomics); a collapsed codebook
+    (16 codes, long row lists cut into pieces) takes the split-and-combine branch."""
+    import ctypes as C
+    from vqvae_amd import _lib
+    from vqvae_amd.backend import DeviceArray
+    B, T, d, k = shape
+    assert B * T > 8192
+    rs = np.random.RandomState(B)
+    idx = rs.randint(0, k, size=(B, T)).astype(np.int32)
+    if k == 512:
+        idx[:, ::3] = 7                       # one hot code with a third of all rows
+    gy = (rs.standard_normal((B, d, T)) * 10.0 ** rs.uniform(-3, 3, size=(B, d, 1))).astype(np.float32)
+    want64 = np.zeros((k, d), np.float64)
+    np.add.at(want64, idx.reshape(-1), gy.transpose(0, 2, 1).reshape(-1, d).astype(np.float64))
+    want = want64.astype(np.float32)
+    # the reference's own arithmetic (float64 one-hot matmul), where its (N,k) float64 one-hot is affordable
+    ref = O.vq_backward(idx, np.zeros((k, d), np.float32), gy)[1] if B * T * k <= (1 << 25) else None
+    d_idx, d_gy = gpu.to_device(idx), gpu.to_device(gy)
+    ws = gpu.workspace(_lib.load().vqvae_vq_workspace_bytes(B, d, T, k))
+    outs = []
+    for _ in range(3):
+        gW = DeviceArray((k, d), np.float32)
+        _lib.call('vqvae_vq_grad_w', d_idx.ptr, d_gy.ptr, B, d, T, k, gW.ptr, 0, ws.ptr, ws.nbytes,
+                  gpu.stream())
+        outs.append(gW.get())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+    # float64 sums of <= 36 000 fp32 terms differ between summation orders by < 2^-40 relative; a
+    # different fp32 rounding needs the sum to sit that close to a rounding boundary
+    mism = int((outs[0] != want).sum())
+    assert mism == 0, '%d of %d entries differ from the float64 scatter-add' % (mism, want.size)
+    if ref is not None:
+        np.testing.assert_array_equal(outs[0], ref.reshape(k, d))
+    # accumulate=1 adds onto the existing values with one fp32 rounding
+    gW = gpu.to_device(np.ones((k, d), np.float32))
+    _lib.call('vqvae_vq_grad_w', d_idx.ptr, d_gy.ptr, B, d, T, k, gW.ptr, 1, ws.ptr, ws.nbytes, gpu.stream())
+    np.testing.assert_array_equal(gW.get(), np.float32(1.0) + want)
+
+
+def _train_py_order_model(cfg, seed=0):
+    """train.py:76-102: construct -> to_gpu -> optimizer.setup -> train, with the condition
+    embed's convs built with in_channels=None exactly as net.py:34-43 does."""
+    import vqvae_amd as V
+    from vqvae_amd import functions as F
+    from vqvae_amd.optimizers import Adam
+    V.core.seed_initializers(seed)
+    enc = V.Encoder(cfg['d'])
+    wn = V.WaveNet(cfg['n_loop'], cfg['n_layer'], cfg['filter_size'], cfg['input_dim'], cfg['residual'],
+                   cfg['dilated'], cfg['skip'], 256, False, 30, -40, cfg['local_dim'] + cfg['global_dim'], 0)
+    ce = V.ConditionEmbed(cfg['n_speaker'], cfg['global_dim'], cfg['local_dim'])
+    dec = V.ExponentialMovingAverage(wn, 0.99)
+    model = V.VAE(enc, dec, ce, cfg['d'], cfg['k'], 0.25, F.softmax_cross_entropy)
+    model.to_gpu()
+    opt = Adam(1e-3)
+    opt.setup(model)
+    return model, opt
+
+
+def test_lazily_shaped_params_are_adopted_and_trained(gpu):
+    """with train.py's order the five local_embed conv weights do not exist at
+    optimizer.setup.  They must join the flat arenas at the first step and be updated by it (and
+    so be part of the all-reduced gradient arena), like Chainer trains lazily initialised params."""
+    import vqvae_amd as V
+    cfg = dict(H.SMALL)
+    model, opt = _train_py_order_model(cfg)
+    lazy = ['/condition_embed/local_embed%d/W' % i for i in range(1, 6)]
+    assert sorted(opt.uninitialized_params()) == lazy
+    n0 = opt.n_train
+    batches = [O.synth_batch(2, length=512, n_speaker=cfg['n_speaker'], seed=40 + s) for s in range(2)]
+    upd = V.VQVAE_StandardUpdater(_Iter(batches), opt, device=0)
+    named = dict(model.namedparams())
+    before = {n: p.data.get().copy() for n, p in named.items() if p.data is not None}
+    upd.update()
+    assert opt.uninitialized_params() == []
+    assert opt.n_train == n0 + sum(named[n].size for n in lazy)
+    first = {n: p.data.get().copy() for n, p in named.items()}
+    last_res = '/decoder/target/resnet/%d/res/' % (cfg['n_loop'] * cfg['n_layer'] - 1)
+    lo, hi = opt.params.ptr, opt.params.ptr + opt.params.nbytes
+    for n, p in named.items():
+        assert lo <= p.data.ptr < hi, n + ' lives outside the flat arena'
+        if p._shadow:
+            continue
+        assert p._grad_slot is not None, n
+        if n.startswith(last_res):
+            continue                                   # no gradient: modules.py:89-96
+        if n in before:
+            assert np.any(first[n] != before[n]), n + ' was not updated by the first step'
+    upd.update()
+    for n in lazy:
+        assert np.any(named[n].data.get() != first[n]), n + ' was not updated by the second step'
+    # Adam moments of the adopted parameters are live (non-zero) after two steps
+    m = opt.m.get()
+    for n, off, size in opt.layout():
+        if n in lazy:
+            assert np.abs(m[off:off + size]).max() > 0, n
+
+
+def test_lazy_order_equals_eager_order_bitwise(gpu):
+    """Adoption is bookkeeping only: the train.py-order model (lazy convs adopted at step 1) and a
+    model whose shapes were forced before setup take bit-identical steps."""
+    import vqvae_amd as V
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    batches = [O.synth_batch(2, length=512, n_speaker=cfg['n_speaker'], seed=60 + s) for s in range(2)]
+    model_a, opt_a = _train_py_order_model(cfg, seed=3)
+    upd_a = V.VQVAE_StandardUpdater(_Iter(batches), opt_a, device=0)
+    upd_a.update()
+    # eager twin: same initial values (copied from A's pre-step state is impossible after the step,
+    # so rebuild with the same initializer seed and force the lazy shapes in creation order)
+    V.core.seed_initializers(3)
+    from vqvae_amd import functions as F
+    enc = V.Encoder(cfg['d'])
+    wn = V.WaveNet(cfg['n_loop'], cfg['n_layer'], cfg['filter_size'], cfg['input_dim'], cfg['residual'],
+                   cfg['dilated'], cfg['skip'], 256, False, 30, -40, cfg['local_dim'] + cfg['global_dim'], 0)
+    ce = V.ConditionEmbed(cfg['n_speaker'], cfg['global_dim'], cfg['local_dim'])
+    dec = V.ExponentialMovingAverage(wn, 0.99)
+    model_b = V.VAE(enc, dec, ce, cfg['d'], cfg['k'], 0.25, F.softmax_cross_entropy)
+    for i, ci in zip(range(1, 6), [cfg['d']] + [cfg['local_dim']] * 4):   # the draws A made at its first forward
+        getattr(ce, 'local_embed%d' % i)._initialize_params(ci)
+    model_b.to_gpu()
+    opt_b = Adam(1e-3)
+    opt_b.setup(model_b)
+    upd_b = V.VQVAE_StandardUpdater(_Iter(batches), opt_b, device=0)
+    upd_b.update()
+    pa, pb = dict(model_a.namedparams()), dict(model_b.namedparams())
+    assert sorted(pa) == sorted(pb)
+    for n in pa:
+        np.testing.assert_array_equal(pa[n].data.get(), pb[n].data.get(), err_msg=n)
+    upd_a.update(); upd_b.update()
+    np.testing.assert_array_equal(opt_a.params.get(), opt_b.params.get())
+
+
+def test_load_npz_into_device_model_with_lazy_params(gpu, tmp_path):
+    """load_npz into a model that is on the device and set up but whose lazily shaped
+    parameters do not exist yet: they are created on the device and adopted, the next step runs,
+    and value-keyed caches notice the load."""
+    import vqvae_amd as V
+    from vqvae_amd import serializers
+    cfg = dict(H.SMALL)
+    batches = [O.synth_batch(2, length=512, n_speaker=cfg['n_speaker'], seed=90 + s) for s in range(2)]
+    model, opt = _train_py_order_model(cfg, seed=5)
+    upd = V.VQVAE_StandardUpdater(_Iter(batches), opt, device=0)
+    upd.update(); upd.update()
+    path = str(tmp_path / 'snap.npz')
+    serializers.save_npz(path, upd)
+    upd.update()
+    want = opt.params.get()
+    model2, opt2 = _train_py_order_model(cfg, seed=6)          # lazy convs still shapeless
+    upd2 = V.VQVAE_StandardUpdater(_Iter(batches), opt2, device=0)
+    assert len(opt2.uninitialized_params()) == 5
+    serializers.load_npz(path, upd2)
+    assert opt2.uninitialized_params() == [] and opt2.t == 2 and upd2.iteration == 2
+    upd2._iterators['main'].i = 2
+    upd2.update()
+    np.testing.assert_array_equal(opt2.params.get(), want)

@@ -256,3 +256,118 @@ def test_crop_or_pad_follows_preprocess_golden():
             assert (lo, hi) == (0, 700 - 256 - 1)
             return int(g['crop_start'])
     np.testing.assert_array_equal(crop_or_pad(g['wave_long'], 255, rng=_Rng()), g['mulaw_long_raw'][0, :, 0])
+
+
+def test_log_report_keys_interval_and_file(tmp_path):
+    """train.py:135-140: LogReport(trigger=(100,'iteration')) averages what the model reports
+    under main/ (net.py:93-95), merges validation/main/* from the Evaluator, adds epoch /
+    iteration / elapsed_time and rewrites <out>/log as a JSON list; PrintReport prints the
+    reference's eight columns."""
+    import io
+    import json
+    from vqvae_amd import core
+    from vqvae_amd.reporting import PRINT_KEYS, LogReport, PrintReport
+
+    class Upd(object):
+        iteration = 0
+    upd, model = Upd(), object()
+    log = LogReport(trigger=(100, 'iteration'), out=str(tmp_path), epoch_of=lambda it: it // 150)
+    buf = io.StringIO()
+    printer = PrintReport(out=buf)
+    for it in range(1, 201):
+        core.report({'loss1': float(it), 'loss2': 2.0, 'loss3': 0.5, 'loss': it + 2.5}, model)
+        upd.iteration = it
+        if it == 150:
+            log.report({'validation/main/loss1': 4.0, 'validation/main/loss2': 1.0,
+                        'validation/main/loss3': 0.25, 'validation/main/loss': 5.25})
+        printer(log(upd))
+    with open(str(tmp_path / 'log')) as f:
+        entries = json.load(f)
+    assert [e['iteration'] for e in entries] == [100, 200]
+    assert entries[0]['main/loss1'] == pytest.approx(50.5) and entries[1]['main/loss1'] == pytest.approx(150.5)
+    assert entries[0]['main/loss3'] == 0.5 and entries[1]['epoch'] == 1
+    assert set(entries[0]) == {'main/loss', 'main/loss1', 'main/loss2', 'main/loss3', 'epoch', 'iteration',
+                               'elapsed_time'}
+    assert entries[1]['validation/main/loss1'] == 4.0 and 'validation/main/loss' in entries[1]
+    assert set(PRINT_KEYS) <= set(entries[1]) | {'epoch', 'iteration'}
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 3 and lines[0].split() == PRINT_KEYS
+
+
+def test_reporter_scope_isolates_validation():
+    """Chainer's Evaluator reports inside its own scope: the training observation survives."""
+    from vqvae_amd import core
+    rep = core.get_current_reporter()
+    core.report({'loss1': 1.0}, object())
+    keep = dict(rep.observation)
+    with core.report_scope({}) as obs:
+        core.report({'loss1': 9.0}, object())
+        assert obs['main/loss1'] == 9.0
+    assert rep.observation == keep and rep.observation['main/loss1'] == 1.0
+
+
+def test_rendezvous_directory_is_private_and_id_keyed(monkeypatch, tmp_path):
+    import stat
+    from vqvae_amd import comm
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path))
+    monkeypatch.setenv('VQVAE_RDZV_ID', 'job/../x y')
+    p = comm._rendezvous_path()
+    d = os.path.dirname(p)
+    assert os.path.dirname(d) == str(tmp_path) and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    assert os.path.basename(p) == 'uid_job____x_y'            # no path separators survive
+    comm._publish(p, b'\x01' * 128)
+    assert comm._read_owned(p) == b'\x01' * 128
+    os.unlink(p)
+    os.symlink('/etc/passwd', p)                               # a planted symlink is refused
+    with pytest.raises(OSError):
+        comm._read_owned(p)
+    os.chmod(d, 0o755)
+    with pytest.raises(RuntimeError):
+        comm._rendezvous_dir()
+
+
+def test_bench_traffic_is_null_when_the_profile_is_stale(monkeypatch, tmp_path):
+    """bench.py reports roofline.traffic only while profiles/roofline_traffic.json carries the hash
+    of the current kernel sources."""
+    import json
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'kernel_source_hash', lambda: 'aaaa')
+    (prof / 'roofline_traffic.json').write_text(json.dumps(
+        {'c2_B16': {'kernel_source_sha256_16': 'aaaa', 'hbm_traffic_bytes_per_launch': 123, 'source': 's'}}))
+    assert bench.measured_traffic('c2_B16') == (123, 's')
+    assert bench.measured_traffic('c5_B16')[0] is None
+    monkeypatch.setattr(bench, 'kernel_source_hash', lambda: 'bbbb')
+    v, why = bench.measured_traffic('c2_B16')
+    assert v is None and 'stale' in why
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* / a shared rendezvous id and propagates failure (here the
+    ranks fail early: there is no GPU in the CPU test environment)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = tmp_path / 'sitecustomize.py'
+    probe.write_text(
+        "import os\n"
+        "if os.environ.get('RANK') is not None:\n"
+        "    open(os.path.join(%r, 'rank%%s' %% os.environ['RANK']), 'w').write(' '.join(\n"
+        "        os.environ.get(k, '?') for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'VQVAE_RDZV_ID')))\n"
+        % str(tmp_path))
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'VQVAE_RDZV_ID'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1',
+                          '--warmup', '0', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    seen = [open(str(tmp_path / ('rank%d' % r))).read().split() for r in range(2)]
+    assert [s[0] for s in seen] == ['0', '1'] and [s[1] for s in seen] == ['0', '1']
+    assert seen[0][2:] == seen[1][2:] and seen[0][2] == '2' and seen[0][3] == '127.0.0.1'
+    assert len(seen[0][5]) == 32
+    import vqvae_amd.backend as backend
+    if not backend.available():
+        assert out.returncode != 0                  # no GPU here: the ranks fail loudly, so does the parent
