@@ -95,3 +95,94 @@ def load_params(model, P, ema=False):
 
 def device_named_grads(model, ema=False):
     return {n: p for n, p in model.namedparams()}
+
+
+# --------------------------------------------------------------------------- #
+# ReLU kinks.  Two fp32 evaluations of the same network agree to ~1e-7 in every activation, so a
+# pre-activation that lands within that distance of zero can come out on either side of the kink.
+# One such element out of the ~2M behind each decoder ReLU moves every gradient below it by
+# ~1/sqrt(2M) ~ 1e-3 relative (measured at configs[0]: 1e-4..2e-3 of scale), which is the
+# subgradient choice at a kink, not arithmetic.  The whole-step parity tests therefore (1) read
+# the device's post-ReLU activations, (2) check that the oracle disagrees about "active" ONLY at
+# elements that are zero to fp32 noise, and (3) let the oracle's backward use the device's choice
+# there.  Everything else -- every multiply-add of forward and backward -- is compared as is.
+# --------------------------------------------------------------------------- #
+def device_relu_sites(model, x_enc, x_dec, speaker):
+    """Post-ReLU activations of the 12 ReLU sites of VAE.__call__ on the device (net.py:20-24,
+    49-53; modules.py:155, 158), computed with the model's own links, no graph, no EMA blend."""
+    import vqvae_amd as V
+    from vqvae_amd import backend, functions as F
+    from vqvae_amd.core import Variable
+    with V.core.no_backprop_mode():
+        h = Variable(backend.to_device(np.ascontiguousarray(x_enc[..., None])))
+        enc = []
+        for i in range(1, 7):
+            h = getattr(model.encoder, 'conv%d' % i)(h, relu=(i < 6))
+            if i < 6:
+                enc.append(h.data.get()[..., 0])
+        e = model.vq(h)
+        ce = []
+        g = e
+        for i in range(1, 6):
+            g = getattr(model.condition_embed, 'local_embed%d' % i)(g, relu=True)
+            ce.append(g.data.get()[..., 0])
+        cond = model.condition_embed(e, Variable(backend.to_device(np.ascontiguousarray(speaker))))
+        wn = getattr(model.decoder, 'target', model.decoder)
+        xd = Variable(backend.to_device(np.ascontiguousarray(x_dec[..., None])))
+        x0 = wn.embed(xd, out_len=x_dec.shape[2])
+        s = F.relu(wn.resnet(x0, cond))
+        z1 = wn.proj1(s, relu=True)
+        return {'enc': enc, 'ce': ce, 's': s.data.get()[..., 0], 'z1': z1.data.get()[..., 0]}
+
+
+def align_relu_kinks(cache, dev, noise=2e-5):
+    """Makes the oracle's cached activations take the device's side at ReLU kinks (in place).
+    Returns the number of elements changed; fails if the two disagree anywhere that is not zero
+    to within ``noise`` x the tensor's scale (that would be an arithmetic difference)."""
+    flips = [0]
+
+    def fix(post, dv, name, pre=None):
+        ref = post if pre is None else pre
+        mism = (ref > 0) != (dv > 0)
+        n = int(mism.sum())
+        if n:
+            scale = float(np.abs(ref).max())
+            worst = max(float(np.abs(ref[mism]).max()), float(np.abs(dv[mism]).max()))
+            assert worst <= noise * scale, \
+                '%s: device and oracle disagree about ReLU activity at a value of %.3e (scale %.3e)' % (name, worst, scale)
+            on = mism & (dv > 0)
+            post[on] = dv[on]
+            post[mism & ~on] = 0
+            if pre is not None:
+                pre[on] = dv[on]
+                pre[mism & ~on] = -0.0
+            flips[0] += n
+    for i in range(5):
+        fix(cache['enc_hs'][i + 1], dev['enc'][i], 'encoder relu %d' % (i + 1))
+        fix(cache['ce_hs'][i + 1], dev['ce'][i], 'condition_embed relu %d' % (i + 1))
+    x, caches, skip_sum, s, z1 = cache['dcache']
+    fix(s, dev['s'], 'decoder relu(skip)', pre=skip_sum)
+    fix(z1, dev['z1'], 'decoder relu(proj1)')
+    return flips[0]
+
+
+def oracle_train_step_aligned(P, state, batch, n_loop, n_layer, dev_sites, beta=0.25, alpha=2e-4, ema=None,
+                              ema_decay=0.9999, loss_kind='softmax'):
+    """oracle.train_step (updaters.py:6-19 incl. the EMA blend) with the ReLU kink choices of the
+    device (see above) applied between its forward and its backward."""
+    x_enc, x_dec, speaker, t = batch
+    losses, cache = O.vae_forward(P, x_enc, x_dec, speaker, t, n_loop, n_layer, beta, loss_kind)
+    if ema is not None:
+        for (n1, a), (n2, b) in zip(O.flatten_params(ema), O.flatten_params(P['decoder'])):
+            O.ema_update(a, b, ema_decay)
+    flips = align_relu_kinks(cache, dev_sites)
+    G = O.vae_backward(P, cache, speaker, t, n_loop, n_layer, beta, loss_kind)
+    flatP, flatG = dict(O.flatten_params(P)), dict(O.flatten_params(G))
+    state['t'] = state.get('t', 0) + 1
+    for name, p in flatP.items():
+        if name not in flatG:
+            continue
+        m = state.setdefault('m' + name, np.zeros_like(p))
+        v = state.setdefault('v' + name, np.zeros_like(p))
+        O.adam_update(p, flatG[name], m, v, state['t'], alpha)
+    return losses, cache, flatG, flips

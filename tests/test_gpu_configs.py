@@ -52,10 +52,13 @@ def test_config0_whole_step_matches_oracle(gpu):
     batch = O.synth_batch(1, length=T, n_speaker=cfg['n_speaker'], seed=71)
     assert batch[0].shape == (1, 1, T + 1) and batch[1].shape == (1, 256, T)
     upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+    sites = H.device_relu_sites(model, batch[0], batch[1], batch[2])     # ReLU kink choices (helpers.py)
     upd.update()
     with _limit_blas():
-        losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], ema=P_ema,
-                                        ema_decay=0.9999)
+        losses, cache, G, flips = H.oracle_train_step_aligned(P, {}, batch, cfg['n_loop'], cfg['n_layer'], sites,
+                                                              ema=P_ema, ema_decay=0.9999)
+    print('configs[0]: %d ReLU kink elements (of ~5.6 M) took the other side on the device' % flips)
+    assert flips <= 64
     # argmin indices: bit-exact (the model's own search, reused for both quantiser applications)
     idx_dev = model.vq._cache[3][0].get()
     np.testing.assert_array_equal(idx_dev.reshape(cache['idx'].shape), cache['idx'])
@@ -80,9 +83,13 @@ def test_config0_whole_step_matches_oracle(gpu):
 
 def _mol_conditioned(P):
     # random-init outputs put most logistics deep in saturation (cdf_delta ~ 1e-12), where the loss
-    # is a step function of fp32 noise; give the output layer trained-like statistics
+    # is a step function of fp32 noise; give the output layer trained-like scales.  The means are
+    # widened only x3: at x30 a bf16 rounding of proj2's operands moves a mean by several bins and
+    # the REFERENCE algorithm's own bf16 gradients land 0.4..1.0 (relative L2) from its fp32 ones
+    # (measured on the oracle); at x3 that distance is 2.6e-2 median -- a regime where comparing
+    # two bf16 evaluations means something.
     W, b = P['decoder']['proj2']
-    W[10:20] *= 30.0          # means spread over the sample range
+    W[10:20] *= 3.0
     b[20:30] = 2.5            # log-scales ~ 2.5 -> inv_std ~ 0.08
 
 
@@ -92,58 +99,135 @@ def _rel_l2(got, want):
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
-def test_config4_as_configured_bf16_step_vs_oracle(gpu):
-    """Mixture-of-logistics decoder, input_dim=1, 30 output channels, n_loop=4 x n_layer=10 = 40
-    blocks, 256 channels everywhere, bf16 operands / fp32 accumulate (modules.py:169-230).  Length
-    2048 (every dilation up to 512 acts) is what the operand-rounding oracle affords.  Rounding is
-    discontinuous, so two bf16 implementations agree to a few bf16 epsilons (2^-8) in relative
-    L2, not to 1e-4: (a) the full-rate condition path rounds the same operands as the oracle;
-    (b) the default latent-rate condition path rounds the condition projection's operands at the
-    latent rate instead -- same bar."""
+def _config4_device_step(gpu, batch, bf16, lazy=True, want_sites=False):
     import vqvae_amd as V
     from vqvae_amd import functions as F
     from vqvae_amd.optimizers import Adam
     cfg = dict(CFG4)
-    T = 2048
-    batch = O.synth_batch_raw(1, length=T, n_speaker=cfg['n_speaker'], seed=19)
-
-    def device_step(lazy):
-        F.LAZY_CONDITION = lazy
+    F.LAZY_CONDITION = lazy
+    if bf16:
         gpu.set_matmul_dtype('bfloat16')
-        try:
-            P, model = H.build_model(cfg, seed=13, use_logistic=True, tweak=_mol_conditioned)
-            model.to_gpu()
-            opt = Adam(2e-4)
-            opt.setup(model)
-            upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
-            upd.update()
-            idx = model.vq._cache[3][0].get()
-            return P, idx, [float(l.data.get()) for l in upd.last_losses], _grads_by_name(model, opt, False)
-        finally:
-            F.LAZY_CONDITION = True
-            gpu.set_matmul_dtype('float32')
-    P, idx_a, l_a, g_a = device_step(lazy=False)
-    O.set_bf16(True)
     try:
-        with _limit_blas():
-            losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+        P, model = H.build_model(cfg, seed=13, use_logistic=True, tweak=_mol_conditioned)
+        model.to_gpu()
+        opt = Adam(2e-4)
+        opt.setup(model)
+        upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+        sites = H.device_relu_sites(model, batch[0], batch[1], batch[2]) if want_sites else None
+        upd.update()
+        idx = model.vq._cache[3][0].get()
+        named = dict(model.namedparams())
+        params = {n: p.data.get() for n, p in named.items()}
+        return P, idx, [float(l.data.get()) for l in upd.last_losses], _grads_by_name(model, opt, False), sites, params
     finally:
-        O.set_bf16(False)
+        F.LAZY_CONDITION = True
+        gpu.set_matmul_dtype('float32')
+
+
+def _to64(t):
+    if isinstance(t, dict):
+        return {k: _to64(v) for k, v in t.items()}
+    if isinstance(t, (list, tuple)):
+        return type(t)(_to64(v) for v in t)
+    return t.astype(np.float64) if isinstance(t, np.ndarray) and t.dtype == np.float32 else t
+
+
+def test_config4_architecture_fp32_whole_step_matches_oracle(gpu):
+    """The configs[4] network exactly as configured -- mixture-of-logistics loss, input_dim=1, 30
+    output channels, n_loop=4 x n_layer=10 = 40 blocks (grouped ResidualNet contractions), 256
+    channels, d=64 k=512 -- one whole training step in fp32 (length 2048: every dilation up to 512
+    acts, the oracle finishes in seconds).  The discretised-logistic gradient divides by
+    cdf_plus - cdf_min, a cancelling difference (modules.py:193, 214-215): the REFERENCE algorithm
+    evaluated in fp32 is itself 4e-5..1e-4 (relative) away from its exact value (measured: fp32 vs
+    float64 oracle), so the device is compared with the algorithm evaluated in float64, at the
+    north_star tolerance, and the fp32 oracle's own distance is shown beside it."""
+    cfg = dict(CFG4)
+    batch = O.synth_batch_raw(1, length=2048, n_speaker=cfg['n_speaker'], seed=19)
+    P, idx, l_dev, g_dev, sites, params = _config4_device_step(gpu, batch, bf16=False, want_sites=True)
+    P64 = _to64(P)
+    batch64 = (batch[0].astype(np.float64), batch[1].astype(np.float64), batch[2], batch[3].astype(np.float64))
+    before = {n: a.copy() for n, a in O.flatten_params(P64)}
+    with _limit_blas():
+        _, _, G32 = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+        losses, cache, G, flips = H.oracle_train_step_aligned(P64, {}, batch64, cfg['n_loop'], cfg['n_layer'],
+                                                              sites, loss_kind='mol')
+    np.testing.assert_array_equal(idx.reshape(cache['idx'].shape), cache['idx'])
+    for i, (a, b) in enumerate(zip(l_dev, losses)):
+        assert_close(a, float(b), 1e-4, 'configs[4] fp32 loss%d' % (i + 1))
     assert len(G) > 300                       # 40 blocks x 8 + encoder, vq, condition embed, embed/proj
-    _, idx_b, l_b, g_b = device_step(lazy=True)
-    worst = {}
+    worst_dev = worst_ref = 0.0
+    for name, arr in G.items():
+        g = g_dev[H._dev_name(name, False)].reshape(arr.shape)
+        assert_close_scaled(g, arr, 2e-4, 'configs[4] fp32 grad ' + name)
+        worst_dev = max(worst_dev, float(np.abs(g - arr).max() / np.abs(arr).max()))
+        worst_ref = max(worst_ref, float(np.abs(G32[name] - arr).max() / np.abs(arr).max()))
+    print('configs[4] fp32: worst gradient error vs the float64 algorithm: device %.2e, fp32 oracle %.2e '
+          '(of scale); %d ReLU kink elements' % (worst_dev, worst_ref, flips))
+    # Adam: the first step moves every entry by ~alpha*sign(g) (train.py:101-102); entries whose
+    # gradient is below the fp32 noise above may take the other sign, all others must agree
+    for name, arr in O.flatten_params(P64):
+        got = params[H._dev_name(name, False)].reshape(arr.shape).astype(np.float64)
+        if name not in G:
+            np.testing.assert_array_equal(got, before[name], err_msg=name)      # no gradient: untouched
+            continue
+        sure = np.abs(G[name]) > 1e-3 * np.abs(G[name]).max()
+        assert np.abs(got - arr)[sure].max() <= 1e-5, 'configs[4] fp32 param ' + name
+        assert np.abs(got - arr).max() <= 2 * 2e-4 + 1e-6, 'configs[4] fp32 param ' + name
+
+
+def test_config4_as_configured_bf16_step_vs_oracle(gpu):
+    """configs[4] as configured, bf16 MFMA operands with fp32 accumulation, one whole step against
+    the operand-rounding oracle (oracle.set_bf16).  Operand rounding is discontinuous: a 1e-7
+    summation-order difference flips the rounding of a few operands per layer, so two bf16
+    evaluations decorrelate with depth: through 40 blocks forward and back they end up about as far
+    from each other (measured 2.0..2.6e-2 relative L2 at the bottom of the stack, < 1e-2 at the
+    top) as the reference algorithm's own bf16 gradients are from its fp32 ones (2.6e-2 median,
+    measured on the oracle).  Bars: losses within 2e-3 of the bf16 oracle; argmin indices equal up
+    to a stray flip; per tensor, with e_ref = the bf16 oracle's own distance from the fp32 oracle:
+    device-vs-bf16-oracle <= 2 e_ref + 1e-2 (measured: median 1.8e-2, max 6.5e-2 on the encoder
+    below the whole decoder, where e_ref is 5e-2) and device-vs-fp32-truth <= 1.5 e_ref + 1e-2
+    (measured ratio: median 1.00, max 1.18) -- the device's bf16 arithmetic is exactly as good as
+    the reference algorithm on rounded operands; on the path that rounds the same operands
+    (full-rate condition projection) and on the default latent-rate path (which rounds the
+    condition projection's operands at the latent rate instead).  Single kernels in this mode hold 1e-4
+    against the operand-rounding oracle (test_gpu_kernels.py); the same network in fp32 holds the
+    north_star tolerances (above)."""
+    cfg = dict(CFG4)
+    batch = O.synth_batch_raw(1, length=2048, n_speaker=cfg['n_speaker'], seed=19)
+    P, idx_a, l_a, g_a, _, _ = _config4_device_step(gpu, batch, bf16=True, lazy=False)
+    _, idx_b, l_b, g_b, _, _ = _config4_device_step(gpu, batch, bf16=True, lazy=True)
+    P32 = H.build_model(cfg, seed=13, use_logistic=True, tweak=_mol_conditioned)[0]
+    with _limit_blas():
+        _, _, G32 = O.train_step(P32, {}, batch, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+        O.set_bf16(True)
+        try:
+            losses, cache, G16 = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], loss_kind='mol')
+        finally:
+            O.set_bf16(False)
+    assert len(G16) > 300
+    report = {}
     for tag, idx, l_dev, g_dev in (('full-rate', idx_a, l_a, g_a), ('latent-rate', idx_b, l_b, g_b)):
-        # the encoder ahead of the quantiser runs on bf16 operands too: a latent may sit within a
-        # bf16 epsilon of a cell boundary, so allow a stray index flip, no more
         flips = int((idx.reshape(cache['idx'].shape) != cache['idx']).sum())
         assert flips <= max(1, cache['idx'].size // 16), (tag, flips)
         for i, (a, b) in enumerate(zip(l_dev, losses)):
-            assert_close(a, float(b), 2e-3, 'configs[4] %s loss%d' % (tag, i + 1))
-        errs = {name: _rel_l2(g_dev[H._dev_name(name, False)], arr) for name, arr in G.items()}
-        name = max(errs, key=errs.get)
-        worst[tag] = (name, errs[name])
-        assert errs[name] < 3e-2, 'configs[4] %s: grad %s relative L2 error %.3e' % (tag, name, errs[name])
-    print('configs[4] bf16 worst gradient relative L2:', worst)
+            assert_close(a, float(b), 2e-3, 'configs[4] bf16 %s loss%d' % (tag, i + 1))
+        direct, ratios = [], []
+        for name, truth in G32.items():
+            g = g_dev[H._dev_name(name, False)]
+            e_pair = _rel_l2(g, G16[name])
+            e_dev, e_ref = _rel_l2(g, truth), _rel_l2(G16[name], truth)
+            direct.append(e_pair)
+            ratios.append(e_dev / max(e_ref, 1e-12))
+            fails = []
+            if not e_pair <= 2.0 * e_ref + 1e-2:        # two perturbations of size e_ref: sqrt(2) e_ref apart
+                fails.append('configs[4] bf16 %s %s: relative L2 vs the bf16 oracle %.3e' % (tag, name, e_pair))
+            if not e_dev <= 1.5 * e_ref + 1e-2:
+                fails.append('configs[4] bf16 %s %s: device %.3e from the fp32 truth, bf16 oracle %.3e' % (tag, name, e_dev, e_ref))
+            report.setdefault(tag + ' failures', []).extend(fails)
+        report[tag] = dict(vs_bf16_oracle_median=float(np.median(direct)), vs_bf16_oracle_max=float(np.max(direct)),
+                           dist_ratio_median=float(np.median(ratios)), dist_ratio_max=float(np.max(ratios)))
+    print('configs[4] bf16:', report)
+    assert not report['full-rate failures'] and not report['latent-rate failures'], report
 
 
 def test_config4_full_size_properties_bf16(gpu):
