@@ -17,15 +17,18 @@
 #include <stdlib.h>
 #include <math.h>
 #include <vector>
+#include <type_traits>
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int BM = 256, BN = 128, BK = 16, NT = 512;
 
 struct Args {
+  unsigned long long* clk;   // per block: {shader cycles, 100 MHz wall ticks} of the block's lifetime (conv_v1 only)
   const float* x;      // (B, Cin, T)
   const float* wpk;    // packed weights, layout per variant
   float* y;            // (B, 256, T)
   int Cin, T, B, dil, ntile_n;
+  int mode;   // V12 diagnostics: 1 = no A loads, 2 = no B loads, 4 = B always from one L2-resident tile
 };
 
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(1); } } while (0)
@@ -108,10 +111,88 @@ __global__ __launch_bounds__(NT, 2) void conv_v0(const Args a) {
 //       ((((kk2*2 + lk)*2 + wn)*32 + li)*4 + j*2 + ni)  <->  k = 4*kk2 + 2*j + lk, n = wn*64 + 2*li + ni
 //   wpk: [tap][kstep][4096] in the A image order.
 // ------------------------------------------------------------------------------------------------
+// V8: V1 with the global loads issued TWO K steps ahead (two register sets): a load has a whole
+// K step (~3.4 us of wall time on a busy SIMD) more to come back before its ds_write needs it.
+__global__ __launch_bounds__(NT, 2) void conv_v8(const Args a) {
+  __shared__ float4 As[2][BK * BM / 4];
+  __shared__ float4 Bs[2][BK * BN / 4];
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const int v_k = tid >> 5, v_col = (tid & 31) * 4;
+  const int b_kk2 = v_k >> 2, b_j = (v_k >> 1) & 1, b_lk = v_k & 1;
+  const int b_wn = v_col >> 6, b_p = (v_col & 63) >> 1;
+  const int b_dst = ((((b_kk2 * 2 + b_lk) * 2 + b_wn) * 32 + b_p) * 4 + b_j * 2) / 2;
+  float4 ra0[2], ra1[2], rb0[2];
+  auto load = [&](int it, auto setc) {
+    constexpr int set = decltype(setc)::value;
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    ra0[set] = wp[tid];
+    ra1[set] = wp[tid + NT];
+    const int tw = t0 - (1 - tap) * a.dil;
+    rb0[set] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tw >= 0) rb0[set] = *reinterpret_cast<const float4*>(xb + (long)(ks * BK + v_k) * a.T + tw + v_col);
+  };
+  auto store = [&](int buf, auto setc) {
+    constexpr int set = decltype(setc)::value;
+    As[buf][tid] = ra0[set];
+    As[buf][tid + NT] = ra1[set];
+    float2* bd = reinterpret_cast<float2*>(&Bs[buf][0]);
+    bd[b_dst] = make_float2(rb0[set].x, rb0[set].y);
+    bd[b_dst + 2] = make_float2(rb0[set].z, rb0[set].w);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  load(0, I0{}); store(0, I0{});
+  load(1, I1{});
+  __syncthreads();
+  const int fa = ((lk * 4 + wm) * 32 + li);
+  const int fb = ((lk * 2 + wn) * 32 + li);
+  auto step = [&](int it, auto curc) {
+    constexpr int cur = decltype(curc)::value;       // LDS buffer == register set parity
+    // loads for step it+2 go to register set `cur` (its previous content, step it, is already in LDS)
+    if (it + 2 < nk) load(it + 2, curc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 af = As[cur][fa + q * 256];
+      const float4 bf = Bs[cur][fb + q * 128];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.w, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.z, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[1][1], 0, 0, 0);
+    }
+    // step it+1's data sits in register set cur^1 (loaded a whole step ago): to LDS buffer cur^1
+    if (it + 1 < nk) store(cur ^ 1, std::integral_constant<int, cur ^ 1>{});
+    __syncthreads();
+  };
+  for (int it = 0; it < nk; it += 2) {
+    step(it, I0{});
+    if (it + 1 < nk) step(it + 1, I1{});
+  }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      *reinterpret_cast<float2*>(&yb[(long)m * a.T + t0 + wn * 64 + 2 * li]) = make_float2(acc[mi][0][r], acc[mi][1][r]);
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(NT, 2) void conv_v1(const Args a) {
   __shared__ float4 As[2][BK * BM / 4];
   __shared__ float4 Bs[2][BK * BN / 4];
+  const unsigned long long c_beg = clock64(), w_beg = wall_clock64();
   int b, t0; tile_of(a, b, t0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
@@ -163,7 +244,7 @@ __global__ __launch_bounds__(NT, 2) void conv_v1(const Args a) {
   for (int it = 0; it < nk; ++it) {
     const int cur = it & 1;
     const bool more = it + 1 < nk;
-    if (more) {
+    if (more && VAR != 5 && VAR != 6) {
       if (VAR == 4) load_a_lds(it + 1, cur ^ 1);
       load(it + 1);
     }
@@ -209,9 +290,9 @@ __global__ __launch_bounds__(NT, 2) void conv_v1(const Args a) {
       }
       if (VAR == 3) __builtin_amdgcn_s_setprio(0);
     }
-    if (more) store(cur ^ 1);
+    if (more && VAR != 5 && VAR != 6) store(cur ^ 1);
     if (VAR == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (VAR != 6) __syncthreads();
   }
   float* yb = a.y + (long)b * BM * a.T;
 #pragma unroll
@@ -221,6 +302,280 @@ __global__ __launch_bounds__(NT, 2) void conv_v1(const Args a) {
       const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
       *reinterpret_cast<float2*>(&yb[(long)m * a.T + t0 + wn * 64 + 2 * li]) = make_float2(acc[mi][0][r], acc[mi][1][r]);
     }
+  if (tid == 0 && a.clk) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// V9: one persistent workgroup per CU, tile 256 rows x 240 columns on v_mfma_f32_16x16x4_f32.
+// B*T = 122 880 columns = 256 CUs x 2 tiles x 240: every CU does exactly the same work (the
+// 256 x 128 tiling needs 1.875 residency rounds).  8 waves, wave w owns rows [32w, 32w+32) = 2 row
+// tiles x 15 column tiles = 30 accumulators of 4 registers.  A image per K step (fragment order, one
+// ds_read_b128 = 4 k4-steps of one row tile): ((((w*2+mt)*4 + kg)*16 + ml)*4 + s) <-> m = 32w+16mt+ml,
+// k = 4s+kg.  B image: natural [k][240].  PIPE: the next tile's first K step is loaded during the
+// epilogue of the current one.
+// ------------------------------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int BN9 = 240;
+template <bool PIPE>
+__global__ __launch_bounds__(NT, 1) void conv_v9(const Args a) {
+  __shared__ float4 As[2][BK * BM / 4];
+  __shared__ float Bs[2][BK][BN9];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ml = lane & 15, kg = lane >> 4;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const int tiles_per_b = a.T / BN9;
+  const int ntiles = a.B * tiles_per_b;
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int tile_lo = blockIdx.x * per, tile_hi = min(ntiles, tile_lo + per);
+  float4 ra0, ra1, rb0, rb1;
+  const int i0 = tid, i1 = tid + NT;                 // B staging: float4 index in [0, 960)
+  const int r0 = i0 / 60, c0 = (i0 % 60) * 4, r1 = i1 / 60, c1 = (i1 % 60) * 4;
+  const bool ok1 = i1 < BK * BN9 / 4;
+  auto load = [&](int tile, int it) {
+    const int b = tile / tiles_per_b, t0 = (tile % tiles_per_b) * BN9;
+    const float* xb = a.x + (long)b * a.Cin * a.T;
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    ra0 = wp[tid];
+    ra1 = wp[tid + NT];
+    const int tw = t0 - (1 - tap) * a.dil;
+    rb0 = make_float4(0.f, 0.f, 0.f, 0.f); rb1 = rb0;
+    if (tw >= 0) {
+      rb0 = *reinterpret_cast<const float4*>(xb + (long)(ks * BK + r0) * a.T + tw + c0);
+      if (ok1) rb1 = *reinterpret_cast<const float4*>(xb + (long)(ks * BK + r1) * a.T + tw + c1);
+    }
+  };
+  auto store = [&](int buf) {
+    As[buf][tid] = ra0;
+    As[buf][tid + NT] = ra1;
+    *reinterpret_cast<float4*>(&Bs[buf][r0][c0]) = rb0;
+    if (ok1) *reinterpret_cast<float4*>(&Bs[buf][r1][c1]) = rb1;
+  };
+  const int fa = ((wave * 2) * 4 + kg) * 16 + ml;      // float4 index of row tile 0; row tile 1 is +64
+  if (tile_lo < tile_hi) { load(tile_lo, 0); store(0); }
+  __syncthreads();
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    f32x4 acc[2][15];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 15; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = it + 1 < nk;
+      const bool next_tile = PIPE && !more && tile + 1 < tile_hi;
+      if (more) load(tile, it + 1);
+      else if (next_tile) load(tile + 1, 0);
+      const float4 a0 = As[cur][fa], a1 = As[cur][fa + 64];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float av0 = s4 == 0 ? a0.x : s4 == 1 ? a0.y : s4 == 2 ? a0.z : a0.w;
+        const float av1 = s4 == 0 ? a1.x : s4 == 1 ? a1.y : s4 == 2 ? a1.z : a1.w;
+        float bv[15];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) bv[j] = Bs[cur][4 * s4 + kg][16 * j + ml];
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv[j], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv[j], acc[1][j], 0, 0, 0);
+        }
+      }
+      if (more || next_tile) store(cur ^ 1);          // nk is even: the next tile starts in buffer 0 again
+      __syncthreads();
+    }
+    {
+      const int b = tile / tiles_per_b, t0 = (tile % tiles_per_b) * BN9;
+      float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* row = yb + (long)(wave * 32 + mt * 16 + 4 * kg + r) * a.T + t0 + ml;
+#pragma unroll
+          for (int j = 0; j < 15; ++j) row[16 * j] = acc[mt][j][r];
+        }
+    }
+    if (!PIPE && tile + 1 < tile_hi) { load(tile + 1, 0); store(0); __syncthreads(); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V11: the V1 loop as a persistent kernel: 512 workgroups (2 per CU) walk the 960 tiles with stride
+// gridDim.x; the first K step of the next tile is fetched during the last K step of the current one
+// and the epilogue's stores drain behind the next tile's MFMAs, so no CU ever sits in a prologue or
+// epilogue with nothing else to do.  GLDS: A staged by global_load_lds.
+// ------------------------------------------------------------------------------------------------
+template <bool GLDS>
+__global__ __launch_bounds__(NT, 4) void conv_v11(const Args a) {
+  __shared__ float4 As[2][BK * BM / 4];
+  __shared__ float4 Bs[2][BK * BN / 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const int ntiles = a.B * a.ntile_n;
+  const int v_k = tid >> 5, v_col = (tid & 31) * 4;
+  const int b_kk2 = v_k >> 2, b_j = (v_k >> 1) & 1, b_lk = v_k & 1;
+  const int b_wn = v_col >> 6, b_p = (v_col & 63) >> 1;
+  const int b_dst = ((((b_kk2 * 2 + b_lk) * 2 + b_wn) * 32 + b_p) * 4 + b_j * 2) / 2;
+  float4 ra0, ra1, rb0;
+  auto load = [&](int tile, int it, int buf) {
+    const int b = tile / a.ntile_n, t0 = (tile % a.ntile_n) * BN;
+    const float* xb = a.x + (long)b * a.Cin * a.T;
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    if (GLDS) {
+      __builtin_amdgcn_global_load_lds(wp + tid, (__attribute__((address_space(3))) void*)&As[buf][wave * 64], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(wp + tid + NT, (__attribute__((address_space(3))) void*)&As[buf][NT + wave * 64], 16, 0, 0);
+    } else {
+      ra0 = wp[tid];
+      ra1 = wp[tid + NT];
+    }
+    const int tw = t0 - (1 - tap) * a.dil;
+    rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tw >= 0) rb0 = *reinterpret_cast<const float4*>(xb + (long)(ks * BK + v_k) * a.T + tw + v_col);
+  };
+  auto store = [&](int buf) {
+    if (!GLDS) {
+      As[buf][tid] = ra0;
+      As[buf][tid + NT] = ra1;
+    }
+    float2* bd = reinterpret_cast<float2*>(&Bs[buf][0]);
+    bd[b_dst] = make_float2(rb0.x, rb0.y);
+    bd[b_dst + 2] = make_float2(rb0.z, rb0.w);
+  };
+  const int fa = ((lk * 4 + wm) * 32 + li);
+  const int fb = ((lk * 2 + wn) * 32 + li);
+  int tile = blockIdx.x;
+  if (tile < ntiles) { load(tile, 0, 0); store(0); }
+  if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nxt = tile + gridDim.x;
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = it + 1 < nk;
+      const bool fetch = more || nxt < ntiles;
+      if (fetch) load(more ? tile : nxt, more ? it + 1 : 0, cur ^ 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 af = As[cur][fa + q * 256];
+        const float4 bf = Bs[cur][fb + q * 128];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.w, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.z, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[1][1], 0, 0, 0);
+      }
+      if (fetch) store(cur ^ 1);
+      if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const int b = tile / a.ntile_n, t0 = (tile % a.ntile_n) * BN;
+    float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        *reinterpret_cast<float2*>(&yb[(long)m * a.T + t0 + wn * 64 + 2 * li]) = make_float2(acc[mi][0][r], acc[mi][1][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V12: both operands staged by LDS-DMA (global_load_lds_dwordx4) into a 3-stage LDS ring, loads
+// issued TWO K steps ahead, counted vmcnt + raw s_barrier (one per K step), no staging VGPRs and no
+// ds_write at all.  8 waves along M (32 rows each); lane li owns columns 4li..4li+3 of the 128-wide
+// tile, so the B image is the natural [k][128] row-major tile (what LDS-DMA writes) and one
+// ds_read_b128 feeds 4 MFMAs; the A image is fragment-ordered by the pack kernel:
+//   float4 index ((kq*2 + lk)*8 + w)*32 + li, component c  <->  m = 32w+li, k = 2*(4kq+c)+lk.
+// Epilogue: one 16-byte store per accumulator row (512 B contiguous per half wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int STAGE_F4 = (BK * BM + BK * BN) / 4;      // float4 per stage: 1024 (A) + 512 (B)
+// LDS-DMA hidden from hipcc's wait bookkeeping (it would drain vmcnt(0) before every ds_read of the
+// same array): M0 = wave-uniform LDS byte address, every lane supplies its own 16-byte source.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int NSTAGE>
+__global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
+  extern __shared__ float4 lds[];
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const int brow = 2 * wave + lk, bcol = 4 * li;       // this lane's piece of the B tile
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int it, int stage) {
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    const unsigned st = lds_base + (unsigned)(stage * STAGE_F4 + uwave * 64) * 16u;     // wave-uniform byte address
+    if (!(a.mode & 1)) {
+      glds16(wp + wave * 64 + lane, st);
+      glds16(wp + (8 + wave) * 64 + lane, st + 8 * 64 * 16);
+    }
+    const int tw = t0 - (1 - tap) * a.dil;             // the harness only times tiles with tw >= 0 correctly
+    const float* src = ((a.mode & 4) ? a.x : xb) + (long)(ks * BK + brow) * a.T + ((tw >= 0 && !(a.mode & 4)) ? tw : 0) + bcol;
+    if (!(a.mode & 2)) glds16(src, st + 1024 * 16);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  if (a.mode == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (lk * 8 + wave) * 32 + li;            // + kq*512
+  const int fb = 1024 + lk * 32 + li;                  // + kk*64
+  int stage = 0;
+  for (int it = 0; it < nk; ++it) {
+    const bool more = it + 2 < nk;
+    int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
+    if (more) issue(it + 2, s2);
+    const float4* st = lds + stage * STAGE_F4;
+    const float4 a0 = st[fa], a1 = st[fa + 512];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float4 bf = st[fb + kk * 64];
+      const float av = kk == 0 ? a0.x : kk == 1 ? a0.y : kk == 2 ? a0.z : kk == 3 ? a0.w : kk == 4 ? a1.x : kk == 5 ? a1.y : kk == 6 ? a1.z : a1.w;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.w, acc[3], 0, 0, 0);
+    }
+    // step it+1's loads (issued one step ago) must have landed; the 3 just issued may stay in flight
+    if (more && a.mode == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (diagnostic modes issue fewer loads: drain)
+    __builtin_amdgcn_s_barrier();
+    if (++stage >= NSTAGE) stage = 0;
+  }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    *reinterpret_cast<float4*>(&yb[(long)m * a.T + t0 + 4 * li]) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -243,9 +598,36 @@ static void pack_v1(const std::vector<float>& W, int Cin, std::vector<float>& ou
         }
 }
 
+static void pack_v9(const std::vector<float>& W, int Cin, std::vector<float>& out) {
+  out.assign((size_t)2 * Cin * BM, 0.f);
+  const int ksteps = Cin / BK;
+  for (int tap = 0; tap < 2; ++tap)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int w = 0; w < 8; ++w) for (int mt = 0; mt < 2; ++mt) for (int kg = 0; kg < 4; ++kg)
+        for (int ml = 0; ml < 16; ++ml) for (int s4 = 0; s4 < 4; ++s4) {
+          const int k = ks * BK + 4 * s4 + kg, m = 32 * w + 16 * mt + ml;
+          const size_t idx = ((size_t)(tap * ksteps + ks)) * (BK * BM) + (((((w * 2 + mt) * 4 + kg) * 16 + ml) * 4) + s4);
+          out[idx] = W[((size_t)m * Cin + k) * 2 + tap];
+        }
+}
+
+static void pack_v12(const std::vector<float>& W, int Cin, std::vector<float>& out) {
+  out.assign((size_t)2 * Cin * BM, 0.f);
+  const int ksteps = Cin / BK;
+  for (int tap = 0; tap < 2; ++tap)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int kq = 0; kq < 2; ++kq) for (int lk = 0; lk < 2; ++lk) for (int w = 0; w < 8; ++w)
+        for (int li = 0; li < 32; ++li) for (int c = 0; c < 4; ++c) {
+          const int k = ks * BK + 2 * (4 * kq + c) + lk, m = 32 * w + li;
+          const size_t idx = ((size_t)(tap * ksteps + ks)) * (BK * BM) + ((((kq * 2 + lk) * 8 + w) * 32 + li) * 4 + c);
+          out[idx] = W[((size_t)m * Cin + k) * 2 + tap];
+        }
+}
+
 int main(int argc, char** argv) {
-  const int B = 16, T = 7680, Cin = 256;
+  const int B = 16, Cin = 256;
   const int dil = argc > 1 ? atoi(argv[1]) : 64;
+  const int T = argc > 2 ? atoi(argv[2]) : 7680;      // 8192 -> 1024 tiles = exactly two residency rounds
   const int reps = 20;
   std::vector<float> hx((size_t)B * Cin * T), hW((size_t)BM * Cin * 2);
   srand(1);
@@ -254,11 +636,17 @@ int main(int argc, char** argv) {
   float *dx, *dw0, *dw1, *dy;
   CHECK(hipMalloc(&dx, hx.size() * 4)); CHECK(hipMalloc(&dy, (size_t)B * BM * T * 4));
   CHECK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
-  std::vector<float> p0, p1; pack_v0(hW, Cin, p0); pack_v1(hW, Cin, p1);
+  std::vector<float> p0, p1, p9; pack_v0(hW, Cin, p0); pack_v1(hW, Cin, p1); pack_v9(hW, Cin, p9);
+  std::vector<float> p12; pack_v12(hW, Cin, p12);
+  float* dw12; CHECK(hipMalloc(&dw12, p12.size() * 4));
+  CHECK(hipMemcpy(dw12, p12.data(), p12.size() * 4, hipMemcpyHostToDevice));
+  float* dw9; CHECK(hipMalloc(&dw9, p9.size() * 4));
+  CHECK(hipMemcpy(dw9, p9.data(), p9.size() * 4, hipMemcpyHostToDevice));
   CHECK(hipMalloc(&dw0, p0.size() * 4)); CHECK(hipMalloc(&dw1, p1.size() * 4));
   CHECK(hipMemcpy(dw0, p0.data(), p0.size() * 4, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(dw1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice));
-  Args a; a.x = dx; a.y = dy; a.Cin = Cin; a.T = T; a.B = B; a.dil = dil; a.ntile_n = T / BN;
+  unsigned long long* dclk; CHECK(hipMalloc(&dclk, 16 * 4096));
+  Args a; a.mode = 0; a.clk = dclk; a.x = dx; a.y = dy; a.Cin = Cin; a.T = T; a.B = B; a.dil = dil; a.ntile_n = T / BN;
   const int grid = B * (T / BN);
   const double flop = 2.0 * B * T * BM * Cin * 2;
   std::vector<float> hy((size_t)B * BM * T);
@@ -267,7 +655,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(hy.data(), dy, hy.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0;
     for (int s = 0; s < 200; ++s) {
-      const int b = rand() % B, m = rand() % BM, t = (s < 20) ? (s * 7) % 200 : rand() % T;
+      const int b = rand() % B, m = rand() % BM, t = dil + 128 + rand() % (T - dil - 128);   // the harness zero-pads whole tiles
       double ref = 0;
       for (int tap = 0; tap < 2; ++tap) {
         const int ts = t - (1 - tap) * dil;
@@ -279,18 +667,26 @@ int main(int argc, char** argv) {
     }
     printf("  %-4s max |err| on 200 samples: %.3e %s\n", name, worst, worst < 1e-4 ? "ok" : "WRONG");
   };
+  int grid_override = 0;
+  size_t dyn_lds = 0;
   auto run = [&](const char* name, void (*kern)(const Args), const float* w) {
+    if (dyn_lds) CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
     a.wpk = w;
+    const int grid = grid_override ? grid_override : B * (T / BN);
     CHECK(hipMemset(dy, 0, hy.size() * 4));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, 0, a);
+    CHECK(hipMemset(dclk, 0, 16 * 4096));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
     CHECK(hipDeviceSynchronize());
     check(name);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-4s dil %4d: %8.1f us/launch  %6.1f TFLOP/s  (%.3f of 157.3)\n", name, dil, 1e3 * ms / reps, flop / (ms / reps) / 1e9, flop / (ms / reps) / 1e9 / 157.3);
+    std::vector<unsigned long long> hc(2 * grid);
+    CHECK(hipMemcpy(hc.data(), dclk, 16 * grid, hipMemcpyDeviceToHost));
+    double cs = 0, ws = 0; for (int i = 0; i < grid; ++i) { cs += hc[2 * i]; ws += hc[2 * i + 1]; }
+    printf("%-9s dil %4d: %8.1f us/launch  %6.1f TFLOP/s  (%.3f of 157.3)   block life %.1f us, shader clock %.0f MHz\n", name, dil, 1e3 * ms / reps, flop / (ms / reps) / 1e9, flop / (ms / reps) / 1e9 / 157.3, ws / grid / 100.0, ws > 0 ? cs / ws * 100.0 : 0.0);
   };
   for (int round = 0; round < 2; ++round) {
     run("V0", conv_v0, dw0);
@@ -298,6 +694,29 @@ int main(int argc, char** argv) {
     run("V2", conv_v1<2>, dw1);
     run("V3", conv_v1<3>, dw1);
     run("V4", conv_v1<4>, dw1);
+    run("V8", conv_v8, dw1);
+    dyn_lds = 3 * STAGE_F4 * 16;
+    run("V12", conv_v12<3>, dw12);
+    a.mode = 1; run("V12*noA", conv_v12<3>, dw12);
+    a.mode = 2; run("V12*noB", conv_v12<3>, dw12);
+    a.mode = 4; run("V12*B-L2", conv_v12<3>, dw12);
+    a.mode = 3; run("V12*none", conv_v12<3>, dw12);
+    a.mode = 0;
+    dyn_lds = 0;
+    grid_override = 512;
+    run("V11", conv_v11<false>, dw1);
+    run("V11g", conv_v11<true>, dw1);
+    grid_override = 1024;
+    run("V11x", conv_v11<false>, dw1);      // non-persistent launch of the same code (one tile per block)
+    grid_override = 0;
+    if (T % BN9 == 0 && false) {
+      grid_override = 256;
+      run("V9", conv_v9<false>, dw9);
+      run("V9p", conv_v9<true>, dw9);
+      grid_override = 0;
+    }
+    run("V5*", conv_v1<5>, dw1);      // * = not a valid convolution: diagnostic upper bounds
+    run("V6*", conv_v1<6>, dw1);
   }
   return 0;
 }
