@@ -793,7 +793,9 @@ struct WgradArgs {
   int M, Tout, B;
   WSeg seg[MAXSEG]; int nseg;
   int ntile_m, ntile_n;      // ntile_n = total over segments
-  int tchunk, nsplit_t;
+  // split-K over the FLATTENED (batch, time) axis in units of WBK-wide K steps: split s owns global
+  // steps [s*steps_per_split, (s+1)*steps_per_split); a step never straddles two batch items
+  int steps_per_b, steps_per_split, nsplit;
   int avec;                  // host: 16-B row loads of gy are legal
   float* slabs;              // [nsplit][ntile_m][ntile_n][128][128]
   float* bslabs;             // [nsplit][nseg][ntile_m*128]
@@ -816,10 +818,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   const int n0 = (ntg - sg.tile0) * BN;
   const int m0 = mt * BM;
   const int split = blockIdx.y;
-  const int b = split / a.nsplit_t;
-  const int tc = split % a.nsplit_t;
-  const int tbeg = tc * a.tchunk;
-  const int tend = min(a.Tout, tbeg + a.tchunk);
+  const int g0 = split * a.steps_per_split;
+  const int g1 = min(a.B * a.steps_per_b, g0 + a.steps_per_split);
+  int b = g0 / a.steps_per_b;
+  int tb = (g0 - b * a.steps_per_b) * WBK;
+  const int tend = a.Tout;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
@@ -842,6 +845,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
 
   const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride;
   const float* xb = sg.x + (long)b * sg.x_bstride;
+  auto advance = [&]() {            // next K step of the flattened (b, t) axis
+    tb += WBK;
+    if (tb >= tend) { tb = 0; ++b; gyb += a.gy_bstride; xb += sg.x_bstride; }
+  };
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
   const bool avec = a.avec != 0;
   const bool bvec = sg.vec != 0;
@@ -868,13 +875,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
     }
     if (bvec) {
       const int t = tb + v_c4;
-      const int tin = t + sg.toff;                     // tmul == 1, tdiv == 1, toff % 4 == 0
-      const bool ok = t < tend && tin >= 0 && tin < sg.Tin;
+      const int tin = t + sg.toff;                     // tmul == 1, tdiv == 1
+      const bool inb = t < tend;
+      const bool whole = inb && tin >= 0 && tin + 3 < sg.Tin;
+      const bool part = inb && !whole && tin + 3 >= 0 && tin < sg.Tin;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ci = n0 + v_row + 32 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && ci < sg.cin) v = *reinterpret_cast<const float4*>(xb + (long)ci * sg.x_cstride + tin);
+        const float* src = xb + (long)ci * sg.x_cstride + tin;
+        if (ci < sg.cin) {
+          if (whole) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else if (part) {                           // the window crosses the row's first / last sample
+            if (tin >= 0 && tin < sg.Tin) v.x = src[0];
+            if (tin + 1 >= 0 && tin + 1 < sg.Tin) v.y = src[1];
+            if (tin + 2 >= 0 && tin + 2 < sg.Tin) v.z = src[2];
+            if (tin + 3 >= 0 && tin + 3 < sg.Tin) v.w = src[3];
+          }
+        }
         rbv[4 * i] = v.x; rbv[4 * i + 1] = v.y; rbv[4 * i + 2] = v.z; rbv[4 * i + 3] = v.w;
       }
     } else {
@@ -892,8 +911,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
     }
   };
 
-  if (tbeg < tend) load(tbeg);
-  for (int tb = tbeg; tb < tend; tb += WBK) {
+  if (g0 < g1) load(tb);
+  for (int g = g0; g < g1; ++g) {
     __syncthreads();
     if (BF16) {
       // bf16 image, k contiguous: row pitch WPB elements (80 B, 16-byte aligned rows, conflict-optimal
@@ -948,7 +967,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
     }
     }
     __syncthreads();
-    if (tb + WBK < tend) load(tb + WBK);
+    if (g + 1 < g1) { advance(); load(tb); }
     if (BF16) {
 #pragma unroll
       for (int k16 = 0; k16 < WBK / 16; ++k16) {
@@ -1151,10 +1170,12 @@ static PackJob pack_bwd_job(float* dst, const float* W, int Cout, int Cin, int K
   return j;
 }
 
-struct WgradPlan { int ntile_m, ntile_n, nsplit_t, tchunk, nsplit, nseg; size_t slab_floats, bslab_floats; };
+struct WgradPlan { int ntile_m, ntile_n, steps_per_b, steps_per_split, nsplit, nseg; size_t slab_floats, bslab_floats; };
 
-// wgrad_kernel runs 2 workgroups per CU (205 VGPR): 512 resident slots on 256 CUs.
-// Choose the split count so that the grid is just under a whole number of rounds.
+// wgrad_kernel runs 2 workgroups per CU (205 VGPR): 512 resident slots on 256 CUs.  The K axis is
+// the flattened (batch, time) axis cut into WBK-wide steps; choose the number of K splits so that
+// tiles x splits is just under a whole number of residency rounds, with as few splits as that
+// allows (every split costs one 64 KB partial slab per tile, written and re-read by the reduce).
 static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   WgradPlan p;
   p.nseg = nseg;
@@ -1162,32 +1183,33 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   p.ntile_n = 0;
   for (int i = 0; i < nseg; ++i) p.ntile_n += cdiv(cins[i], BN);
   const long tiles = (long)p.ntile_m * p.ntile_n;
-  const long per_t = tiles * B;                 // blocks per time split
-  int maxs = Tout / 128;
+  p.steps_per_b = cdiv(Tout, WBK);
+  const long total_steps = (long)B * p.steps_per_b;
+  long maxs = total_steps / 4;                 // at least 4 K steps (128 positions) per split
   if (maxs < 1) maxs = 1;
-  if (maxs > 32) maxs = 32;
-  // smallest split count whose grid fills >= 92 % of its last residency round
-  // (and at least one full round); otherwise the best fill found
+  if (maxs > 256) maxs = 256;
   const long slots = 512;
-  int want = 1;
+  long want = 1;
   double best = -1.0;
-  for (int w = 1; w <= maxs; ++w) {
-    const long blocks = per_t * w;
+  for (long w = 1; w <= maxs; ++w) {
+    const long sps = (total_steps + w - 1) / w;
+    const long ns = (total_steps + sps - 1) / sps;        // splits actually produced
+    const long blocks = tiles * ns;
     const long rounds = (blocks + slots - 1) / slots;
     const double eff = (double)blocks / (double)(rounds * slots);
     if (eff > best + 1e-9) { best = eff; want = w; }
     if (eff >= 0.92 && blocks >= slots) { want = w; break; }
   }
-  p.tchunk = cdiv(cdiv(Tout, want), WBK) * WBK;
-  p.nsplit_t = cdiv(Tout, p.tchunk);
-  p.nsplit = p.nsplit_t * B;
+  p.steps_per_split = (int)((total_steps + want - 1) / want);
+  p.nsplit = (int)((total_steps + p.steps_per_split - 1) / p.steps_per_split);
   p.slab_floats = (size_t)p.nsplit * p.ntile_m * p.ntile_n * BM * BN;
   p.bslab_floats = (size_t)p.nsplit * nseg * p.ntile_m * BM;
   return p;
 }
 
 static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream_t st) {
-  w.ntile_m = p.ntile_m; w.ntile_n = p.ntile_n; w.tchunk = p.tchunk; w.nsplit_t = p.nsplit_t;
+  w.ntile_m = p.ntile_m; w.ntile_n = p.ntile_n;
+  w.steps_per_b = p.steps_per_b; w.steps_per_split = p.steps_per_split; w.nsplit = p.nsplit;
   w.slabs = ws;
   bool any_b = w.ngbl > 0;
   for (int i = 0; i < w.nseg; ++i) any_b = any_b || w.seg[i].gb || w.seg[i].gb2;
@@ -1196,7 +1218,7 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
   // 16-B row loads: every row start and every chunk start must be 16-B aligned and no float4
   // may straddle a row end
-  bool av = (w.Tout % 4 == 0) && (w.gy_bstride % 4 == 0) && (p.tchunk % 4 == 0);
+  bool av = (w.Tout % 4 == 0) && (w.gy_bstride % 4 == 0);
   for (int i = 0; i < w.nseg; ++i) {
     const float* g = w.seg[i].gy ? w.seg[i].gy : w.gy;
     av = av && (((uintptr_t)g) % 16 == 0);
@@ -1204,9 +1226,10 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   w.avec = av ? 1 : 0;
   for (int i = 0; i < w.nseg; ++i) {
     WSeg& sg = w.seg[i];
-    sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && sg.toff % 4 == 0 && sg.Tin % 4 == 0 &&
-              sg.x_cstride % 4 == 0 && sg.x_bstride % 4 == 0 && w.Tout % 4 == 0 &&
-              p.tchunk % 4 == 0 && ((uintptr_t)sg.x) % 16 == 0) ? 1 : 0;
+    // dwordx4 row loads: global loads only need dword alignment on gfx950, so a shifted window
+    // (toff % 4 != 0: dilations 1 and 2) keeps them; a group that straddles the row's valid range is
+    // fetched element by element inside the kernel
+    sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && w.Tout % 4 == 0) ? 1 : 0;
   }
   ProfScope ps(tag, st);
   if (g_matmul_dtype == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
@@ -1768,4 +1791,48 @@ extern "C" int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x
   wa.seg[0].gb = gbd;
   wa.accumulate = accumulate;
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+}
+
+// gWd_l (+)= sum_{b,t} gh_l[b,:,t] x_l[b,:,t - (K-1-j) dil_l]^T, gbd_l (+)= rowsum(gh_l) for several
+// blocks in ONE launch: every (block, tap) pair is a segment with its own output-gradient tensor,
+// input tensor and time shift, so the K splits (and the partial slabs the reduce re-reads) are
+// shared by nblocks * K * Cr/128 tiles instead of paid per block.
+extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblocks, const int* dils,
+                                        const float* const* x, const float* const* gh,
+                                        float* const* gWd, float* const* gbd, int accumulate,
+                                        void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && nblocks * d->K <= MAXSEG, "resstack_dil_wgrad: nblocks * filter_size must be 1..%d", MAXSEG);
+  VQ_REQUIRE(dils && x && gh && gWd && ws, "resstack_dil_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  const int T = d->T;
+  int cins[MAXSEG];
+  WgradArgs wa; memset(&wa, 0, sizeof(wa));
+  int n = 0;
+  for (int l = 0; l < nblocks; ++l) {
+    VQ_REQUIRE(x[l] && gh[l] && dils[l] >= 1, "resstack_dil_wgrad: bad block %d", l);
+    for (int j = 0; j < d->K; ++j) {
+      WSeg& sg = wa.seg[n];
+      sg.gy = gh[l];
+      sg.x = x[l]; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
+      sg.tmul = 1; sg.toff = -(d->K - 1 - j) * dils[l]; sg.tdiv = 1;
+      sg.gw = gWd[l] ? gWd[l] + j : nullptr; sg.gw_co_stride = (long)d->Cr * d->K; sg.gw_ci_stride = d->K;
+      sg.gb = (j == 0 && gbd) ? gbd[l] : nullptr;
+      cins[n++] = d->Cr;
+    }
+  }
+  WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, n);
+  if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_dil_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
+  wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
+  wa.nseg = n;
+  wa.accumulate = accumulate;
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+}
+
+extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_desc* d, int nblocks) {
+  if (!d || nblocks < 1 || nblocks * d->K > MAXSEG) return 0;
+  int cins[MAXSEG];
+  for (int i = 0; i < nblocks * d->K; ++i) cins[i] = d->Cr;
+  WgradPlan p = plan_wgrad(d->Cd, d->B, d->T, cins, nblocks * d->K);
+  return (p.slab_floats + p.bslab_floats) * sizeof(float) + 256;
 }

@@ -107,6 +107,9 @@ PROTOTYPES = {
                                           c_size_t, P]),
     'vqvae_resstack_res_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, PP, c_int, P,
                                          c_size_t, P]),
+    'vqvae_resstack_dil_wgrad_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
+    'vqvae_resstack_dil_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, C.POINTER(c_int), PP, PP, PP, PP,
+                                         c_int, P, c_size_t, P]),
     'vqvae_vq_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'vqvae_vq_nearest_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P,
                                      c_size_t, P]),

@@ -202,6 +202,14 @@ int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* g_res, const float* const* z,
                              float* const* gWr, float* const* gbr, int accumulate, void* ws,
                              size_t ws_bytes, vqvae_stream_t s);
+/* dilated-conv weight / bias gradients of nblocks blocks (nblocks * K <= 24) in one launch: block l
+ * contributes K segments (x[l] shifted by -(K-1-j)*dils[l], output gradient gh[l]); gWd[l] (Cd,Cr,K),
+ * gbd[l] (Cd) -- NULL entries are skipped.  Workspace from the _workspace_bytes query.            */
+size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_desc* d, int nblocks);
+int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblocks, const int* dils,
+                             const float* const* x, const float* const* gh, float* const* gWd,
+                             float* const* gbd, int accumulate, void* ws, size_t ws_bytes,
+                             vqvae_stream_t s);
 
 /* ---- vector quantiser: StraightThrough.forward / backward (utils.py:176-231).
  *      z (B,d,T) [T contiguous], W (k,d).  idx (B,T) int32 is bit-exact with
