@@ -28,7 +28,8 @@ struct Args {
   const float* wpk;    // packed weights, layout per variant
   float* y;            // (B, 256, T)
   int Cin, T, B, dil, ntile_n;
-  int mode;   // V12 diagnostics: 1 = no A loads, 2 = no B loads, 4 = B always from one L2-resident tile
+  int stagger;   // V12 mode 32: delay (100 MHz ticks) of workgroups 256..511
+  int mode;   // V12 diagnostics: 1 = no A loads, 2 = no B loads, 4 = B always from one L2-resident tile, 8 = no barrier, 16 = no LDS reads
 };
 
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); exit(1); } } while (0)
@@ -516,6 +517,10 @@ template <int NSTAGE>
 __global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
   extern __shared__ float4 lds[];
   int b, t0; tile_of(a, b, t0);
+  if ((a.mode & 32) && blockIdx.x >= 256 && blockIdx.x < 512) {      // stagger the second workgroup of every CU by ~half a tile
+    const unsigned long long w0 = wall_clock64();
+    while (wall_clock64() - w0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
   f32x16 acc[4];
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
   };
   issue(0, 0);
   issue(1, 1);
-  if (a.mode == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if ((a.mode & 31) == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int fa = (lk * 8 + wave) * 32 + li;            // + kq*512
@@ -554,10 +559,12 @@ __global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
     int s2 = stage + 2; if (s2 >= NSTAGE) s2 -= NSTAGE;
     if (more) issue(it + 2, s2);
     const float4* st = lds + stage * STAGE_F4;
-    const float4 a0 = st[fa], a1 = st[fa + 512];
+    float4 a0, a1;
+    if (a.mode & 16) { a0 = make_float4(1.f, 2.f, 3.f, 4.f); a1 = a0; } else { a0 = st[fa]; a1 = st[fa + 512]; }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const float4 bf = st[fb + kk * 64];
+      float4 bf;
+      if (a.mode & 16) bf = make_float4(0.5f, 0.25f, 0.125f, 1.f); else bf = st[fb + kk * 64];
       const float av = kk == 0 ? a0.x : kk == 1 ? a0.y : kk == 2 ? a0.z : kk == 3 ? a0.w : kk == 4 ? a1.x : kk == 5 ? a1.y : kk == 6 ? a1.z : a1.w;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.x, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.y, acc[1], 0, 0, 0);
@@ -565,9 +572,9 @@ __global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
       acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.w, acc[3], 0, 0, 0);
     }
     // step it+1's loads (issued one step ago) must have landed; the 3 just issued may stay in flight
-    if (more && a.mode == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (more && (a.mode & 31) == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (diagnostic modes issue fewer loads: drain)
-    __builtin_amdgcn_s_barrier();
+    if (!(a.mode & 8)) __builtin_amdgcn_s_barrier();
     if (++stage >= NSTAGE) stage = 0;
   }
   float* yb = a.y + (long)b * BM * a.T;
@@ -646,7 +653,7 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(dw0, p0.data(), p0.size() * 4, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(dw1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice));
   unsigned long long* dclk; CHECK(hipMalloc(&dclk, 16 * 4096));
-  Args a; a.mode = 0; a.clk = dclk; a.x = dx; a.y = dy; a.Cin = Cin; a.T = T; a.B = B; a.dil = dil; a.ntile_n = T / BN;
+  Args a; a.mode = 0; a.stagger = 0; a.clk = dclk; a.x = dx; a.y = dy; a.Cin = Cin; a.T = T; a.B = B; a.dil = dil; a.ntile_n = T / BN;
   const int grid = B * (T / BN);
   const double flop = 2.0 * B * T * BM * Cin * 2;
   std::vector<float> hy((size_t)B * BM * T);
@@ -701,6 +708,12 @@ int main(int argc, char** argv) {
     a.mode = 2; run("V12*noB", conv_v12<3>, dw12);
     a.mode = 4; run("V12*B-L2", conv_v12<3>, dw12);
     a.mode = 3; run("V12*none", conv_v12<3>, dw12);
+    a.mode = 3 + 8; run("V12*nobar", conv_v12<3>, dw12);
+    a.mode = 3 + 16; run("V12*nolds", conv_v12<3>, dw12);
+    a.mode = 3 + 8 + 16; run("V12*mfma", conv_v12<3>, dw12);
+    a.mode = 32; a.stagger = 3000; run("V12stg30", conv_v12<3>, dw12);
+    a.mode = 32; a.stagger = 5500; run("V12stg55", conv_v12<3>, dw12);
+    a.mode = 32; a.stagger = 8000; run("V12stg80", conv_v12<3>, dw12);
     a.mode = 0;
     dyn_lds = 0;
     grid_override = 512;
