@@ -35,6 +35,7 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 // v_cvt_pk_bf16_f32) when they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
 // HBM tensors, epilogues and accumulators stay fp32 in both modes.
 static int g_matmul_dtype = 0;
+static int g_wgrad_impl = 0;      // 0: auto; 1: force the generic wgrad_kernel (tests / A-B timing)
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;   // wgrad tiles; conv_gemm derives BM/NT from WM
 constexpr int MAXSEG = 24;   // a whole ResidualNet's blocks can feed one contraction
@@ -776,6 +777,9 @@ __global__ void pack_kernel(const PackArgs pa) {
 // ---------------------------------------------------------------------------
 // bwd-weight: gW[co, (seg,ci)] = sum_{b,t} gy[b,co,t] * x_seg[b,ci,tin(t)]
 // ---------------------------------------------------------------------------
+#ifndef WGRAD_WAVES_PER_EU
+#define WGRAD_WAVES_PER_EU 2
+#endif
 constexpr int WBK = 32, WP = WBK + 1;
 constexpr int WPB = 40;     // bf16 image of the wgrad tiles: 32 k + 8 pad = 80 B per row
 
@@ -804,7 +808,7 @@ struct WgradArgs {
 };
 
 template <bool BF16>
-__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NT, WGRAD_WAVES_PER_EU) void wgrad_kernel(const WgradArgs a) {
   __shared__ float As[BM][WP];
   __shared__ float Bs[BN][WP];
   const int tile = blockIdx.x;
@@ -1033,6 +1037,198 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// wgrad2_kernel -- the fp32 weight-gradient contraction for stride-1 segments (every conv of the
+// decoder): same splits, slabs and fixed-order reduce as wgrad_kernel, rebuilt around 16-byte LDS
+// traffic and 4 waves per SIMD.
+//   * tile (64*WM) x 128 per 128*WM-thread workgroup (WM = 4: 256 x 128, the activation tile is
+//     shared by twice the rows; 2 workgroups = 16 waves per CU), wave tile 64 x 64;
+//   * both operands are K-contiguous in HBM (time is the contraction axis) and stay that way in
+//     LDS: image [row][16 t] filled by dwordx4 row loads + ds_write_b128 -- no transposing scalar
+//     writes.  A lane's MFMA fragment is one ds_read_b128 = 4 consecutive t of its row; the k-th
+//     MFMA of a group takes component k of BOTH operands, i.e. the contraction index is visited
+//     in the order the fragments deliver it (any order is valid as long as A and B agree);
+//   * 16-byte chunk c of row r sits at chunk slot c ^ ((r >> 2) & 3): the 16 lanes one
+//     ds_read_b128 cycle serves ({0-3,12-15,20-27}, ...) land on 16 distinct slots of the 256-B
+//     bank row (conflict-free reads AND writes);
+//   * double-buffered (2 x 24 KB), next step prefetched into registers, ONE barrier per 16-t step
+//     (32 MFMAs per wave), <= 128 VGPRs.
+// ---------------------------------------------------------------------------
+constexpr int W2K = 16;                                   // t per K step
+template <int WM>
+__global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) {
+  constexpr int NT2 = 128 * WM, BM2 = 64 * WM;
+  constexpr int STAGE = (BM2 + BN) * 4;                   // float4 per stage
+  constexpr int NA = BM2 * 4 / NT2, NB = BN * 4 / NT2;    // float4 row loads per thread: 2 and 1 (WM=4) / 2 and 2
+  __shared__ float4 lds[2 * STAGE];
+  const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;       // a.ntile_m counts 128-row slab tiles
+  // XCD-aware order (1-D grid): workgroups that run on one XCD at the same time are consecutive
+  // tiles of ONE split -- the column tiles of a segment pair share their output-gradient rows and
+  // K range, so that operand is fetched into the XCD's L2 once instead of once per column tile
+  int logical;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int ntiles = ntm * a.ntile_n;
+  const int tile = logical % ntiles;
+  const int split = logical / ntiles;
+  const int ntg = tile % a.ntile_n;                        // column tile fastest: neighbours share gy
+  const int mt = tile / a.ntile_n;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i)
+    if (i < a.nseg && ntg >= a.seg[i].tile0) s = i;
+  const WSeg& sg = a.seg[s];
+  const int n0 = (ntg - sg.tile0) * BN;
+  const int m0 = mt * BM2;
+  // K steps of 16 t: two per WBK step of the split plan
+  const int spb = a.steps_per_b * (WBK / W2K);
+  const int g0 = split * a.steps_per_split * (WBK / W2K);
+  const int g1 = min(a.B * spb, g0 + a.steps_per_split * (WBK / W2K));
+  int b = g0 / spb;
+  int tb = (g0 - b * spb) * W2K;
+  const int Tout = a.Tout;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int s_chunk = tid & 3, s_row = tid >> 2;          // staging role: chunk of 4 t, row (+ NT2/4 per extra load)
+  constexpr int RSTEP = NT2 / 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
+
+  const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride + (long)(m0 + s_row) * Tout + 4 * s_chunk;
+  const float* xb = sg.x + (long)b * sg.x_bstride + (long)(n0 + s_row) * sg.x_cstride + 4 * s_chunk + sg.toff;
+  const long a_rstep = (long)RSTEP * Tout, b_rstep = (long)RSTEP * sg.x_cstride;
+  bool a_ok[NA], b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a_ok[i] = (m0 + s_row + RSTEP * i) < a.M;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
+  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
+
+  float4 ra[NA], rb[NB];
+  auto load = [&]() {
+    const int t = tb + 4 * s_chunk;
+    const bool tin_range = t < Tout;                      // Tout % 4 == 0: a group is in or out as a whole
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tin_range && a_ok[i]) ra[i] = *reinterpret_cast<const float4*>(gyb + i * a_rstep + tb);
+    }
+    const int tin = t + sg.toff;
+    const bool whole = tin_range && tin >= 0 && tin + 3 < sg.Tin;
+    const bool part = tin_range && !whole && tin + 3 >= 0 && tin < sg.Tin;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[i]) {
+        const float* src = xb + i * b_rstep + tb;
+        if (whole) {
+          rb[i] = *reinterpret_cast<const float4*>(src);   // dword-aligned dwordx4: fine on gfx950
+        } else if (part) {                                 // the shifted window crosses the row's first / last sample
+          if (tin >= 0 && tin < sg.Tin) rb[i].x = src[0];
+          if (tin + 1 >= 0 && tin + 1 < sg.Tin) rb[i].y = src[1];
+          if (tin + 2 >= 0 && tin + 2 < sg.Tin) rb[i].z = src[2];
+          if (tin + 3 >= 0 && tin + 3 < sg.Tin) rb[i].w = src[3];
+        }
+      }
+    }
+  };
+  auto advance = [&]() {
+    tb += W2K;
+    if (tb >= spb * W2K) { tb = 0; ++b; gyb += a.gy_bstride; xb += sg.x_bstride; }   // same step count per item as the plan
+  };
+  // staging destinations (float4 index inside a stage): row r, chunk c -> r*4 + (c ^ ((r>>2)&3)); the
+  // extra rows are RSTEP (a multiple of 16) further, which leaves the swizzle term unchanged
+  const int st_a = s_row * 4 + (s_chunk ^ ((s_row >> 2) & 3));
+  const int st_b = BM2 * 4 + st_a;
+  auto store = [&](int stage) {
+    float4* base = lds + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      base[st_a + i * RSTEP * 4] = ra[i];
+      bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) base[st_b + i * RSTEP * 4] = rb[i];
+  };
+  // fragment addresses: row = w*64 + t*32 + li, chunk = lk + 2q
+  const int swz = (li >> 2) & 3;
+  const int fa0 = (wm * 64 + li) * 4 + (lk ^ swz), fa1 = (wm * 64 + li) * 4 + ((lk + 2) ^ swz);
+  const int fb0 = BM2 * 4 + (wn * 64 + li) * 4 + (lk ^ swz), fb1 = BM2 * 4 + (wn * 64 + li) * 4 + ((lk + 2) ^ swz);
+
+  if (g0 < g1) { load(); store(0); }
+  __syncthreads();
+  for (int g = g0; g < g1; ++g) {
+    const int cur = (g - g0) & 1;
+    const bool more = g + 1 < g1;
+    if (more) { advance(); load(); }
+    const float4* st = lds + cur * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 a0 = st[q ? fa1 : fa0], a1 = st[(q ? fa1 : fa0) + 128];
+      const float4 b0 = st[q ? fb1 : fb0], b1 = st[(q ? fb1 : fb0) + 128];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab(s): a 256-row tile is two 128-row slab tiles
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int rowb = wm * 64 + mi * 32;                    // wave-uniform
+    const int mt_slab = (m0 + rowb) / BM;
+    if (mt_slab >= a.ntile_m) continue;
+    float* slab = a.slabs + (((long)split * a.ntile_m + mt_slab) * a.ntile_n + ntg) * (BM * BN);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = wn * 64 + ni * 32 + li;
+        slab[row * BN + col] = acc[mi][ni][r];
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 1, 4);
+      v += __shfl_xor(v, 2, 4);
+      const int row = m0 + s_row + RSTEP * i;              // global row
+      if (s_chunk == 0 && row < a.ntile_m * BM)
+        a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
+    }
+  }
+}
+
 // block = (64 outputs) x (4 split groups): each thread sums every 4th split with
 // 4 independent accumulators, then the 4 groups combine through LDS in fixed order.
 // Outputs [0,total) are weight-gradient entries, [total, total + nseg*Mpad) bias entries.
@@ -1231,8 +1427,15 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
     // fetched element by element inside the kernel
     sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && w.Tout % 4 == 0) ? 1 : 0;
   }
+  // fp32, stride-1 segments, 16-B aligned output-gradient rows: the 16-byte-LDS kernel
+  bool fast = (g_matmul_dtype == 0) && av && g_wgrad_impl != 1;
+  for (int i = 0; i < w.nseg; ++i) fast = fast && w.seg[i].tmul == 1 && w.seg[i].tdiv == 1;
   ProfScope ps(tag, st);
-  if (g_matmul_dtype == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
+  if (fast && w.M % 256 == 0) {
+    hipLaunchKernelGGL(wgrad2_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+  } else if (fast) {
+    hipLaunchKernelGGL(wgrad2_kernel<2>, dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+  } else if (g_matmul_dtype == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
   const long total = (long)p.ntile_m * BM * p.ntile_n * BN + (long)p.nseg * p.ntile_m * BM;
@@ -1253,6 +1456,11 @@ extern "C" int vqvae_set_matmul_dtype(int dtype) {
   return 0;
 }
 extern "C" int vqvae_get_matmul_dtype(void) { return vq::g_matmul_dtype; }
+extern "C" int vqvae_set_wgrad_impl(int impl) {
+  VQ_REQUIRE(impl == 0 || impl == 1, "set_wgrad_impl: 0 (auto) or 1 (generic kernel)");
+  vq::g_wgrad_impl = impl;
+  return 0;
+}
 
 // ---------------------------------------------------------------------------
 // C ABI: generic conv1d

@@ -87,6 +87,7 @@ PROTOTYPES = {
     'vqvae_prof_read': (c_int, [c_int, C.POINTER(c_double), C.POINTER(c_int)]),
     'vqvae_set_matmul_dtype': (c_int, [c_int]),
     'vqvae_get_matmul_dtype': (c_int, []),
+    'vqvae_set_wgrad_impl': (c_int, [c_int]),
     'vqvae_conv1d_workspace_bytes': (c_size_t, [C.POINTER(Conv1dDesc)]),
     'vqvae_conv1d_fwd': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, P]),
     'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),

@@ -88,6 +88,9 @@ int vqvae_prof_read(int tag, double* total_ms, int* launches);
  *      Tensors in HBM, biases, gates, losses, optimizer and the vector quantiser stay fp32.     */
 int vqvae_set_matmul_dtype(int dtype);
 int vqvae_get_matmul_dtype(void);
+/* weight-gradient kernel choice: 0 = automatic (the 16-byte-LDS fp32 kernel where it applies),
+ * 1 = always the generic kernel (A/B checks) */
+int vqvae_set_wgrad_impl(int impl);
 
 /* ---- generic 1-D convolution == chainer L.Convolution2D / L.DilatedConvolution2D
  *      with ksize=(K,1), stride=(s,1), pad=(p,0), dilate=(d,1)

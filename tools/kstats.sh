@@ -17,7 +17,7 @@ grep "^{" /tmp/b.log | tail -1 | python -c "import json,sys; d=json.loads(sys.st
 t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python - "$t" <<'PY'
 import csv, sys, collections
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'conv_gemm_kernel<0, 4' in r['Kernel_Name'] or 'wgrad_kernel' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'conv_gemm_kernel<0, 4' in r['Kernel_Name'] or 'wgrad' in r['Kernel_Name']]
 h = collections.defaultdict(list)
 for r in rows:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
