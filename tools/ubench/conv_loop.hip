@@ -11,7 +11,19 @@
 //   V2  V1 with the fragment reads split in two halves (16 fragment registers)
 //   V3  V1 + s_setprio(1) around the MFMA block
 //   V4  V1 with A staged by global_load_lds (no VGPRs, no ds_write for A)
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 conv_loop.hip -o conv_loop ; run: ./conv_loop [dil]
+//   V5*/V6*  diagnostic upper bounds (no global traffic / no barrier): not valid convolutions
+//   V8  register prefetch two K steps ahead (hipcc serialises it with vmcnt(0): slower)
+//   V11 persistent 2-workgroup/CU walk over the tiles (spills at 128 VGPRs: slower)
+//   V12 LDS-DMA (global_load_lds_dwordx4 in inline asm) 3-stage ring, 8 waves along M, float4 epilogue;
+//       modes isolate the cost of the A / B load streams, the barrier and the LDS reads
+//   V13 one 4-wave workgroup per CU, 256 x 256 tile, fragments prefetched across k-pairs and stages
+//       (DISABLED by default: intermittently wrong results -- a race we did not resolve -- and no faster)
+//   V14 V13's in-wave pipelining with two 4-wave workgroups per CU (256 x 128 tiles)
+// Measured on MI355X (T = 7680, dil 64; run-to-run +-3 %): V0 108-113, V1/V2 108-112, V4 112-114,
+// V12 109-113, V14 112 TFLOP/s; V5* 125-132, V12 without loads 123-126, MFMA only (no LDS, no barrier,
+// no loads) 127-136; exactly two residency rounds (T = 8192) +4 %.  Every load stream costs ~4-6 %
+// whether it comes from HBM or from L2; latency hiding (distance-2 prefetch, LDS-DMA) changes nothing.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 conv_loop.hip -o conv_loop ; run: ./conv_loop [dil] [T]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -586,6 +598,177 @@ __global__ __launch_bounds__(NT, 4) void conv_v12(const Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// V13: ONE workgroup of 4 waves per CU (one wave per SIMD, 512 registers each), tile 256 x 256, wave
+// tile 128 x 128 = 16 accumulators: 16 MFMAs per pair of ds_read_b128, 16 KB of operands per MFLOP
+// (24 in the 256 x 128 tiling).  3-stage LDS-DMA ring; the fragments of the next k-pair -- and, at
+// the end of a K step, of the NEXT stage -- are read before the current MFMAs are issued, so the
+// single wave of a SIMD never waits on LDS and the per-step barrier only covers write-after-read.
+//   A image per K step: float4 ((kk*2+lk)*2 + wm)*32 + li, component i <-> m = 128wm + 32i + li, k = 2kk+lk
+//   B image per K step: natural [16 k][256 columns]; lane li owns columns 128wn + 4li .. +3
+// ------------------------------------------------------------------------------------------------
+constexpr int BN13 = 256, NT13 = 256, STAGE13_F4 = (BK * BM + BK * BN13) / 4;     // 2048 float4 = 32 KB
+__global__ __launch_bounds__(NT13, 1) void conv_v13(const Args a) {
+  extern __shared__ float4 lds[];
+  const int tiles_per_b = a.T / BN13;
+  int logical;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int b = logical / tiles_per_b, t0 = (logical % tiles_per_b) * BN13;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int it, int stage) {
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    const unsigned st = lds_base + (unsigned)(stage * STAGE13_F4) * 16u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)                            // A: 16 pieces of 1 KB, 4 per wave
+      glds16(wp + (i * 4 + wave) * 64 + lane, st + (unsigned)((i * 4 + uwave) * 64) * 16u);
+    const int tw = t0 - (1 - tap) * a.dil;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // B: 16 rows of 1 KB, 4 per wave
+      const int row = i * 4 + wave;
+      const float* src = xb + (long)(ks * BK + row) * a.T + (tw >= 0 ? tw : 0) + 4 * lane;
+      glds16(src, st + (unsigned)(1024 + (i * 4 + uwave) * 64) * 16u);
+    }
+  };
+  issue(0, 0);
+  issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int fa = (lk * 2 + wm) * 32 + li;                  // + kk*128
+  const int fb = 1024 + lk * 64 + wn * 32 + li;            // + kk*128
+  float4 ca = lds[fa], cb = lds[fb];                        // fragments of (stage 0, kk 0)
+  int stage = 0;
+  for (int it = 0; it < nk; ++it) {
+    int s1 = stage + 1; if (s1 >= 3) s1 -= 3;
+    int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
+    if (it + 2 < nk) issue(it + 2, s2);
+    const float4* st = lds + stage * STAGE13_F4;
+    const float4* sn = lds + s1 * STAGE13_F4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float4 na, nb;
+      if (kk < 7) { na = st[fa + (kk + 1) * 128]; nb = st[fb + (kk + 1) * 128]; }
+      else { na = sn[fa]; nb = sn[fb]; }                   // first fragments of the next K step (junk after the last)
+      const float av[4] = {ca.x, ca.y, ca.z, ca.w};
+      const float bv[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      ca = na; cb = nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage it+2 has landed (issued a whole K step ago)
+    __builtin_amdgcn_s_barrier();                          // ... for everyone; and stage `stage` is free to be refilled
+    stage = s1;
+  }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      *reinterpret_cast<float4*>(&yb[(long)m * a.T + t0 + wn * 128 + 4 * li]) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V14: V13's in-wave pipelining with TWO independent workgroups per CU: 4 waves each (2 per SIMD,
+// 256 registers), tile 256 x 128, wave tile 128 x 64 = 8 accumulators; lane li owns columns
+// 64wn + 2li, +1 (one ds_read_b64 per k-pair), A fragment as in V13.  3-stage ring of 24 KB.
+// ------------------------------------------------------------------------------------------------
+constexpr int STAGE14_F4 = (BK * BM + BK * BN) / 4;      // 1536 float4 = 24 KB
+__global__ __launch_bounds__(256, 2) void conv_v14(const Args a) {
+  extern __shared__ float4 lds[];
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int it, int stage) {
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    const unsigned st = lds_base + (unsigned)(stage * STAGE14_F4) * 16u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)                            // A: 16 KB, 4 pieces per wave
+      glds16(wp + (i * 4 + wave) * 64 + lane, st + (unsigned)((i * 4 + uwave) * 64) * 16u);
+    const int tw = t0 - (1 - tap) * a.dil;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                          // B: 16 rows of 512 B = 8 pieces, 2 per wave (2 rows each)
+      const int row = (i * 4 + wave) * 2 + lk;
+      const float* src = xb + (long)(ks * BK + row) * a.T + (tw >= 0 ? tw : 0) + 4 * li;
+      glds16(src, st + (unsigned)(1024 + (i * 4 + uwave) * 64) * 16u);
+    }
+  };
+  issue(0, 0);
+  issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float2* lds2 = reinterpret_cast<const float2*>(lds);
+  const int fa = (lk * 2 + wm) * 32 + li;                  // float4 index, + kk*128
+  const int fb = 2 * 1024 + lk * 64 + wn * 32 + li;        // float2 index, + kk*128
+  float4 ca = lds[fa];
+  float2 cb = lds2[fb];
+  int stage = 0;
+  for (int it = 0; it < nk; ++it) {
+    int s1 = stage + 1; if (s1 >= 3) s1 -= 3;
+    int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
+    if (it + 2 < nk) issue(it + 2, s2);
+    const float4* st = lds + stage * STAGE14_F4;
+    const float4* sn = lds + s1 * STAGE14_F4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float4 na; float2 nb;
+      if (kk < 7) { na = st[fa + (kk + 1) * 128]; nb = reinterpret_cast<const float2*>(st)[fb + (kk + 1) * 128]; }
+      else { na = sn[fa]; nb = reinterpret_cast<const float2*>(sn)[fb]; }
+      const float av[4] = {ca.x, ca.y, ca.z, ca.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cb.x, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], cb.y, acc[i][1], 0, 0, 0);
+      }
+      ca = na; cb = nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage = s1;
+  }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      *reinterpret_cast<float2*>(&yb[(long)m * a.T + t0 + wn * 64 + 2 * li]) = make_float2(acc[i][0][r], acc[i][1][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 static void pack_v0(const std::vector<float>& W, int Cin, std::vector<float>& out) {   // W[m][ci][tap]
   out.assign((size_t)2 * Cin * BM, 0.f);
   for (int tap = 0; tap < 2; ++tap)
@@ -631,6 +814,19 @@ static void pack_v12(const std::vector<float>& W, int Cin, std::vector<float>& o
         }
 }
 
+static void pack_v13(const std::vector<float>& W, int Cin, std::vector<float>& out) {
+  out.assign((size_t)2 * Cin * BM, 0.f);
+  const int ksteps = Cin / BK;
+  for (int tap = 0; tap < 2; ++tap)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int kk = 0; kk < 8; ++kk) for (int lk = 0; lk < 2; ++lk) for (int wm = 0; wm < 2; ++wm)
+        for (int li = 0; li < 32; ++li) for (int i = 0; i < 4; ++i) {
+          const int k = ks * BK + 2 * kk + lk, m = 128 * wm + 32 * i + li;
+          const size_t idx = ((size_t)(tap * ksteps + ks)) * (BK * BM) + ((((kk * 2 + lk) * 2 + wm) * 32 + li) * 4 + i);
+          out[idx] = W[((size_t)m * Cin + k) * 2 + tap];
+        }
+}
+
 int main(int argc, char** argv) {
   const int B = 16, Cin = 256;
   const int dil = argc > 1 ? atoi(argv[1]) : 64;
@@ -644,6 +840,9 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&dx, hx.size() * 4)); CHECK(hipMalloc(&dy, (size_t)B * BM * T * 4));
   CHECK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   std::vector<float> p0, p1, p9; pack_v0(hW, Cin, p0); pack_v1(hW, Cin, p1); pack_v9(hW, Cin, p9);
+  std::vector<float> p13; pack_v13(hW, Cin, p13);
+  float* dw13; CHECK(hipMalloc(&dw13, p13.size() * 4));
+  CHECK(hipMemcpy(dw13, p13.data(), p13.size() * 4, hipMemcpyHostToDevice));
   std::vector<float> p12; pack_v12(hW, Cin, p12);
   float* dw12; CHECK(hipMalloc(&dw12, p12.size() * 4));
   CHECK(hipMemcpy(dw12, p12.data(), p12.size() * 4, hipMemcpyHostToDevice));
@@ -674,7 +873,7 @@ int main(int argc, char** argv) {
     }
     printf("  %-4s max |err| on 200 samples: %.3e %s\n", name, worst, worst < 1e-4 ? "ok" : "WRONG");
   };
-  int grid_override = 0;
+  int grid_override = 0, nt_override = 0;
   size_t dyn_lds = 0;
   auto run = [&](const char* name, void (*kern)(const Args), const float* w) {
     if (dyn_lds) CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
@@ -682,12 +881,12 @@ int main(int argc, char** argv) {
     const int grid = grid_override ? grid_override : B * (T / BN);
     CHECK(hipMemset(dy, 0, hy.size() * 4));
     CHECK(hipMemset(dclk, 0, 16 * 4096));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt_override ? nt_override : NT), dyn_lds, 0, a);
     CHECK(hipDeviceSynchronize());
     check(name);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(nt_override ? nt_override : NT), dyn_lds, 0, a);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), dyn_lds, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(nt_override ? nt_override : NT), dyn_lds, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> hc(2 * grid);
@@ -702,6 +901,14 @@ int main(int argc, char** argv) {
     run("V3", conv_v1<3>, dw1);
     run("V4", conv_v1<4>, dw1);
     run("V8", conv_v8, dw1);
+    if (T % BN13 == 0 && getenv("CONV_LOOP_V13")) {
+      dyn_lds = 3 * STAGE13_F4 * 16; grid_override = B * (T / BN13); nt_override = NT13;
+      run("V13", conv_v13, dw13);
+      grid_override = 0; nt_override = 0;
+    }
+    dyn_lds = 3 * STAGE14_F4 * 16; nt_override = 256;
+    run("V14", conv_v14, dw13);
+    nt_override = 0;
     dyn_lds = 3 * STAGE_F4 * 16;
     run("V12", conv_v12<3>, dw12);
     a.mode = 1; run("V12*noA", conv_v12<3>, dw12);
