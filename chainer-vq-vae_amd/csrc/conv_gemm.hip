@@ -22,6 +22,7 @@
 //   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A^T
 //                           slabs the GEMM wants ([k][m], m contiguous, zero padded).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace vq {
@@ -76,6 +77,13 @@ struct GemmArgs {
   int B;
   int ntile_m, ntile_n;
   OutR out[2];
+  // split-K (EPI_LINEAR, 128-row tiles, fp32): a latent-rate GEMM has a handful of output tiles
+  // and a long contraction (the condition gradient: 32 tiles, K = 5120), so ksplit > 1 workgroups
+  // share a tile, each over ksteps_per_split K steps, writing raw partial tiles to `partial`
+  // ([split][tile][128][128]); gemm_splitk_reduce_kernel sums them in split order and applies
+  // the epilogue.
+  int ksplit, ksteps_per_split;
+  float* partial;
 };
 
 // Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error
@@ -129,8 +137,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
     const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
-  const int mt = logical % a.ntile_m;
-  const int rest = logical / a.ntile_m;
+  const int ntiles_all = a.ntile_m * a.ntile_n * a.B;
+  const int ksp = (EPI == EPI_LINEAR && WM == 2 && !BF16 && a.ksplit > 1) ? logical / ntiles_all : 0;
+  const int tile_id = (EPI == EPI_LINEAR && WM == 2 && !BF16 && a.ksplit > 1) ? logical % ntiles_all : logical;
+  const int mt = tile_id % a.ntile_m;
+  const int rest = tile_id / a.ntile_m;
   const int nt = rest % a.ntile_n;
   const int b = rest / a.ntile_n;
   const int m0 = mt * BM, t0 = nt * BN;
@@ -353,13 +364,23 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
     };
 
     int s = 0, c0 = 0;
-    load_tiles(s, c0);
-    store_tiles(0);
+    int it_beg = 0, it_end = nk;
+    if (EPI == EPI_LINEAR && a.ksplit > 1) {          // this workgroup's share of the K steps
+      it_beg = ksp * a.ksteps_per_split;
+      it_end = min(nk, it_beg + a.ksteps_per_split);
+      int skip = it_beg;
+      while (s < a.nseg) {
+        const int steps = (a.seg[s].cin + BK - 1) / BK;
+        if (skip < steps) { c0 = skip * BK; break; }
+        skip -= steps; ++s;
+      }
+    }
+    if (it_beg < it_end) { load_tiles(s, c0); store_tiles(0); }
     __syncthreads();
 
-    for (int it = 0; it < nk; ++it) {
-      const int cur = it & 1;
-      const bool more = (it + 1) < nk;
+    for (int it = it_beg; it < it_end; ++it) {
+      const int cur = (it - it_beg) & 1;
+      const bool more = (it + 1) < it_end;
       if (more) {
         c0 += BK;
         if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
@@ -491,6 +512,17 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   // ---- epilogue ----------------------------------------------------------
   // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int T = a.Tout;
+  if (EPI == EPI_LINEAR && WM == 2 && !BF16 && a.ksplit > 1) {
+    float* pt = a.partial + ((long)ksp * ntiles_all + tile_id) * (128 * 128);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pt[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 128 + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+    return;
+  }
   if (EPI == EPI_LINEAR) {
     // ---- interior tiles: software-pipelined epilogue --------------------------------------------
     // VMEM operations retire through one in-order counter, so "load sub-tile q+1, then store
@@ -1307,6 +1339,49 @@ static bool seg_vec_ok(const Seg& s) {
          (((uintptr_t)s.x) % 16 == 0);
 }
 
+// sums the split-K partial tiles in split order and applies the linear epilogue
+// (bias, residual add, accumulate, relu) of conv_gemm_kernel<EPI_LINEAR>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs a) {
+  const int ntiles_all = a.ntile_m * a.ntile_n * a.B;
+  const long total = (long)ntiles_all * (128 * 128);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % (128 * 128));
+    const int tile_id = (int)(i / (128 * 128));
+    const int mt = tile_id % a.ntile_m;
+    const int rest = tile_id / a.ntile_m;
+    const int nt = rest % a.ntile_n, b = rest / a.ntile_n;
+    const int m = mt * 128 + e / 128, t = nt * 128 + e % 128;
+    if (m >= a.M || t >= a.Tout) continue;
+    float v = 0.f;
+    for (int s = 0; s < a.ksplit; ++s) v += a.partial[((long)s * ntiles_all + tile_id) * (128 * 128) + e];
+    const int o = (a.out[1].y != nullptr && m >= a.out[0].rows) ? 1 : 0;
+    const OutR& od = a.out[o];
+    const int mr = o ? m - a.out[0].rows : m;
+    const long off = (long)mr * a.Tout + t;
+    if (od.bias) v += od.bias[mr];
+    if (od.add) v += od.add[(long)b * od.add_bstride + off];
+    float* yp = od.y + (long)b * od.y_bstride + off;
+    if (od.accumulate) v += *yp;
+    if (od.relu) v = fmaxf(v, 0.f);
+    *yp = v;
+  }
+}
+
+// split-K plan for a small-grid, long-K linear GEMM (see GemmArgs::ksplit); 1 = no split
+static int plan_ksplit(int M, int Tout, int B, int nk) {
+  if (g_matmul_dtype != 0 || M % 256 == 0) return 1;
+  const long tiles = (long)cdiv(M, 128) * cdiv(Tout, BN) * B;
+  if (tiles > 128 || nk < 32) return 1;
+  long s = 512 / tiles;                     // fill ~half the chip's 1024 slots
+  if (s > nk / 8) s = nk / 8;               // at least 8 K steps per split
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : (int)s;
+}
+static size_t ksplit_partial_floats(int M, int Tout, int B, int nk) {
+  const int s = plan_ksplit(M, Tout, B, nk);
+  return s > 1 ? (size_t)s * cdiv(M, 128) * cdiv(Tout, BN) * B * 128 * 128 : 0;
+}
+
 template <int EPI>
 static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   const bool big = (g.M % 256 == 0) && (EPI != EPI_GATE_BWD);    // 256-row tiles (8 waves)
@@ -1319,16 +1394,37 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if (EPI == EPI_LINEAR && g.out[1].y == nullptr) g.out[0].rows = g.M;
   const long nblk = (long)g.ntile_m * g.ntile_n * g.B;
   if (nblk <= 0) return 0;
+  static const bool trace = getenv("VQVAE_TRACE_GEMM") != nullptr;
+  if (trace && nblk <= 64) {
+    int ktot = 0; for (int i = 0; i < g.nseg; ++i) ktot += g.seg[i].cin;
+    fprintf(stderr, "[gemm] epi %d M %d Tout %d B %d nseg %d K %d blocks %ld tag %d tmul %d tdiv %d\n", EPI, g.M, g.Tout, g.B, g.nseg, ktot, nblk, tag, g.seg[0].tmul, g.seg[0].tdiv);
+  }
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
+  // split-K when the caller provided a partial-tile buffer and the shape calls for it
+  int nk = 0;
+  for (int i = 0; i < g.nseg; ++i) nk += cdiv(g.seg[i].cin, BK);
+  g.ksplit = 1;
+  if (EPI == EPI_LINEAR && !big && g.partial != nullptr) {
+    const int sp = plan_ksplit(g.M, g.Tout, g.B, nk);
+    if (sp > 1) { g.ksplit = sp; g.ksteps_per_split = cdiv(nk, sp); }
+  }
+  const long grid = nblk * g.ksplit;
   ProfScope ps(tag, st);
   if (g_matmul_dtype == 1) {
     if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, true>), dim3((unsigned)nblk), dim3(256), 0, st, g);
   } else {
     if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)nblk), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
   }
   VQ_LAUNCH_CHECK();
+  if (g.ksplit > 1) {
+    const long total = nblk * 128 * 128;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, g);
+    VQ_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -1488,7 +1584,11 @@ extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
   WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K < MAXTAPS ? d->K : MAXTAPS);
   size_t wg = (p.slab_floats + p.bslab_floats) * sizeof(float);
   size_t pk = conv_pack_floats(d) * sizeof(float);
-  return align_up(wg > pk ? wg : pk, 256) + 256;
+  // forward / backward-data may split K: packed weights first, then the partial tiles
+  size_t pf = ksplit_partial_floats(d->Cout, d->Tout, d->B, d->K * cdiv(d->Cin, BK));
+  size_t pb = ksplit_partial_floats(d->Cin, d->Tin, d->B, d->K * cdiv(d->Cout, BK));
+  size_t gm = align_up(pk, 256) + (pf > pb ? pf : pb) * sizeof(float);
+  return align_up(wg > gm ? wg : gm, 256) + 256;
 }
 
 extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
@@ -1514,6 +1614,11 @@ extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, cons
   g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
   g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
   g.out[0].bias = b; g.out[0].relu = d->relu;
+  {
+    const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
+    const size_t need = ksplit_partial_floats(d->Cout, d->Tout, d->B, d->K * cdiv(d->Cin, BK)) * sizeof(float);
+    if (need > 0 && pkb + need <= ws_bytes) g.partial = (float*)((char*)ws + pkb);
+  }
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_FWD, st);
 }
 
@@ -1541,6 +1646,11 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
   g.M = d->Cin; g.Tout = d->Tin; g.B = d->B;
   g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;
   g.out[0].accumulate = accumulate;
+  {
+    const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
+    const size_t need = ksplit_partial_floats(d->Cin, d->Tin, d->B, d->K * cdiv(d->Cout, BK)) * sizeof(float);
+    if (need > 0 && pkb + need <= ws_bytes) g.partial = (float*)((char*)ws + pkb);
+  }
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_BWD_DATA, st);
 }
 

@@ -31,6 +31,9 @@ CONV_CASES = [
     (1, 192, 130, 256, 1, 1, 0, 1, None),    # condition_proj
     (2, 40, 77, 50, 3, 2, 2, 3, None),       # everything odd
     (1, 16, 7, 20, 4, 2, 1, 1, None),        # tiny T
+    (2, 1280, 120, 192, 1, 1, 0, 1, None),   # few output tiles, long K: fwd takes the split-K path
+    (2, 192, 120, 1280, 1, 1, 0, 1, None),   # ... and here bwd-data does (the latent-rate condition gradient)
+    (3, 520, 90, 70, 3, 1, 2, 2, None),      # split-K with ragged channels, taps and a partial last split
 ]
 
 

@@ -17,12 +17,12 @@ grep "^{" /tmp/b.log | tail -1 | python -c "import json,sys; d=json.loads(sys.st
 t=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python - "$t" <<'PY'
 import csv, sys, collections
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'conv_gemm_kernel<0, 4' in r['Kernel_Name'] or 'wgrad' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 h = collections.defaultdict(list)
 for r in rows:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     h[(r['Kernel_Name'][:34], r['Grid_Size_X'], r.get('Grid_Size_Y'))].append(d)
-for k, v in sorted(h.items(), key=lambda kv: -sum(kv[1])):
+for k, v in sorted(h.items(), key=lambda kv: -sum(kv[1]))[:32]:
     print(k, 'n/step %.1f' % (len(v) / 13), 'avg %.1f us' % (sum(v) / len(v)), 'ms/step %.2f' % (sum(v) / 13 / 1e3))
 PY
 python - "$t" <<'PY'
