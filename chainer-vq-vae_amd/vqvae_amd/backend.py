@@ -135,6 +135,14 @@ def device_info():
 
 # --------------------------------------------------------------------------- #
 # caching allocator: exact-size free lists (a training step repeats its sizes)
+#
+# INVARIANT (stream safety).  A block returns to the pool when the last Python reference to it
+# drops -- not when the GPU work that uses it has finished.  That is safe on ONE stream (a later
+# user of the block is enqueued behind the earlier one).  Work on the side / pool streams must
+# therefore keep every operand referenced until a join event on the main stream has been
+# enqueued AFTER it: ResidualStackFunction.backward holds gh / saved activations / scratch in
+# locals until its final wait_event; generation.run_many synchronises around its launches.  A
+# new side-stream use that frees a temporary earlier would corrupt memory silently.
 # --------------------------------------------------------------------------- #
 def _round(nbytes):
     return max(256, (nbytes + 255) // 256 * 256)
