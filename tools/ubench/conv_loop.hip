@@ -19,6 +19,7 @@
 //   V13 one 4-wave workgroup per CU, 256 x 256 tile, fragments prefetched across k-pairs and stages
 //       (DISABLED by default: intermittently wrong results -- a race we did not resolve -- and no faster)
 //   V14 V13's in-wave pipelining with two 4-wave workgroups per CU (256 x 128 tiles)
+//   V15 V12 with a dedicated loader wave (9 waves; waves 0-7 issue no VMEM at all): 93 TFLOP/s, slower
 // Measured on MI355X (T = 7680, dil 64; run-to-run +-3 %): V0 108-113, V1/V2 108-112, V4 112-114,
 // V12 109-113, V14 112 TFLOP/s; V5* 125-132, V12 without loads 123-126, MFMA only (no LDS, no barrier,
 // no loads) 127-136; exactly two residency rounds (T = 8192) +4 %.  Every load stream costs ~4-6 %
@@ -769,6 +770,79 @@ __global__ __launch_bounds__(256, 2) void conv_v14(const Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// V15: V12 with a dedicated LOADER wave: 9 waves per workgroup, waves 0-7 only ds_read + MFMA, wave 8
+// issues every LDS-DMA piece of the K step (16 A + 8 B) and is the only wave with VMEM instructions
+// in the loop -- tests whether the load cost is VMEM issue inside the MFMA waves' instruction streams.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(576, 5) void conv_v15(const Args a) {
+  extern __shared__ float4 lds[];
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const bool loader = __builtin_amdgcn_readfirstlane(wave) == 8;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)lds;
+  auto issue = [&](int it, int stage) {                    // loader wave only: the whole stage
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    const unsigned st = lds_base + (unsigned)(stage * STAGE_F4) * 16u;
+    const float4* ap = wp + lane;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) { glds16(ap, st + (unsigned)(i * 64) * 16u); ap += 64; }
+    const int tw = t0 - (1 - tap) * a.dil;
+    const float* src = xb + (long)(ks * BK + lk) * a.T + (tw >= 0 ? tw : 0) + 4 * li;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) { glds16(src, st + (unsigned)(1024 + i * 64) * 16u); src += 2L * a.T; }
+  };
+  if (loader) {
+    issue(0, 0); issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int it = 0; it < nk; ++it) {
+      int s2 = stage + 2; if (s2 >= 3) s2 -= 3;
+      if (it + 2 < nk) { issue(it + 2, s2); asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (++stage >= 3) stage = 0;
+    }
+    return;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  __builtin_amdgcn_s_barrier();
+  const int fa = (lk * 8 + wave) * 32 + li;
+  const int fb = 1024 + lk * 32 + li;
+  int stage = 0;
+  for (int it = 0; it < nk; ++it) {
+    const float4* st = lds + stage * STAGE_F4;
+    const float4 a0 = st[fa], a1 = st[fa + 512];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float4 bf = st[fb + kk * 64];
+      const float av = kk == 0 ? a0.x : kk == 1 ? a0.y : kk == 2 ? a0.z : kk == 3 ? a0.w : kk == 4 ? a1.x : kk == 5 ? a1.y : kk == 6 ? a1.z : a1.w;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf.w, acc[3], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (++stage >= 3) stage = 0;
+  }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    *reinterpret_cast<float4*>(&yb[(long)m * a.T + t0 + 4 * li]) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static void pack_v0(const std::vector<float>& W, int Cin, std::vector<float>& out) {   // W[m][ci][tap]
   out.assign((size_t)2 * Cin * BM, 0.f);
   for (int tap = 0; tap < 2; ++tap)
@@ -906,6 +980,8 @@ int main(int argc, char** argv) {
       run("V13", conv_v13, dw13);
       grid_override = 0; nt_override = 0;
     }
+    dyn_lds = 3 * STAGE_F4 * 16; nt_override = 576;
+    run("V15", conv_v15, dw12);
     dyn_lds = 3 * STAGE14_F4 * 16; nt_override = 256;
     run("V14", conv_v14, dw13);
     nt_override = 0;
