@@ -117,14 +117,46 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
   const int rows = B * C;
   const bool vec = (Tout % 4 == 0) && (gy_bstride % 4 == 0) && (((uintptr_t)gy) % 16 == 0) &&
                    (((uintptr_t)w0) % 16 == 0) && (((uintptr_t)w1) % 16 == 0);
+  const int n4 = Tout >> 2;
+  // Pipelined form (a whole row fits one pass of 8 float4 per thread): the workgroups are
+  // persistent (2 per CU) and the NEXT row's loads are in flight while the current row is summed,
+  // so a row costs max(load, sum) instead of load + sum + a workgroup launch.
+  const bool pipe = vec && n4 <= 256 * 8;
+  float4 v[8];
+  auto fetch = [&](int r) {
+    const int b = r / C, c = r % C;
+    const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int q = k * 256 + threadIdx.x;
+      v[k] = q < n4 ? reinterpret_cast<const float4*>(g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&]() {          // products of the fetched row -> LDS (same roundings as the scalar form)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int q = k * 256 + threadIdx.x;
+      if (q < n4) {
+        const int t = q << 2;
+        const float4 a = reinterpret_cast<const float4*>(w0)[q];
+        const float4 bq = reinterpret_cast<const float4*>(w1)[q];
+        const int o = t + (t >> 5);          // 4 consecutive t never straddle a 32-block
+        r0[o] = __fmul_rn(v[k].x, a.x); r0[o + 1] = __fmul_rn(v[k].y, a.y);
+        r0[o + 2] = __fmul_rn(v[k].z, a.z); r0[o + 3] = __fmul_rn(v[k].w, a.w);
+        r1[o] = __fmul_rn(v[k].x, bq.x); r1[o + 1] = __fmul_rn(v[k].y, bq.y);
+        r1[o + 2] = __fmul_rn(v[k].z, bq.z); r1[o + 3] = __fmul_rn(v[k].w, bq.w);
+      }
+    }
+  };
+  if (pipe && blockIdx.x < rows) fetch(blockIdx.x);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int b = r / C, c = r % C;
     const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
     __syncthreads();
-    if (vec) {     // 16-B loads, eight in flight per thread before the first LDS write
-      const int n4 = Tout >> 2;
+    if (pipe) {
+      stage();
+    } else if (vec) {     // 16-B loads, eight in flight per thread before the first LDS write
       for (int base = 0; base < n4; base += 256 * 8) {
-        float4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int q = base + k * 256 + threadIdx.x;
@@ -147,18 +179,19 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
       }
     } else {
       for (int t = threadIdx.x; t < Tout; t += 256) {
-        const float v = g[t];
-        r0[t + (t >> 5)] = __fmul_rn(v, w0[t]);
-        r1[t + (t >> 5)] = __fmul_rn(v, w1[t]);
+        const float vv = g[t];
+        r0[t + (t >> 5)] = __fmul_rn(vv, w0[t]);
+        r1[t + (t >> 5)] = __fmul_rn(vv, w1[t]);
       }
     }
     __syncthreads();
+    if (pipe && r + (int)gridDim.x < rows) fetch(r + gridDim.x);      // in flight during the sums below
     for (int i = threadIdx.x; i < 2 * Tin; i += 256) {
       const int part = i >= Tin ? 1 : 0;
-      const int v = part ? i - Tin : i;
+      const int vi = part ? i - Tin : i;
       const float* rr = part ? r1 : r0;
-      const int lo = part ? lo1[v] : lo0[v];
-      const int hi = part ? hi1[v] : hi0[v];
+      const int lo = part ? lo1[vi] : lo0[vi];
+      const int hi = part ? hi1[vi] : hi0[vi];
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       int t = lo;
       for (; t + 3 < hi; t += 4) {
@@ -168,11 +201,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
         a3 += (double)rr[t + 3 + ((t + 3) >> 5)];
       }
       for (; t < hi; ++t) a0 += (double)rr[t + (t >> 5)];
-      ps[part * Tin + v] = (a0 + a1) + (a2 + a3);
+      ps[part * Tin + vi] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < Tin; v += 256)
-      gx[(long)b * gx_bstride + (long)c * Tin + v] = (float)(ps[v] + ps[Tin + v]);
+    for (int vi = threadIdx.x; vi < Tin; vi += 256)
+      gx[(long)b * gx_bstride + (long)c * Tin + vi] = (float)(ps[vi] + ps[Tin + vi]);
   }
 }
 
@@ -513,6 +546,8 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
   if (lds <= 96 * 1024) {
     int nb = B * C;
     if (nb > 8192) nb = 8192;
+    const bool pipe = (Tout % 4 == 0) && (Tout / 4 <= 256 * 8);
+    if (pipe && nb > 512) nb = 512;            // persistent: 2 workgroups per CU, next row prefetched
     VQ_CHECK_HIP(hipFuncSetAttribute((const void*)upsample_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   } else {
