@@ -1,4 +1,4 @@
-"""LogReport / PrintReport of the reference's trainer wiring (train.py:135-140), SURVEY.md 8f row 4.
+"""LogReport / PrintReport / PlotReport of the reference's trainer wiring (train.py:135-149), SURVEY.md 8f row 4.
 
 The model reports ``loss1 / loss2 / loss3 / loss`` under the observer prefix ``main/`` on every
 call (net.py:93-95); Chainer's ``LogReport(trigger=params.report_interval)`` averages every
@@ -105,3 +105,61 @@ class PrintReport(object):
             cells.append(('' if v is None else ('%d' % v if isinstance(v, int) else '%.6g' % v)).ljust(n))
         self.out.write('  '.join(cells) + '\n')
         self.out.flush()
+
+
+class PlotReport(object):
+    """extensions.PlotReport(y_keys, x_key, file_name=...) (train.py:141-149: loss1.png, loss2.png,
+    loss3.png with the train and validation curves over the iteration).  Call with the LogReport
+    after each interval: ``plot(log)`` redraws ``<out>/<file_name>`` from ``log.log``.  Like
+    Chainer's, it needs matplotlib (Agg backend) and only warns when that is missing."""
+
+    _warned = False
+
+    def __init__(self, y_keys, x_key='iteration', file_name='plot.png', out=None):
+        self.y_keys = [y_keys] if isinstance(y_keys, str) else list(y_keys)
+        self.x_key = x_key
+        self.file_name = file_name
+        self.out = out
+
+    @staticmethod
+    def available():
+        try:
+            import matplotlib  # noqa: F401
+            return True
+        except ImportError:
+            return False
+
+    def __call__(self, log):
+        entries = log.log if hasattr(log, 'log') else list(log)
+        out = self.out if self.out is not None else getattr(log, 'out', None)
+        if out is None or not entries:
+            return None
+        if not self.available():
+            if not PlotReport._warned:
+                sys.stderr.write('PlotReport: matplotlib is not installed, no plots are written\n')
+                PlotReport._warned = True
+            return None
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+        fig = plt.figure()
+        ax = fig.add_subplot(1, 1, 1)
+        ax.set_xlabel(self.x_key)
+        ax.grid(True)
+        for key in self.y_keys:
+            pts = [(e[self.x_key], e[key]) for e in entries if key in e and self.x_key in e]
+            if pts:
+                ax.plot([p[0] for p in pts], [p[1] for p in pts], marker='x', label=key)
+        if ax.has_data():
+            ax.legend(loc='best')
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, self.file_name)
+        fig.savefig(path)
+        plt.close(fig)
+        return path
+
+
+def reference_plots(out=None):
+    """The three PlotReports of train.py:141-149."""
+    return [PlotReport(['main/loss%d' % i, 'validation/main/loss%d' % i], 'iteration',
+                       file_name='loss%d.png' % i, out=out) for i in (1, 2, 3)]

@@ -371,3 +371,28 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     import vqvae_amd.backend as backend
     if not backend.available():
         assert out.returncode != 0                  # no GPU here: the ranks fail loudly, so does the parent
+
+
+def test_plot_report_writes_the_three_loss_pngs(tmp_path):
+    """train.py:141-149: loss1.png / loss2.png / loss3.png with the train and validation curves."""
+    from vqvae_amd.reporting import LogReport, PlotReport, reference_plots
+    if not PlotReport.available():
+        pytest.skip('matplotlib is not installed (PlotReport then only warns, as Chainer does)')
+
+    class Upd(object):
+        iteration = 0
+    log = LogReport(trigger=10, out=str(tmp_path))
+    upd = Upd()
+    for it in range(1, 31):
+        upd.iteration = it
+        obs = {'main/loss1': 5.5 - 0.1 * it, 'main/loss2': 1.0 / it, 'main/loss3': 0.25 / it}
+        if it % 10 == 0:
+            obs.update({'validation/main/loss1': 5.6 - 0.1 * it, 'validation/main/loss2': 1.1 / it,
+                        'validation/main/loss3': 0.3 / it})
+        log(upd, obs)
+    paths = [p(log) for p in reference_plots()]
+    assert [os.path.basename(p) for p in paths] == ['loss1.png', 'loss2.png', 'loss3.png']
+    for p in paths:
+        with open(p, 'rb') as f:
+            assert f.read(8) == b'\x89PNG\r\n\x1a\n'
+        assert os.path.getsize(p) > 2000
