@@ -1707,6 +1707,10 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   L.p_r = plan_wgrad(d->Cr, d->B, d->T, cz, 1);
   L.p_s = plan_wgrad(d->Cs, d->B, d->T, cz, 1);
   size_t sl = L.p_h.slab_floats + L.p_h.bslab_floats;
+  {   // without a condition tensor the same launch has K segments: its plan may need MORE splits
+    WgradPlan pk = plan_wgrad(d->Cd, d->B, d->T, cins, d->K);
+    if (pk.slab_floats + pk.bslab_floats > sl) sl = pk.slab_floats + pk.bslab_floats;
+  }
   size_t s2 = L.p_r.slab_floats + L.p_r.bslab_floats;
   size_t s3 = L.p_s.slab_floats + L.p_s.bslab_floats;
   if (s2 > sl) sl = s2;
@@ -1951,10 +1955,15 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
   size_t gc_pk = (size_t)nblocks * pad16(d->Cd) * pad128(d->Cc);
   int cz[MAXSEG];
   for (int i = 0; i < nblocks; ++i) cz[i] = Ch;
-  WgradPlan p = plan_wgrad(d->Cs, d->B, d->T, cz, nblocks);
-  WgradPlan p2 = plan_wgrad(d->Cr, d->B, d->T, cz, nblocks);
-  size_t wg = p.slab_floats + p.bslab_floats;
-  if (p2.slab_floats + p2.bslab_floats > wg) wg = p2.slab_floats + p2.bslab_floats;
+  // the res-conv gradients skip blocks without a residual output (the last one), and the split
+  // count -- hence the slab volume -- is not monotonic in the segment count: cover every count
+  size_t wg = 0;
+  for (int n = 1; n <= nblocks; ++n) {
+    WgradPlan p = plan_wgrad(d->Cs, d->B, d->T, cz, n);
+    WgradPlan p2 = plan_wgrad(d->Cr, d->B, d->T, cz, n);
+    if (p.slab_floats + p.bslab_floats > wg) wg = p.slab_floats + p.bslab_floats;
+    if (p2.slab_floats + p2.bslab_floats > wg) wg = p2.slab_floats + p2.bslab_floats;
+  }
   size_t m = skip_pk > gc_pk ? skip_pk : gc_pk;
   if (wg > m) m = wg;
   return m * sizeof(float) + 1024;
@@ -2151,6 +2160,10 @@ extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_
   if (!d || nblocks < 1 || nblocks * d->K > MAXSEG) return 0;
   int cins[MAXSEG];
   for (int i = 0; i < nblocks * d->K; ++i) cins[i] = d->Cr;
-  WgradPlan p = plan_wgrad(d->Cd, d->B, d->T, cins, nblocks * d->K);
-  return (p.slab_floats + p.bslab_floats) * sizeof(float) + 256;
+  size_t need = 0;             // any group of 1..nblocks blocks may be flushed; fewer tiles can mean more splits
+  for (int n = 1; n <= nblocks; ++n) {
+    WgradPlan p = plan_wgrad(d->Cd, d->B, d->T, cins, n * d->K);
+    if (p.slab_floats + p.bslab_floats > need) need = p.slab_floats + p.bslab_floats;
+  }
+  return need * sizeof(float) + 256;
 }

@@ -442,3 +442,52 @@ def test_device_input_pipeline_from_waveforms_golden(gpu):
         np.testing.assert_array_equal(x_dec.get()[i], g['mulaw_%s_x_dec' % name][:, :, 0].argmax(axis=0))
         np.testing.assert_array_equal(t.get()[i], g['mulaw_%s_t' % name])
     assert x_dec.get()[0, -1] == 128 and t.get()[0, -1, 0] == 128       # zero padding == bin quantize//2
+
+
+def test_resstack_workspace_queries_cover_every_group_size(gpu):
+    """Regression: the split-K plan (hence the partial-slab volume) is not monotonic in the number
+    of segments of a batched weight-gradient launch, and callers flush groups of any size up to
+    the queried one (the last block has no residual gradient; a stack of 6 blocks flushes 5 + 1).
+    With EXACTLY the queried workspace every group size must run and give the right gradients
+    (shape of BASELINE configs[0]: B = 1, T = 7680)."""
+    import ctypes as C
+    from vqvae_amd import _lib
+    from vqvae_amd.backend import DeviceArray
+    B, T, Cr, Cd, Cs, Cc, K = 1, 7680, 256, 256, 256, 192, 2
+    Ch = Cd // 2
+    d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, 1)
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    nb = 20
+    z = [gpu.to_device((rs.standard_normal((B, Ch, T)) * 0.5).astype(np.float32)) for _ in range(2)]
+    g = [gpu.to_device(rs.standard_normal((B, Cr, T)).astype(np.float32)) for _ in range(2)]
+    zh, gh = [a.get() for a in z], [a.get() for a in g]
+    ws = DeviceArray((lib.vqvae_resstack_workspace_bytes(C.byref(d), nb) // 4 + 1,), np.float32)
+    for n in (20, 19, 7, 1):
+        gW = [DeviceArray((Cr, Ch), np.float32) for _ in range(n)]
+        gb = [DeviceArray((Cr,), np.float32) for _ in range(n)]
+        _lib.call('vqvae_resstack_res_wgrad', C.byref(d), n, _lib.ptr_array([g[i % 2] for i in range(n)]),
+                  _lib.ptr_array([z[i % 2] for i in range(n)]), _lib.ptr_array(gW), _lib.ptr_array(gb), 0,
+                  ws.ptr, ws.nbytes, gpu.stream())
+        for i in (0, n - 1):
+            want = np.einsum('bot,bit->oi', gh[i % 2].astype(np.float64), zh[i % 2].astype(np.float64))
+            assert_close_scaled(gW[i].get(), want, 1e-4, 'res wgrad, group of %d, block %d' % (n, i))
+            assert_close_scaled(gb[i].get(), gh[i % 2].sum(axis=(0, 2), dtype=np.float64), 1e-4, 'gb')
+    # dilated-conv gradients: groups of 1..5 blocks with the workspace queried for 5
+    x = gpu.to_device(rs.standard_normal((B, Cr, T)).astype(np.float32))
+    ghd = gpu.to_device(rs.standard_normal((B, Cd, T)).astype(np.float32))
+    xh, ghh = x.get(), ghd.get()
+    ws2 = DeviceArray((lib.vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d), 5) // 4 + 1,), np.float32)
+    for n in (5, 3, 1):
+        dils = (C.c_int * n)(*[2 ** i for i in range(n)])
+        gW = [DeviceArray((Cd, Cr, K), np.float32) for _ in range(n)]
+        gb = [DeviceArray((Cd,), np.float32) for _ in range(n)]
+        _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), n, dils, _lib.ptr_array([x] * n),
+                  _lib.ptr_array([ghd] * n), _lib.ptr_array(gW), _lib.ptr_array(gb), 0, ws2.ptr,
+                  ws2.nbytes, gpu.stream())
+        i = n - 1
+        dil = 2 ** i
+        xs = np.zeros_like(xh); xs[:, :, dil:] = xh[:, :, :-dil]              # tap 0 sees x[t - dil]
+        want = np.stack([np.einsum('bot,bit->oi', ghh.astype(np.float64), xs.astype(np.float64)),
+                         np.einsum('bot,bit->oi', ghh.astype(np.float64), xh.astype(np.float64))], axis=2)
+        assert_close_scaled(gW[i].get(), want, 1e-4, 'dilated wgrad, group of %d' % n)
