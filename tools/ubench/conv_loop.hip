@@ -19,6 +19,7 @@
 //   V13 one 4-wave workgroup per CU, 256 x 256 tile, fragments prefetched across k-pairs and stages
 //       (DISABLED by default: intermittently wrong results -- a race we did not resolve -- and no faster)
 //   V14 V13's in-wave pipelining with two 4-wave workgroups per CU (256 x 128 tiles)
+//   V16 V11 without spills (buffer-resource stores): persistent 107-109, the same code one tile per workgroup 107-109
 //   V15 V12 with a dedicated loader wave (9 waves; waves 0-7 issue no VMEM at all): 93 TFLOP/s, slower
 // Measured on MI355X (T = 7680, dil 64; run-to-run +-3 %): V0 108-113, V1/V2 108-112, V4 112-114,
 // V12 109-113, V14 112 TFLOP/s; V5* 125-132, V12 without loads 123-126, MFMA only (no LDS, no barrier,
@@ -843,6 +844,95 @@ __global__ __launch_bounds__(576, 5) void conv_v15(const Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// V16: V11 again (persistent workgroups, next tile's first K step fetched during the last K step of
+// the current tile, stores draining behind the next tile's MFMAs) with a register-lean epilogue:
+// buffer-resource stores (SGPR base + one VGPR lane offset + SGPR row offset) instead of 32 64-bit
+// store addresses per lane, so the kernel fits 128 VGPRs without spilling.
+// ------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc16_t;
+__global__ __launch_bounds__(NT, 4) void conv_v16(const Args a) {
+  __shared__ float4 As[2][BK * BM / 4];
+  __shared__ float4 Bs[2][BK * BN / 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int ksteps = a.Cin / BK;
+  const int nk = 2 * ksteps;
+  const int ntiles = a.B * a.ntile_n;
+  const int v_k = tid >> 5, v_col = (tid & 31) * 4;
+  const int b_kk2 = v_k >> 2, b_j = (v_k >> 1) & 1, b_lk = v_k & 1;
+  const int b_wn = v_col >> 6, b_p = (v_col & 63) >> 1;
+  const int b_dst = ((((b_kk2 * 2 + b_lk) * 2 + b_wn) * 32 + b_p) * 4 + b_j * 2) / 2;
+  float4 ra0, ra1, rb0;
+  auto load = [&](int tile, int it) {
+    const int b = tile / a.ntile_n, t0 = (tile % a.ntile_n) * BN;
+    const float* xb = a.x + (long)b * a.Cin * a.T;
+    const int tap = it / ksteps, ks = it % ksteps;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpk) + ((long)(tap * ksteps + ks)) * (BK * BM / 4);
+    ra0 = wp[tid];
+    ra1 = wp[tid + NT];
+    const int tw = t0 - (1 - tap) * a.dil;
+    rb0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tw >= 0) rb0 = *reinterpret_cast<const float4*>(xb + (long)(ks * BK + v_k) * a.T + tw + v_col);
+  };
+  auto store = [&](int buf) {
+    As[buf][tid] = ra0;
+    As[buf][tid + NT] = ra1;
+    float2* bd = reinterpret_cast<float2*>(&Bs[buf][0]);
+    bd[b_dst] = make_float2(rb0.x, rb0.y);
+    bd[b_dst + 2] = make_float2(rb0.z, rb0.w);
+  };
+  const int fa = ((lk * 4 + wm) * 32 + li);
+  const int fb = ((lk * 2 + wn) * 32 + li);
+  // lane part of every store address: row 4*lk (+ the r-dependent rows through the SGPR offset), column pair 2*li
+  const unsigned voff = 4u * (unsigned)((wm * 64 + 4 * lk) * a.T + wn * 64 + 2 * li);
+  int tile = blockIdx.x;
+  if (tile < ntiles) { load(tile, 0); store(0); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nxt = tile + gridDim.x;
+    for (int it = 0; it < nk; ++it) {
+      const int cur = it & 1;
+      const bool more = it + 1 < nk;
+      const bool fetch = more || nxt < ntiles;
+      if (fetch) load(more ? tile : nxt, more ? it + 1 : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 af = As[cur][fa + q * 256];
+        const float4 bf = Bs[cur][fb + q * 128];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.w, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.z, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[1][1], 0, 0, 0);
+      }
+      if (fetch) store(cur ^ 1);
+      __syncthreads();
+    }
+    const int b = __builtin_amdgcn_readfirstlane(tile / a.ntile_n);
+    const int t0 = __builtin_amdgcn_readfirstlane((tile % a.ntile_n) * BN);
+    const rsrc16_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y + (long)b * BM * a.T + t0, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned soff = 4u * (unsigned)((mi * 32 + (r & 3) + 8 * (r >> 2)) * a.T);
+        const float2 v = make_float2(acc[mi][0][r], acc[mi][1][r]);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), ry, voff, soff, 0);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static void pack_v0(const std::vector<float>& W, int Cin, std::vector<float>& out) {   // W[m][ci][tap]
   out.assign((size_t)2 * Cin * BM, 0.f);
   for (int tap = 0; tap < 2; ++tap)
@@ -999,6 +1089,10 @@ int main(int argc, char** argv) {
     a.mode = 32; a.stagger = 8000; run("V12stg80", conv_v12<3>, dw12);
     a.mode = 0;
     dyn_lds = 0;
+    grid_override = 512;
+    run("V16", conv_v16, dw1);
+    grid_override = 960;
+    run("V16x", conv_v16, dw1);       // same code, one tile per workgroup
     grid_override = 512;
     run("V11", conv_v11<false>, dw1);
     run("V11g", conv_v11<true>, dw1);
