@@ -34,6 +34,10 @@ CONV_CASES = [
     (2, 1280, 120, 192, 1, 1, 0, 1, None),   # few output tiles, long K: fwd takes the split-K path
     (2, 192, 120, 1280, 1, 1, 0, 1, None),   # ... and here bwd-data does (the latent-rate condition gradient)
     (3, 520, 90, 70, 3, 1, 2, 2, None),      # split-K with ragged channels, taps and a partial last split
+    (2, 40, 76, 50, 3, 1, 2, 2, None),       # wgrad2_kernel<2>: ragged rows and columns, T % 16 != 0
+    (3, 130, 64, 300, 2, 1, 1, 1, 64),       # wgrad2_kernel<2>: three 128-row tiles, the last one ragged
+    (2, 96, 20, 256, 1, 1, 0, 1, None),      # wgrad2_kernel<4>: 256 rows, fewer positions than one K step pair
+    (1, 256, 1000, 512, 2, 1, 3, 3, 1000),   # wgrad2_kernel<4>: two 256-row tiles, shifted window (dilation 3)
 ]
 
 
