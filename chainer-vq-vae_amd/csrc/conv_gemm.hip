@@ -84,6 +84,10 @@ struct GemmArgs {
   // the epilogue.
   int ksplit, ksteps_per_split;
   float* partial;
+  // device-side conditional launch: when non-null and *skip_flag != 0 every workgroup returns at
+  // once (the one-hot embed conv launches its gather form and this dense form; a flag computed on
+  // the device picks one of them without a host round trip)
+  const int32_t* skip_flag;
 };
 
 // Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error
@@ -127,6 +131,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   constexpr int BM = 64 * WM, NT = 128 * WM;
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
 
   // ---- XCD-aware tile order: consecutive logical tiles (which share the same
   // activation window across their M tiles) land on the same XCD / L2. -------
@@ -837,12 +842,14 @@ struct WgradArgs {
   float* bslabs;             // [nsplit][nseg][ntile_m*128]
   float* gbl[MAXSEG]; int ngbl;   // further copies of segment 0's bias grad (shared gy, many layers)
   int accumulate;
+  const int32_t* skip_flag;       // see GemmArgs::skip_flag
 };
 
 template <bool BF16>
 __global__ __launch_bounds__(NT, WGRAD_WAVES_PER_EU) void wgrad_kernel(const WgradArgs a) {
   __shared__ float As[BM][WP];
   __shared__ float Bs[BN][WP];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const int tile = blockIdx.x;
   const int mt = tile % a.ntile_m;
   const int ntg = tile / a.ntile_m;
@@ -1093,6 +1100,7 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
   constexpr int STAGE = (BM2 + BN) * 4;                   // float4 per stage
   constexpr int NA = BM2 * 4 / NT2, NB = BN * 4 / NT2;    // float4 row loads per thread: 2 and 1 (WM=4) / 2 and 2
   __shared__ float4 lds[2 * STAGE];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;       // a.ntile_m counts 128-row slab tiles
   // XCD-aware order (1-D grid): workgroups that run on one XCD at the same time are consecutive
   // tiles of ONE split -- the column tiles of a segment pair share their output-gradient rows and
@@ -1266,6 +1274,7 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // Outputs [0,total) are weight-gradient entries, [total, total + nseg*Mpad) bias entries.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
   __shared__ float red[4][64];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const long ncol = (long)a.ntile_n * BN;
   const long total = (long)a.ntile_m * BM * ncol;
   const long mpad = (long)a.ntile_m * BM;
@@ -1342,6 +1351,7 @@ static bool seg_vec_ok(const Seg& s) {
 // sums the split-K partial tiles in split order and applies the linear epilogue
 // (bias, residual add, accumulate, relu) of conv_gemm_kernel<EPI_LINEAR>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs a) {
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const int ntiles_all = a.ntile_m * a.ntile_n * a.B;
   const long total = (long)ntiles_all * (128 * 128);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1594,6 +1604,12 @@ extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
 extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
                                 const float* b, float* y, void* ws, size_t ws_bytes,
                                 vqvae_stream_t s) {
+  return vqvae_conv1d_fwd_cond(d, x, W, b, y, ws, ws_bytes, nullptr, s);
+}
+
+extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                                     const float* b, float* y, void* ws, size_t ws_bytes,
+                                     const int32_t* skip_flag, vqvae_stream_t s) {
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(x && W && y && ws, "conv1d_fwd: null pointer");
   hipStream_t st = (hipStream_t)s;
@@ -1614,6 +1630,7 @@ extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, cons
   g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
   g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
   g.out[0].bias = b; g.out[0].relu = d->relu;
+  g.skip_flag = skip_flag;
   {
     const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
     const size_t need = ksplit_partial_floats(d->Cout, d->Tout, d->B, d->K * cdiv(d->Cin, BK)) * sizeof(float);
@@ -1657,6 +1674,13 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
 extern "C" int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                                        float* gW, float* gb, int accumulate, void* ws,
                                        size_t ws_bytes, vqvae_stream_t s) {
+  return vqvae_conv1d_bwd_weight_cond(d, x, gy, gW, gb, accumulate, ws, ws_bytes, nullptr, s);
+}
+
+extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                                            float* gW, float* gb, int accumulate, void* ws,
+                                            size_t ws_bytes, const int32_t* skip_flag,
+                                            vqvae_stream_t s) {
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(x && gy && gW && ws, "conv1d_bwd_weight: null pointer");
   hipStream_t st = (hipStream_t)s;
@@ -1674,6 +1698,7 @@ extern "C" int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* 
     sg.gw = gW + j; sg.gw_co_stride = (long)d->Cin * d->K; sg.gw_ci_stride = d->K;
   }
   w.seg[0].gb = gb; w.accumulate = accumulate;
+  w.skip_flag = skip_flag;
   return launch_wgrad(w, p, (float*)ws, VQVAE_PROF_CONV_WGRAD, st);
 }
 

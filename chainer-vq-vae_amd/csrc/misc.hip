@@ -437,7 +437,9 @@ __global__ void onehot_kernel(const int32_t* __restrict__ idx, long idx_bstride,
 // sum_tap W[co, idx[b, t-(K-1-tap)], tap]   (zero for negative times; modules.py:127-128,151-152)
 __global__ void embed_gather_kernel(const int32_t* __restrict__ idx, long idx_bstride, int B, int T,
                                     const float* __restrict__ W, const float* __restrict__ bias,
-                                    int Cout, int q, int K, float* __restrict__ y) {
+                                    int Cout, int q, int K, float* __restrict__ y,
+                                    const int32_t* __restrict__ run_flag) {
+  if (run_flag != nullptr && *run_flag == 0) return;      // device-side conditional launch
   const long total = (long)B * Cout * T;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
@@ -453,6 +455,243 @@ __global__ void embed_gather_kernel(const int32_t* __restrict__ idx, long idx_bs
       if (ti >= 0) acc = __fadd_rn(acc, wc[(long)ib[ti] * K + tap]);
     }
     y[i] = bias ? __fadd_rn(acc, bias[co]) : acc;
+  }
+}
+
+// ---- the decoder's embed conv on a ONE-HOT input (modules.py:127-128, 151-152; utils.py:85-87) ----
+// The reference feeds the 256-channel one-hot tensor through a dense conv: 2*B*T*Cout*q*K FLOP of
+// multiplications by zero, forward and again in the weight gradient.  onehot_scan_kernel recovers the
+// class index of every column and proves (or refutes) on the device that the tensor is exactly
+// one-hot; the gather / bincount forms below and the dense kernels are then both launched, each
+// guarded by the flag, so the choice needs no host round trip and a non-one-hot input silently
+// takes the dense path.
+__global__ __launch_bounds__(256) void onehot_scan_kernel(const float* __restrict__ x, int B, int q, int T,
+                                                          int32_t* __restrict__ idx,
+                                                          int32_t* __restrict__ flag) {
+  const long N = (long)B * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / T;
+    const int t = (int)(i % T);
+    const float* xp = x + b * (long)q * T + t;
+    int pos = 0, ones = 0;
+    bool ok = true;
+#pragma unroll 8
+    for (int c = 0; c < q; ++c) {
+      const float v = xp[(long)c * T];
+      if (v == 1.0f) { pos = c; ++ones; }
+      else if (v != 0.0f) ok = false;
+    }
+    idx[i] = pos;
+    if (!ok || ones != 1) atomicExch(flag, 0);
+  }
+}
+__global__ void set_flag_kernel(int32_t* flag, int32_t v) { *flag = v; }
+
+// T % 4 == 0 form: 64 column quads x 4 channel groups per workgroup, 16-byte loads, four in flight
+__global__ __launch_bounds__(256) void onehot_scan4_kernel(const float* __restrict__ x, int B, int q, int T,
+                                                           int32_t* __restrict__ idx,
+                                                           int32_t* __restrict__ flag) {
+  __shared__ int s_pos[4][64][4];
+  __shared__ int s_cnt[4][64][4];       // number of ones; -1000 marks an entry that is neither 0 nor 1
+  const int cq = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long nquad = (long)B * T / 4;
+  const long quad = (long)blockIdx.x * 64 + cq;
+  int pos[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  if (quad < nquad) {
+    const long i0 = quad * 4;
+    const long b = i0 / T;
+    const int t = (int)(i0 % T);
+    const int c0 = (int)(((long)q * grp) / 4), c1 = (int)(((long)q * (grp + 1)) / 4);
+    const float* xp = x + b * (long)q * T + t;
+    auto look = [&](const float4 v, int c) {
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (e[j] == 1.0f) { pos[j] = c; ++cnt[j]; }
+        else if (e[j] != 0.0f) cnt[j] = -1000;
+      }
+    };
+    int c = c0;
+    for (; c + 3 < c1; c += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)c * T);
+      const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(c + 1) * T);
+      const float4 v2 = *reinterpret_cast<const float4*>(xp + (long)(c + 2) * T);
+      const float4 v3 = *reinterpret_cast<const float4*>(xp + (long)(c + 3) * T);
+      look(v0, c); look(v1, c + 1); look(v2, c + 2); look(v3, c + 3);
+    }
+    for (; c < c1; ++c) look(*reinterpret_cast<const float4*>(xp + (long)c * T), c);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s_pos[grp][cq][j] = pos[j]; s_cnt[grp][cq][j] = cnt[j]; }
+  __syncthreads();
+  if (grp == 0 && quad < nquad) {
+    int4 out;
+    int* o = reinterpret_cast<int*>(&out);
+    bool good = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = 0, p = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cg = s_cnt[g][cq][j];
+        if (cg < 0) good = false;
+        if (cg > 0) p = s_pos[g][cq][j];
+        n += cg;
+      }
+      if (n != 1) good = false;
+      o[j] = p;
+    }
+    *reinterpret_cast<int4*>(idx + quad * 4) = out;
+    if (!good) atomicExch(flag, 0);
+  }
+}
+
+// weight gradient of the embed conv from the class indices: gW[co, c, tap] = sum of gy[b, co, t] over
+// the positions whose input class (at t - (K-1-tap)) is c -- a weighted bincount of each output-
+// gradient row.  One wave per (b, co) row, bins in LDS (ds_add_f32; lanes of one instruction that hit
+// the same bin are applied in lane order, instructions in program order: deterministic), per-row
+// partial histograms to HBM, then a fixed-order sum over the batch.
+__global__ __launch_bounds__(256) void embed_bincount_kernel(const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ gy, int B, int Cout,
+                                                             int q, int K, int T, float* __restrict__ part,
+                                                             const int32_t* __restrict__ run_flag) {
+  extern __shared__ float bins[];                 // [4 waves][K][q]
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* mine = bins + (size_t)wave * K * q;
+  const long rows = (long)B * Cout;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    for (int i = lane; i < K * q; i += 64) mine[i] = 0.f;
+    const long b = row / Cout;
+    const int32_t* ib = idx + b * T;
+    const float* g = gy + row * T;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < T) {
+        const float v = g[t];
+        for (int tap = 0; tap < K; ++tap) {
+          const int ti = t - (K - 1 - tap);
+          if (ti >= 0) atomicAdd(&mine[tap * q + ib[ti]], v);
+        }
+      }
+    }
+    float* out = part + row * (long)K * q;
+    for (int i = lane; i < K * q; i += 64) out[i] = mine[i];
+  }
+}
+__global__ void embed_bincount_reduce_kernel(const float* __restrict__ part, int B, int Cout, int q, int K,
+                                             float* __restrict__ gW, int accumulate,
+                                             const int32_t* __restrict__ run_flag) {
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const long total = (long)Cout * K * q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q);
+    const long r = i / q;
+    const int tap = (int)(r % K), co = (int)(r / K);
+    float v = 0.f;
+    for (int b = 0; b < B; ++b) v += part[(((long)b * Cout + co) * K + tap) * q + c];
+    float* dst = gW + ((long)co * q + c) * K + tap;                 // Chainer layout (Cout, q, K)
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+// bias gradient = row sum of gy = sum over batch and classes of the UNSHIFTED tap's histograms
+// (every position has exactly one class there).  One wave per output channel, fixed order.
+__global__ __launch_bounds__(64) void embed_bincount_bias_kernel(const float* __restrict__ part, int B,
+                                                                 int Cout, int q, int K, float* __restrict__ gb,
+                                                                 int accumulate,
+                                                                 const int32_t* __restrict__ run_flag) {
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const int co = blockIdx.x, lane = threadIdx.x;
+  float v = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* pp = part + (((long)b * Cout + co) * K + (K - 1)) * q;
+    for (int c = lane; c < q; c += 64) v += pp[c];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) gb[co] = accumulate ? gb[co] + v : v;
+}
+
+// K == 2, T % 4 == 0: four output columns per thread, one 16-byte store
+__global__ __launch_bounds__(256) void embed_gather2x4_kernel(const int32_t* __restrict__ idx, int B, int T,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int Cout, int q,
+                                                              float* __restrict__ y,
+                                                              const int32_t* __restrict__ run_flag) {
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const int T4 = T >> 2;
+  const long total = (long)B * Cout * T4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T4) * 4;
+    const long r = i / T4;
+    const int co = (int)(r % Cout);
+    const long b = r / Cout;
+    const int32_t* ib = idx + b * T + t;
+    const int4 c1 = *reinterpret_cast<const int4*>(ib);             // classes at t .. t+3   (tap 1)
+    const int cm = t > 0 ? ib[-1] : -1;                              // class at t-1          (tap 0 of column t)
+    const float* wc = W + (long)co * q * 2;
+    const float bv = bias ? bias[co] : 0.f;
+    // same order as the dense GEMM's segments: tap 0 first, then tap 1, then the bias
+    float4 o;
+    o.x = __fadd_rn(cm >= 0 ? wc[2 * cm] : 0.f, wc[2 * c1.x + 1]);
+    o.y = __fadd_rn(wc[2 * c1.x], wc[2 * c1.y + 1]);
+    o.z = __fadd_rn(wc[2 * c1.y], wc[2 * c1.z + 1]);
+    o.w = __fadd_rn(wc[2 * c1.z], wc[2 * c1.w + 1]);
+    if (bias) { o.x = __fadd_rn(o.x, bv); o.y = __fadd_rn(o.y, bv); o.z = __fadd_rn(o.z, bv); o.w = __fadd_rn(o.w, bv); }
+    *reinterpret_cast<float4*>(y + (b * Cout + co) * (long)T + t) = o;
+  }
+}
+
+// K == 2, T % 4 == 0 form of the bincount: four positions per lane (16-byte loads), two chunks in flight.
+// The kernel is bound by the LDS atomic unit, about 3 clocks per lane-add whatever the addresses
+// are: spreading the lanes over BC_NCOPY private copies of the histograms (8 copies, 2 waves)
+// measured 313 us against 309 us for one copy per wave, so one copy it is -- 8 KB of LDS per
+// workgroup, which lets it share a CU with the MFMA kernels it is overlapped with.
+constexpr int BC_NCOPY = 1, BC_WAVES = 4;
+__global__ __launch_bounds__(64 * BC_WAVES) void embed_bincount2x4_kernel(const int32_t* __restrict__ idx,
+                                                                const float* __restrict__ gy, int B, int Cout,
+                                                                int q, int T, float* __restrict__ part,
+                                                                const int32_t* __restrict__ run_flag) {
+  extern __shared__ float bins[];                 // [BC_WAVES][NCOPY][2][q]
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* base = bins + (size_t)wave * BC_NCOPY * 2 * q;
+  float* b0 = base + (size_t)(lane % BC_NCOPY) * 2 * q;   // tap 0: class of the previous position
+  float* b1 = b0 + q;                                      // tap 1: class of the position itself
+  const long rows = (long)B * Cout;
+  for (long row = (long)blockIdx.x * BC_WAVES + wave; row < rows; row += (long)gridDim.x * BC_WAVES) {
+    for (int i = lane; i < BC_NCOPY * 2 * q; i += 64) base[i] = 0.f;
+    const long b = row / Cout;
+    const int32_t* ib = idx + b * T;
+    const float* g = gy + row * T;
+    auto add = [&](const float4 v, const int4 c, int cm) {
+      atomicAdd(&b1[c.x], v.x); atomicAdd(&b1[c.y], v.y); atomicAdd(&b1[c.z], v.z); atomicAdd(&b1[c.w], v.w);
+      if (cm >= 0) atomicAdd(&b0[cm], v.x);
+      atomicAdd(&b0[c.x], v.y); atomicAdd(&b0[c.y], v.z); atomicAdd(&b0[c.z], v.w);
+    };
+    int t = 4 * lane;
+    for (; t + 256 < T; t += 512) {               // two independent chunks per iteration
+      const float4 v0 = *reinterpret_cast<const float4*>(g + t);
+      const int4 c0 = *reinterpret_cast<const int4*>(ib + t);
+      const int m0 = t > 0 ? ib[t - 1] : -1;
+      const float4 v1 = *reinterpret_cast<const float4*>(g + t + 256);
+      const int4 c1 = *reinterpret_cast<const int4*>(ib + t + 256);
+      const int m1 = ib[t + 255];
+      add(v0, c0, m0);
+      add(v1, c1, m1);
+    }
+    for (; t < T; t += 256) {
+      const float4 v0 = *reinterpret_cast<const float4*>(g + t);
+      const int4 c0 = *reinterpret_cast<const int4*>(ib + t);
+      add(v0, c0, t > 0 ? ib[t - 1] : -1);
+    }
+    float* out = part + row * (long)2 * q;
+    for (int i = lane; i < 2 * q; i += 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int cpy = 0; cpy < BC_NCOPY; ++cpy) v += base[(size_t)cpy * 2 * q + i];
+      out[i] = v;
+    }
   }
 }
 
@@ -650,9 +889,82 @@ int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, floa
 int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, const float* W,
                            const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s) {
   VQ_REQUIRE(idx && W && y && B > 0 && T > 0 && Cout > 0 && q > 0 && K >= 1, "embed_gather_fwd: bad arguments");
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)B * Cout * T, 256, 4096)), dim3(256), 0, (hipStream_t)s, idx, idx_bstride, B, T, W, b, Cout, q, K, y);
+  if (K == 2 && T % 4 == 0 && idx_bstride == (long)T && (((uintptr_t)y) % 16 == 0) && (((uintptr_t)idx) % 16 == 0)) {
+    hipLaunchKernelGGL(embed_gather2x4_kernel, dim3(grid_for((size_t)B * Cout * (T / 4), 256, 8192)), dim3(256), 0, (hipStream_t)s, idx, B, T, W, b, Cout, q, y, (const int32_t*)nullptr);
+    VQ_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)B * Cout * T, 256, 4096)), dim3(256), 0, (hipStream_t)s, idx, idx_bstride, B, T, W, b, Cout, q, K, y, (const int32_t*)nullptr);
   VQ_LAUNCH_CHECK();
   return 0;
+}
+
+size_t vqvae_embed_onehot_workspace_bytes(int B, int Cout, int q, int K, int T) {
+  vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
+  return align_up((size_t)B * Cout * K * q * sizeof(float), 256) + vqvae_conv1d_workspace_bytes(&d) + 256;
+}
+
+int vqvae_embed_onehot_fwd(const float* x, const float* W, const float* b, int B, int Cout, int q,
+                           int K, int T, float* y, int32_t* idx, int32_t* flag, void* ws,
+                           size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(x && W && y && idx && flag && ws && B > 0 && Cout > 0 && q > 0 && K >= 1 && T > 0, "embed_onehot_fwd: bad arguments");
+  if (ws_bytes < vqvae_embed_onehot_workspace_bytes(B, Cout, q, K, T)) { set_error("embed_onehot_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, st, flag, 1);
+  const bool vec4 = (T % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0);
+  if (vec4) {
+    const long nquad = (long)B * T / 4;
+    hipLaunchKernelGGL(onehot_scan4_kernel, dim3((unsigned)((nquad + 63) / 64)), dim3(256), 0, st, x, B, q, T, idx, flag);
+  } else {
+    hipLaunchKernelGGL(onehot_scan_kernel, dim3(grid_for((size_t)B * T, 256, 2048)), dim3(256), 0, st, x, B, q, T, idx, flag);
+  }
+  VQ_LAUNCH_CHECK();
+  // one-hot: gather of K weight columns (bit-identical to the dense conv) ...
+  if (vec4 && K == 2) {
+    hipLaunchKernelGGL(embed_gather2x4_kernel, dim3(grid_for((size_t)B * Cout * (T / 4), 256, 8192)), dim3(256), 0, st, idx, B, T, W, b, Cout, q, y, (const int32_t*)flag);
+  } else {
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)B * Cout * T, 256, 4096)), dim3(256), 0, st, idx, (long)T, B, T, W, b, Cout, q, K, y, (const int32_t*)flag);
+  }
+  VQ_LAUNCH_CHECK();
+  // ... anything else: the dense causal conv (pad K-1, cropped to T), skipped on the device when flag != 0
+  vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
+  char* cw = (char*)ws + align_up((size_t)B * Cout * K * q * sizeof(float), 256);
+  return vqvae_conv1d_fwd_cond(&d, x, W, b, y, cw, ws_bytes - (size_t)(cw - (char*)ws), flag, s);
+}
+
+int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* flag, const float* gy,
+                             int B, int Cout, int q, int K, int T, float* gW, float* gb,
+                             int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(idx && gy && gW && ws && B > 0 && Cout > 0 && q > 0 && K >= 1 && T > 0, "embed_onehot_wgrad: bad arguments");
+  VQ_REQUIRE(flag == nullptr || x != nullptr, "embed_onehot_wgrad: a flag needs the dense input for its fallback");
+  if (ws_bytes < vqvae_embed_onehot_workspace_bytes(B, Cout, q, K, T)) { set_error("embed_onehot_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  float* part = (float*)ws;
+  const size_t lds = (size_t)4 * K * q * sizeof(float);
+  VQ_REQUIRE(lds <= 64 * 1024, "embed_onehot_wgrad: K*q too large for the LDS histograms");
+  const long rows = (long)B * Cout;
+  int nb = (int)((rows + 3) / 4);
+  if (nb > 2048) nb = 2048;
+  const size_t lds2 = (size_t)BC_WAVES * BC_NCOPY * 2 * q * sizeof(float);
+  if (K == 2 && T % 4 == 0 && (((uintptr_t)gy) % 16 == 0) && lds2 <= 64 * 1024) {
+    int nb2 = (int)((rows + BC_WAVES - 1) / BC_WAVES);
+    if (nb2 > 4096) nb2 = 4096;
+    hipLaunchKernelGGL(embed_bincount2x4_kernel, dim3(nb2), dim3(64 * BC_WAVES), lds2, st, idx, gy, B, Cout, q, T, part, flag);
+  } else {
+    hipLaunchKernelGGL(embed_bincount_kernel, dim3(nb), dim3(256), lds, st, idx, gy, B, Cout, q, K, T, part, flag);
+  }
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_bincount_reduce_kernel, dim3(grid_for((size_t)Cout * K * q, 256, 2048)), dim3(256), 0, st,
+                     (const float*)part, B, Cout, q, K, gW, accumulate, flag);
+  VQ_LAUNCH_CHECK();
+  if (gb != nullptr) {
+    hipLaunchKernelGGL(embed_bincount_bias_kernel, dim3(Cout), dim3(64), 0, st, (const float*)part, B, Cout, q, K, gb, accumulate, flag);
+    VQ_LAUNCH_CHECK();
+  }
+  if (flag == nullptr) return 0;                          // index-fed input: there is no dense form to fall back to
+  vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
+  char* cw = (char*)ws + align_up((size_t)B * Cout * K * q * sizeof(float), 256);
+  return vqvae_conv1d_bwd_weight_cond(&d, x, gy, gW, gb, accumulate, cw, ws_bytes - (size_t)(cw - (char*)ws), flag, s);
 }
 
 int vqvae_concat(float* dst, const float* const* srcs, int n, size_t count, vqvae_stream_t s) {

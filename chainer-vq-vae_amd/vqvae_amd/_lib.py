@@ -121,6 +121,12 @@ PROTOTYPES = {
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
     'vqvae_onehot': (c_int, [P, c_long, c_int, c_int, c_int, P, P]),
     'vqvae_embed_gather_fwd': (c_int, [P, c_long, c_int, c_int, P, P, c_int, c_int, c_int, P, P]),
+    'vqvae_embed_onehot_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'vqvae_embed_onehot_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    'vqvae_embed_onehot_wgrad': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
+                                         c_size_t, P]),
+    'vqvae_conv1d_fwd_cond': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, P, P]),
+    'vqvae_conv1d_bwd_weight_cond': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P, P]),
     'vqvae_concat': (c_int, [P, PP, c_int, c_size_t, P]),
     'vqvae_split': (c_int, [P, PP, c_int, c_size_t, c_int, P]),
     'vqvae_embed_broadcast_fwd': (c_int, [P, P, c_int, c_int, c_int, P, c_long, P]),

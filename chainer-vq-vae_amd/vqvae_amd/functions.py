@@ -512,7 +512,8 @@ def mixture_of_logistics_nll(y, t, quantize=256, log_scale_min=-40.0):
 class EmbedConvFromIndices(FunctionNode):
     """Causal (K,1) conv of the one-hot of ``idx`` (modules.py:127-128, 151-152) without the
     one-hot: forward is a K-column gather of W (bit-identical to the dense conv); the weight
-    gradient materialises the one-hot on the device and reuses the dense wgrad kernel."""
+    gradient is a weighted bincount of the output-gradient rows by class (the same kernel the
+    one-hot float input takes once the device has recognised it, so both inputs train alike)."""
 
     def check_type_forward(self, in_vars):
         idx, W = in_vars[0], in_vars[1]
@@ -534,21 +535,78 @@ class EmbedConvFromIndices(FunctionNode):
     def backward(self, indexes, gys):
         idx, B, T, Cout, q, K, has_b = self._saved
         gy = gys[0].data
-        onehot = DeviceArray((B, q, T), np.float32)
-        _lib.call('vqvae_onehot', idx.ptr, T, B, q, T, onehot.ptr, _S())
-        desc = _conv_desc(B, q, T, Cout, T, K, 1, K - 1, 1, False)
-        ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(desc)))
-        wv = self.inputs[1]
-        buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
-        gW = buf.reshape(wv.shape) if buf is not None else DeviceArray(wv.shape, np.float32)
-        gb = None
-        if has_b:
-            bv = self.inputs[2]
-            buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
-            gb = buf if buf is not None else DeviceArray((Cout,), np.float32)
-        _lib.call('vqvae_conv1d_bwd_weight', C.byref(desc), onehot.ptr, gy.ptr, gW.ptr, _p(gb), 0,
-                  ws.ptr, ws.nbytes, _S())
+        gW, gb = _embed_wgrad(self, None, idx, None, gy, B, Cout, q, K, T, has_b)
         return (None, gW, gb) if has_b else (None, gW)
+
+
+def _embed_wgrad(node, x, idx, flag, gy, B, Cout, q, K, T, has_b):
+    """Weight (and bias) gradient of the embed conv as a weighted bincount of the rows of ``gy``
+    by input class.  The kernel is bound by the LDS atomic unit (about 3 clocks per lane-add:
+    0.31 ms at configs[1], level with the dense MFMA wgrad it replaces, but without reading the
+    one-hot tensor).  Running it on the side stream under the rest of the backward sweep was
+    measured and costs 0.13 ms/step more than it hides (A/B, 3x interleaved): main stream."""
+    wv = node.inputs[1]
+    buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
+    gW = buf.reshape(wv.shape) if buf is not None else DeviceArray(wv.shape, np.float32)
+    gb = None
+    if has_b:
+        bv = node.inputs[2]
+        buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
+        gb = buf if buf is not None else DeviceArray((Cout,), np.float32)
+    ws = backend.workspace(_lib.load().vqvae_embed_onehot_workspace_bytes(B, Cout, q, K, T))
+    _lib.call('vqvae_embed_onehot_wgrad', _p(x), idx.ptr, _p(flag), gy.ptr, B, Cout, q, K, T, gW.ptr,
+              _p(gb), 0, ws.ptr, ws.nbytes, _S())
+    return gW, gb
+
+
+class EmbedConvOneHot(FunctionNode):
+    """The decoder's causal embed conv (modules.py:127-128, 151-152) on the reference's input
+    contract -- the one-hot FLOAT tensor (B, q, T, 1) of utils.py:85-87.  A dense conv over it is
+    2*B*T*Cout*q*K FLOP of multiplications by zero, forward and again in the weight gradient.
+    The device scans the tensor once (class index per column + a flag "exactly one-hot") and then
+    runs EITHER the gather / bincount forms OR the dense kernels, selected by that flag on the
+    device: no host round trip, and an input that is not one-hot silently takes the dense path.
+    Forward is bit-identical to the dense conv on a one-hot input."""
+
+    def check_type_forward(self, in_vars):
+        x, W = in_vars[0], in_vars[1]
+        type_expect((x.ndim in (3, 4) and W.ndim in (3, 4), 'embed conv: x (B,q,T[,1]), W (Cout,q,K[,1])'),
+                    (x.shape[1] == W.shape[1], 'embed conv: in-channels mismatch'))
+
+    def forward(self, inputs):
+        x, W = inputs[0], inputs[1]
+        b = inputs[2] if len(inputs) > 2 else None
+        backend.require_device(x, W)
+        B, q, T = x.shape[:3]
+        Cout, _, K = W.shape[:3]
+        y = DeviceArray((B, Cout, T, 1), np.float32)
+        idx = DeviceArray((B, T), np.int32)
+        flag = DeviceArray((1,), np.int32)
+        ws = backend.workspace(_lib.load().vqvae_embed_onehot_workspace_bytes(B, Cout, q, K, T))
+        _lib.call('vqvae_embed_onehot_fwd', x.ptr, W.ptr, _p(b), B, Cout, q, K, T, y.ptr, idx.ptr, flag.ptr,
+                  ws.ptr, ws.nbytes, _S())
+        self.retain_inputs((0, 1))
+        self._saved = (idx, flag, B, T, Cout, q, K, b is not None)
+        return y,
+
+    def backward(self, indexes, gys):
+        idx, flag, B, T, Cout, q, K, has_b = self._saved
+        x, W = [v.data for v in self.get_retained_inputs()]
+        gy = gys[0].data
+        gW, gb = _embed_wgrad(self, x, idx, flag, gy, B, Cout, q, K, T, has_b)
+        gx = None
+        if 0 in indexes:                       # the input is data on the training path; kept for completeness
+            desc = _conv_desc(B, q, T, Cout, T, K, 1, K - 1, 1, False)
+            gx = DeviceArray(x.shape, np.float32)
+            wsd = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(desc)))
+            _lib.call('vqvae_conv1d_bwd_data', C.byref(desc), W.ptr, gy.ptr, gx.ptr, 0, wsd.ptr, wsd.nbytes, _S())
+        return (gx, gW, gb) if has_b else (gx, gW)
+
+
+def embed_conv_onehot(x, W, b=None):
+    """Causal (K,1) conv, pad K-1, cropped to the input length, of a (possibly) one-hot input."""
+    args = (x, W) if b is None else (x, W, b)
+    return EmbedConvOneHot().apply(args)[0]
 
 
 def embed_conv_indices(idx, W, b=None):

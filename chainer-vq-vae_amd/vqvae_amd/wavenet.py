@@ -441,6 +441,12 @@ class WaveNet(Chain):
             # device-side input pipeline: x holds mu-law bin indices (B, T) instead of the
             # one-hot (B, q, T, 1) tensor -- the embed conv is a gather of its weight columns
             x = F.embed_conv_indices(x, self.embed.W, self.embed.b)
+        elif (self.input_dim >= 8 and self.embed.W.data is not None and x.shape[1] == self.embed.W.shape[1]
+              and self.embed.pad[0] == self.embed.ksize[0] - 1 and self.embed.stride[0] == 1
+              and _lib.load().vqvae_get_matmul_dtype() == 0):      # bf16 mode rounds W: dense kernels
+            # the reference's one-hot float input (utils.py:85-87): same causal conv, but the device
+            # checks for one-hot-ness and then gathers / bincounts instead of multiplying by zeros
+            x = F.embed_conv_onehot(x, self.embed.W, self.embed.b)
         else:
             length = x.shape[2]
             # causal conv: pad 1 then crop to `length` (modules.py:151-152), fused as out_len

@@ -114,6 +114,16 @@ int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const floa
 int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                             float* gW, float* gb, int accumulate, void* ws,
                             size_t ws_bytes, vqvae_stream_t s);
+/* Device-side conditional forms: the whole launch is a no-op when skip_flag != NULL and
+ * *skip_flag != 0 at execution time (skip_flag is a device pointer).  Used to pick between two
+ * implementations of one operator by a flag computed on the device, without a host round trip
+ * (vqvae_embed_onehot_*).                                                                        */
+int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                          const float* b, float* y, void* ws, size_t ws_bytes,
+                          const int32_t* skip_flag, vqvae_stream_t s);
+int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                                 float* gW, float* gb, int accumulate, void* ws, size_t ws_bytes,
+                                 const int32_t* skip_flag, vqvae_stream_t s);
 
 /* ---- WaveNet ResidualBlock (WaveNet/modules.py:30-56), dropout_zero_rate == 0:
  *      h = dilconv(x)[:, :, :T] + condition_proj(c); z = tanh(h_a)*sigmoid(h_b);
@@ -312,6 +322,23 @@ int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, floa
                  vqvae_stream_t s);
 int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, const float* W,
                            const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s);
+/*      embed_onehot_fwd / _wgrad: the SAME conv applied to the reference's one-hot float input
+ *                  x (B,q,T) (utils.py:85-87, modules.py:151-152).  fwd scans x on the device
+ *                  (idx (B,T) int32 out; *flag = 1 iff every column is exactly one 1.0 and q-1 zeros),
+ *                  then launches the gather form (runs iff *flag != 0; bit-identical to the dense
+ *                  conv) and the dense conv (runs iff *flag == 0): no host round trip, any other
+ *                  input silently takes the dense path.  wgrad likewise: a weighted bincount of the
+ *                  output-gradient rows by class (deterministic; LDS histograms, fixed-order batch
+ *                  sum; gb = row sums) iff *flag != 0, else the dense weight gradient.  flag == NULL
+ *                  (with x == NULL): indices are authoritative (index-fed input), bincount only.
+ *                  gW (Cout,q,K), workspace from the query.                                     */
+size_t vqvae_embed_onehot_workspace_bytes(int B, int Cout, int q, int K, int T);
+int vqvae_embed_onehot_fwd(const float* x, const float* W, const float* b, int B, int Cout, int q,
+                           int K, int T, float* y, int32_t* idx, int32_t* flag, void* ws,
+                           size_t ws_bytes, vqvae_stream_t s);
+int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* flag, const float* gy,
+                             int B, int Cout, int q, int K, int T, float* gW, float* gb,
+                             int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
 
 /* ---- gather n (<= 32) equally sized arrays (host array of device pointers) into one
  *      contiguous array and back (NULL destinations are skipped): lets ResidualNet

@@ -382,8 +382,17 @@ def test_device_input_pipeline(gpu):
     y_dense.backward()
     y_idx.grad = _dev(gpu, gy)
     y_idx.backward()
-    np.testing.assert_array_equal(vW2.grad.get(), vW1.grad.get())
-    np.testing.assert_array_equal(vb2.grad.get(), vb1.grad.get())
+    # weight gradient: the index-fed conv and the one-hot float input (once the device has recognised
+    # it) run the same bincount kernel -> identical bits; the dense GEMM sums in another order
+    vW3, vb3 = Variable(_dev(gpu, W)), Variable(_dev(gpu, b))
+    y_oh = F.embed_conv_onehot(Variable(_dev(gpu, onehot)), vW3, vb3)
+    np.testing.assert_array_equal(y_oh.data.get(), y_dense.data.get())
+    y_oh.grad = _dev(gpu, gy)
+    y_oh.backward()
+    np.testing.assert_array_equal(vW2.grad.get(), vW3.grad.get())
+    np.testing.assert_array_equal(vb2.grad.get(), vb3.grad.get())
+    assert_close_scaled(vW2.grad.get(), vW1.grad.get(), 1e-5, 'bincount vs dense weight gradient')
+    assert_close_scaled(vb2.grad.get(), vb1.grad.get(), 1e-5, 'bincount vs dense bias gradient')
 
 
 @pytest.fixture
@@ -495,3 +504,56 @@ def test_resstack_workspace_queries_cover_every_group_size(gpu):
         want = np.stack([np.einsum('bot,bit->oi', ghh.astype(np.float64), xs.astype(np.float64)),
                          np.einsum('bot,bit->oi', ghh.astype(np.float64), xh.astype(np.float64))], axis=2)
         assert_close_scaled(gW[i].get(), want, 1e-4, 'dilated wgrad, group of %d' % n)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 256, 300), (1, 48, 50, 37), (3, 256, 256, 128)])
+def test_embed_conv_onehot_auto_paths(gpu, shape):
+    """The decoder's embed conv on the reference's one-hot float input (modules.py:127-128,151-152):
+    a one-hot tensor takes the gather / bincount forms (forward bit-identical to the dense conv, weight
+    gradient vs the oracle), the same call on a tensor that is NOT one-hot (one entry 0.5, one column
+    with two ones, one all-zero column) takes the dense kernels -- both selected on the device --
+    and both match the oracle's dense conv."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cout, q, T = shape
+    rs = np.random.RandomState(B * 1000 + q)
+    W = (rs.standard_normal((Cout, q, 2)) / np.sqrt(2 * q)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    cls = rs.randint(0, q, size=(B, T))
+    onehot = np.zeros((B, q, T), np.float32)
+    for bi in range(B):
+        onehot[bi, cls[bi], np.arange(T)] = 1.0
+    soft = onehot.copy()
+    soft[0, cls[0, 3], 3] = 0.5                       # not exactly 1
+    soft[B - 1, (cls[B - 1, 5] + 1) % q, 5] = 1.0     # two ones in a column
+    soft[0, cls[0, 7], 7] = 0.0                       # an empty column
+    gy = rs.standard_normal((B, Cout, T)).astype(np.float32)
+    for x, want_flag in ((onehot, 1), (soft, 0)):
+        y_ref = O.conv1d_fwd(x, W, b, 1, 1, 1)[:, :, :T]
+        gpad = np.zeros((B, Cout, T + 1), np.float32); gpad[:, :, :T] = gy
+        _, gW_ref, gb_ref = O.conv1d_bwd(x, W, gpad, 1, 1, 1, need_gx=False)
+        vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+        y = F.embed_conv_onehot(vx, vW, vb)
+        assert int(y.creator._saved[1].get()[0]) == want_flag
+        np.testing.assert_array_equal(y.creator._saved[0].get(), np.where(x == 1.0, np.arange(q)[None, :, None], 0).max(axis=1)) \
+            if want_flag else None
+        assert_close(y.data.get()[..., 0], y_ref, 1e-5, 'embed conv fwd (flag %d)' % want_flag)
+        if want_flag:
+            # bit-identical to the dense kernel on the same one-hot tensor
+            y_dense = F.convolution_1d(vx, vW, vb, pad=1, out_len=T)
+            np.testing.assert_array_equal(y.data.get(), y_dense.data.get())
+        y.grad = _dev(gpu, to4(gy))
+        y.backward()
+        assert_close_scaled(vW.grad.get()[..., 0], gW_ref, 1e-4, 'embed conv gW (flag %d)' % want_flag)
+        assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'embed conv gb (flag %d)' % want_flag)
+    # the bincount is deterministic: three runs, same bits
+    outs = []
+    for _ in range(3):
+        vx, vW, vb = Variable(_dev(gpu, to4(onehot))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+        y = F.embed_conv_onehot(vx, vW, vb)
+        y.grad = _dev(gpu, to4(gy))
+        y.backward()
+        outs.append((vW.grad.get().copy(), vb.grad.get().copy()))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[0], outs[0][0])
+        np.testing.assert_array_equal(o[1], outs[0][1])
