@@ -126,6 +126,264 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 
 // WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
 // halves the activation-tile loads per FLOP and is used whenever M >= 256.
+// Epilogue of the conv GEMM kernels: acc[mi][ni] is the wave's 2 x 2 block of 32 x 32 accumulator tiles
+// (rows m0 + wm*64 + mi*32, columns t0 + wn*64 + ni*32) of batch item b.  SPLITK: this instantiation
+// may have been launched with ksplit > 1 (raw partial tiles out, gemm_splitk_reduce_kernel finishes).
+template <int EPI, int WM, bool SPLITK>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
+                                              const int b, const int wm, const int wn, const int li, const int lk,
+                                              const int ksp, const int tile_id, const int ntiles_all) {
+  // ---- epilogue ----------------------------------------------------------
+  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int T = a.Tout;
+  if (SPLITK && a.ksplit > 1) {
+    float* pt = a.partial + ((long)ksp * ntiles_all + tile_id) * (128 * 128);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pt[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 128 + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
+    return;
+  }
+  if (EPI == EPI_LINEAR) {
+    // ---- interior tiles: software-pipelined epilogue --------------------------------------------
+    // VMEM operations retire through one in-order counter, so "load sub-tile q+1, then store
+    // sub-tile q" lets the next operands travel while the previous results drain; the plain
+    // load/store/load/store order exposed one load AND one store latency per sub-tile, which is
+    // what bounded the K = 128 projections (315 MB of traffic per launch, 8 GFLOP).
+    bool fast = (t0 + BN <= T);
+    {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        const int o = (mb < a.out[0].rows) ? 0 : 1;
+        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
+        const int mr0 = o ? mb - a.out[0].rows : mb;
+        fast = fast && (mr0 + 32 <= rows_left) && !(a.out[o].add && a.out[o].accumulate);
+      }
+    }
+    if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
+      // bias first, one row group at a time (the registers are needed for the operand pipeline)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+        const OutR& od = a.out[o];
+        if (od.bias) {
+          const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
+          float bias[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bias[r] = od.bias[mrb + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][n2][r] += bias[r];
+        }
+      }
+      float pv[2][16];
+#pragma unroll
+      for (int q = 0; q <= 4; ++q) {
+        if (q < 4) {                 // request the operands of sub-tile q
+          const int mi = q >> 1, ni = q & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+          const float* src = od.add ? od.add + (long)b * od.add_bstride
+                                    : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
+          if (src) {
+            const rsrc_t rs = make_rsrc(src);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
+          }
+        }
+        if (q > 0) {                 // finish sub-tile q - 1
+          const int p = q - 1, mi = p >> 1, ni = p & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+          const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mi][ni][r] + pv[p & 1][r];
+            if (od.relu) v = fmaxf(v, 0.f);
+            buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+          }
+        }
+      }
+    } else {
+    // ---- edge tiles: fully predicated ---------------------------------------------------------
+      // All loads of a 32x32 sub-tile (bias, residual, old value) are issued before its
+      // first store, so they overlap instead of serialising behind may-alias stores.
+  #pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wm * 64 + mi * 32;
+        // the host guarantees out[0].rows % 32 == 0 when two ranges exist: wave-uniform
+        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+        const OutR& od = a.out[o];
+        const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
+        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
+        float bias[16];
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mr = mrb + (r & 3) + 8 * (r >> 2);
+          bias[r] = (od.bias && mr < rows_left) ? od.bias[mr] : 0.f;
+        }
+  #pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          const bool tok = t < T;
+          float addv[16], oldv[16];
+          const long boff = (long)mrb * T + t;
+          if (od.add) {
+            const float* ap = od.add + (long)b * od.add_bstride + boff;
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              addv[r] = (tok && mrb + dr < rows_left) ? ap[(long)dr * T] : 0.f;
+            }
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) addv[r] = 0.f;
+          }
+          float* yp = od.y + (long)b * od.y_bstride + boff;
+          if (od.accumulate) {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              oldv[r] = (tok && mrb + dr < rows_left) ? yp[(long)dr * T] : 0.f;
+            }
+          } else {
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
+          }
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (tok && mrb + dr < rows_left) {
+              float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
+              if (od.relu) v = fmaxf(v, 0.f);
+              yp[(long)dr * T] = v;
+            }
+          }
+        }
+      }
+    }
+  } else if (EPI == EPI_GATE) {
+    // packed rows: each 64-row wave tile = 32 tanh rows (mi=0) + the matching 32
+    // sigmoid rows (mi=1) of channel group g.
+    const int Ch = a.M >> 1;
+    const int g = (m0 + wm * 64) >> 6;
+    const OutR& og = a.out[0];   // gates (B, 2Ch, T)
+    const OutR& oz = a.out[1];   // z (B, Ch, T)
+    // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
+    // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
+    // (a load behind a may-alias store would wait for the store's acknowledgement: one in-order counter).
+    int tt[2], vv[2];
+    float w0v[2], w1v[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      tt[ni] = t0 + wn * 64 + ni * 32 + li;
+      const bool tok = tt[ni] < T;
+      vv[ni] = (tok && a.lerp.P) ? a.lerp.v0[tt[ni]] : 0;
+      w0v[ni] = (tok && a.lerp.P) ? a.lerp.w0[tt[ni]] : 0.f;
+      w1v[ni] = (tok && a.lerp.P) ? a.lerp.w1[tt[ni]] : 0.f;
+    }
+    const float* Pb = a.lerp.P ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;
+    const rsrc_t rP = make_rsrc(Pb);
+    const int chl = 32 * g + 4 * lk;            // this lane's first channel; row r adds (r&3) + 8*(r>>2)
+    unsigned vP[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) vP[ni] = 4u * (unsigned)(chl * a.lerp.Tl + vv[ni]);
+    const unsigned sPq = 4u * (unsigned)(Ch * a.lerp.Tl);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      const int ch = chl + dr;
+      if (ch >= Ch) continue;
+      float ba = 0.f, bb = 0.f;
+      if (og.bias) { ba += og.bias[ch]; bb += og.bias[Ch + ch]; }
+      if (og.bias2) { ba += og.bias2[ch]; bb += og.bias2[Ch + ch]; }
+      const unsigned sP = 4u * (unsigned)(dr * a.lerp.Tl);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        float pa = 0.f, pb = 0.f;
+        if (Pb) {      // h += upsample(P)[t]: condition projected at latent rate
+          pa = w0v[ni] * buf_ld(rP, vP[ni], sP) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP);
+          pb = w0v[ni] * buf_ld(rP, vP[ni], sP + sPq) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP + sPq);
+        }
+        acc[0][ni][r] = (acc[0][ni][r] + ba) + pa;
+        acc[1][ni][r] = (acc[1][ni][r] + bb) + pb;
+      }
+    }
+    // Phase 2 -- gate and the three stores per element
+    const rsrc_t rG = make_rsrc(og.y + (long)b * og.y_bstride);
+    const rsrc_t rZ = make_rsrc(oz.y + (long)b * oz.y_bstride);
+    unsigned vT[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) vT[ni] = 4u * (unsigned)(chl * T + tt[ni]);
+    const unsigned sGq = 4u * (unsigned)(Ch * T);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (chl + dr >= Ch) continue;
+      const unsigned sT = 4u * (unsigned)(dr * T);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (tt[ni] >= T) continue;
+        const float ta = fast_tanhf_(acc[0][ni][r]);
+        const float sb = sigmoidf_(acc[1][ni][r]);
+        buf_st(ta, rG, vT[ni], sT);
+        buf_st(sb, rG, vT[ni], sT + sGq);
+        buf_st(ta * sb, rZ, vT[ni], sT);
+      }
+    }
+  } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
+    const int Ch = a.M;
+    const OutR& od = a.out[0];
+    const rsrc_t rGt = make_rsrc(od.add + (long)b * od.add_bstride);
+    const rsrc_t rGh = make_rsrc(od.y + (long)b * od.y_bstride);
+    const unsigned sQ = 4u * (unsigned)(Ch * T);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int t = t0 + wn * 64 + ni * 32 + li;
+        const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+        const bool tok = t < T;
+        const unsigned voff = 4u * (unsigned)(mb * T + t);
+        // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
+        float ta[16], sb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = tok && mb + dr < Ch;
+          const unsigned so = 4u * (unsigned)(dr * T);
+          ta[r] = ok ? buf_ld(rGt, voff, so) : 0.f;
+          sb[r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (tok && mb + dr < Ch) {
+            const float gz = acc[mi][ni][r];
+            const unsigned so = 4u * (unsigned)(dr * T);
+            buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
+            buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
+          }
+        }
+      }
+  }
+}
+
 template <int EPI, int WM, bool BF16>
 __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(const GemmArgs a) {
   constexpr int BM = 64 * WM, NT = 128 * WM;
@@ -514,255 +772,207 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------
-  // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int T = a.Tout;
-  if (EPI == EPI_LINEAR && WM == 2 && !BF16 && a.ksplit > 1) {
-    float* pt = a.partial + ((long)ksp * ntiles_all + tile_id) * (128 * 128);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          pt[(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 128 + wn * 64 + ni * 32 + li] = acc[mi][ni][r];
-    return;
+  gemm_epilogue<EPI, WM, (EPI == EPI_LINEAR && WM == 2 && !BF16)>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
+}
+
+// ---------------------------------------------------------------------------
+// matmul mode 2: fp32 products on the bf16 matrix pipe.
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of v_mfma_f32_32x32x16_bf16 on gfx950, so an fp32
+// product is cheaper as six bf16 products of an EXACT three-way split of both operands:
+//     x = x_h + x_m + x_l     (three bf16, each RNE of the remainder: 3 x 8 significand bits and
+//                              the signs of the remainders cover all 24 bits of an fp32)
+//     a*b ~= a_l*b_h + a_h*b_l + a_m*b_m + a_m*b_h + a_h*b_m + a_h*b_h        (fp32 accumulate)
+// A product of two bf16 is exact in fp32, and the three dropped products (m*l, l*m, l*l) are below
+// 2^-25 |a*b| -- less than the rounding of ONE fp32 multiply -- so the result is as accurate as the
+// fp32 MFMA path (tests/test_gpu_kernels.py compares both with float64); it is not a reduced-
+// precision mode like mode 1.  6 x 32 cycles per 16 k against 8 x 64: 0.375 of the MFMA time.
+//
+// Weights arrive already split from pack_kernel, in the order the LDS image wants: per 16-k step,
+// [piece 3][k-half 2][m] 16-byte words (8 consecutive k of one piece).  Activations are split while
+// they are staged: every thread owns one column of the tile and 16/NQ channels of the step, which
+// is also what makes every window (stride, dilation shift, transposed-conv gaps) the same path.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack_bf16x2(x0, x1);
+  float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = pack_bf16x2(r0, r1);
+  r0 -= __builtin_bit_cast(float, m << 16); r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+  l = pack_bf16x2(r0, r1);
+}
+
+template <int EPI, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void conv_gemm_x3_kernel(const GemmArgs a) {
+  constexpr int BM = 64 * WM, NT = 128 * WM;
+  constexpr int NQ = NT / 128;            // staging threads per tile column
+  constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 (WM = 2) or 4
+  constexpr bool SPLITK = (EPI == EPI_LINEAR && WM == 2);
+  __shared__ uint4 As[2][3][2][BM];
+  __shared__ uint4 Bs[2][3][2][BN];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
+
+  const int nblk = gridDim.x;
+  int logical;
+  {
+    const int id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
-  if (EPI == EPI_LINEAR) {
-    // ---- interior tiles: software-pipelined epilogue --------------------------------------------
-    // VMEM operations retire through one in-order counter, so "load sub-tile q+1, then store
-    // sub-tile q" lets the next operands travel while the previous results drain; the plain
-    // load/store/load/store order exposed one load AND one store latency per sub-tile, which is
-    // what bounded the K = 128 projections (315 MB of traffic per launch, 8 GFLOP).
-    bool fast = (t0 + BN <= T);
-    {
+  const int ntiles_all = a.ntile_m * a.ntile_n * a.B;
+  const int ksp = (SPLITK && a.ksplit > 1) ? logical / ntiles_all : 0;
+  const int tile_id = (SPLITK && a.ksplit > 1) ? logical % ntiles_all : logical;
+  const int mt = tile_id % a.ntile_m;
+  const int rest = tile_id / a.ntile_m;
+  const int nt = rest % a.ntile_n;
+  const int b = rest / a.ntile_n;
+  const int m0 = mt * BM, t0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 32;
-        const int o = (mb < a.out[0].rows) ? 0 : 1;
-        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
-        const int mr0 = o ? mb - a.out[0].rows : mb;
-        fast = fast && (mr0 + 32 <= rows_left) && !(a.out[o].add && a.out[o].accumulate);
-      }
-    }
-    if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
-      // bias first, one row group at a time (the registers are needed for the operand pipeline)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 32;
-        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-        const OutR& od = a.out[o];
-        if (od.bias) {
-          const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
-          float bias[16];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) bias[r] = od.bias[mrb + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-          for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][n2][r] += bias[r];
-        }
-      }
-      float pv[2][16];
-#pragma unroll
-      for (int q = 0; q <= 4; ++q) {
-        if (q < 4) {                 // request the operands of sub-tile q
-          const int mi = q >> 1, ni = q & 1;
-          const int mb = m0 + wm * 64 + mi * 32;
-          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-          const OutR& od = a.out[o];
-          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
-          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
-          const float* src = od.add ? od.add + (long)b * od.add_bstride
-                                    : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
-          if (src) {
-            const rsrc_t rs = make_rsrc(src);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
-          }
-        }
-        if (q > 0) {                 // finish sub-tile q - 1
-          const int p = q - 1, mi = p >> 1, ni = p & 1;
-          const int mb = m0 + wm * 64 + mi * 32;
-          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-          const OutR& od = a.out[o];
-          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
-          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
-          const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][ni][r] + pv[p & 1][r];
-            if (od.relu) v = fmaxf(v, 0.f);
-            buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
-          }
-        }
-      }
-    } else {
-    // ---- edge tiles: fully predicated ---------------------------------------------------------
-      // All loads of a 32x32 sub-tile (bias, residual, old value) are issued before its
-      // first store, so they overlap instead of serialising behind may-alias stores.
-  #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int mb = m0 + wm * 64 + mi * 32;
-        // the host guarantees out[0].rows % 32 == 0 when two ranges exist: wave-uniform
-        const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-        const OutR& od = a.out[o];
-        const int mrb = (o ? mb - a.out[0].rows : mb) + 4 * lk;
-        const int rows_left = (o ? a.M - a.out[0].rows : min(a.M, a.out[0].rows));
-        float bias[16];
-  #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int mr = mrb + (r & 3) + 8 * (r >> 2);
-          bias[r] = (od.bias && mr < rows_left) ? od.bias[mr] : 0.f;
-        }
-  #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int t = t0 + wn * 64 + ni * 32 + li;
-          const bool tok = t < T;
-          float addv[16], oldv[16];
-          const long boff = (long)mrb * T + t;
-          if (od.add) {
-            const float* ap = od.add + (long)b * od.add_bstride + boff;
-  #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int dr = (r & 3) + 8 * (r >> 2);
-              addv[r] = (tok && mrb + dr < rows_left) ? ap[(long)dr * T] : 0.f;
-            }
-          } else {
-  #pragma unroll
-            for (int r = 0; r < 16; ++r) addv[r] = 0.f;
-          }
-          float* yp = od.y + (long)b * od.y_bstride + boff;
-          if (od.accumulate) {
-  #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int dr = (r & 3) + 8 * (r >> 2);
-              oldv[r] = (tok && mrb + dr < rows_left) ? yp[(long)dr * T] : 0.f;
-            }
-          } else {
-  #pragma unroll
-            for (int r = 0; r < 16; ++r) oldv[r] = 0.f;
-          }
-  #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            if (tok && mrb + dr < rows_left) {
-              float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
-              if (od.relu) v = fmaxf(v, 0.f);
-              yp[(long)dr * T] = v;
-            }
-          }
-        }
-      }
-    }
-  } else if (EPI == EPI_GATE) {
-    // packed rows: each 64-row wave tile = 32 tanh rows (mi=0) + the matching 32
-    // sigmoid rows (mi=1) of channel group g.
-    const int Ch = a.M >> 1;
-    const int g = (m0 + wm * 64) >> 6;
-    const OutR& og = a.out[0];   // gates (B, 2Ch, T)
-    const OutR& oz = a.out[1];   // z (B, Ch, T)
-    // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
-    // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
-    // (a load behind a may-alias store would wait for the store's acknowledgement: one in-order counter).
-    int tt[2], vv[2];
-    float w0v[2], w1v[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      tt[ni] = t0 + wn * 64 + ni * 32 + li;
-      const bool tok = tt[ni] < T;
-      vv[ni] = (tok && a.lerp.P) ? a.lerp.v0[tt[ni]] : 0;
-      w0v[ni] = (tok && a.lerp.P) ? a.lerp.w0[tt[ni]] : 0.f;
-      w1v[ni] = (tok && a.lerp.P) ? a.lerp.w1[tt[ni]] : 0.f;
-    }
-    const float* Pb = a.lerp.P ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;
-    const rsrc_t rP = make_rsrc(Pb);
-    const int chl = 32 * g + 4 * lk;            // this lane's first channel; row r adds (r&3) + 8*(r>>2)
-    unsigned vP[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) vP[ni] = 4u * (unsigned)(chl * a.lerp.Tl + vv[ni]);
-    const unsigned sPq = 4u * (unsigned)(Ch * a.lerp.Tl);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);
-      const int ch = chl + dr;
-      if (ch >= Ch) continue;
-      float ba = 0.f, bb = 0.f;
-      if (og.bias) { ba += og.bias[ch]; bb += og.bias[Ch + ch]; }
-      if (og.bias2) { ba += og.bias2[ch]; bb += og.bias2[Ch + ch]; }
-      const unsigned sP = 4u * (unsigned)(dr * a.lerp.Tl);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        float pa = 0.f, pb = 0.f;
-        if (Pb) {      // h += upsample(P)[t]: condition projected at latent rate
-          pa = w0v[ni] * buf_ld(rP, vP[ni], sP) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP);
-          pb = w0v[ni] * buf_ld(rP, vP[ni], sP + sPq) + w1v[ni] * buf_ld(rP, vP[ni] + 4u, sP + sPq);
-        }
-        acc[0][ni][r] = (acc[0][ni][r] + ba) + pa;
-        acc[1][ni][r] = (acc[1][ni][r] + bb) + pb;
-      }
-    }
-    // Phase 2 -- gate and the three stores per element
-    const rsrc_t rG = make_rsrc(og.y + (long)b * og.y_bstride);
-    const rsrc_t rZ = make_rsrc(oz.y + (long)b * oz.y_bstride);
-    unsigned vT[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) vT[ni] = 4u * (unsigned)(chl * T + tt[ni]);
-    const unsigned sGq = 4u * (unsigned)(Ch * T);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);
-      if (chl + dr >= Ch) continue;
-      const unsigned sT = 4u * (unsigned)(dr * T);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        if (tt[ni] >= T) continue;
-        const float ta = fast_tanhf_(acc[0][ni][r]);
-        const float sb = sigmoidf_(acc[1][ni][r]);
-        buf_st(ta, rG, vT[ni], sT);
-        buf_st(sb, rG, vT[ni], sT + sGq);
-        buf_st(ta * sb, rZ, vT[ni], sT);
-      }
-    }
-  } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
-    const int Ch = a.M;
-    const OutR& od = a.out[0];
-    const rsrc_t rGt = make_rsrc(od.add + (long)b * od.add_bstride);
-    const rsrc_t rGh = make_rsrc(od.y + (long)b * od.y_bstride);
-    const unsigned sQ = 4u * (unsigned)(Ch * T);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int t = t0 + wn * 64 + ni * 32 + li;
-        const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
-        const bool tok = t < T;
-        const unsigned voff = 4u * (unsigned)(mb * T + t);
-        // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
-        float ta[16], sb[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          const bool ok = tok && mb + dr < Ch;
-          const unsigned so = 4u * (unsigned)(dr * T);
-          ta[r] = ok ? buf_ld(rGt, voff, so) : 0.f;
-          sb[r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          if (tok && mb + dr < Ch) {
-            const float gz = acc[mi][ni][r];
-            const unsigned so = 4u * (unsigned)(dr * T);
-            buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
-            buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
-          }
-        }
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int nk = 0;
+  for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
+  int it_beg = 0, it_end = nk;
+  if (SPLITK && a.ksplit > 1) {
+    it_beg = ksp * a.ksteps_per_split;
+    it_end = min(nk, it_beg + a.ksteps_per_split);
   }
+  const int nsteps = it_end - it_beg;
+
+  // ---- staging state of the next step to fetch (advanced once per fetch) ----------------------
+  const int s_n = tid & 127, s_c = (tid >> 7) * CPT;       // this thread's column and first channel of a step
+  const int a_hi = tid / BM, a_m = tid % BM;               // A: 16-byte words (2j + a_hi) * BM + a_m, j = 0..2
+  int seg_i = 0, c_n = 0, cin_n = 0, left = nsteps;
+  const uint4* wp = nullptr;
+  const float* xp = nullptr;
+  const float* xsafe = a.seg[0].x;
+  long wadv = 0, wl2 = 0, xadv = 0, xcs = 0;
+  bool ok_n = false;
+  auto seg_setup = [&](int s, int skip) {
+    const Seg& sg = a.seg[s];
+    cin_n = sg.cin; c_n = skip * BK;
+    wadv = 6L * sg.ldw; wl2 = 2L * sg.ldw;
+    wp = reinterpret_cast<const uint4*>(sg.w) + (long)skip * wadv + (long)a_hi * sg.ldw + m0 + a_m;
+    xcs = sg.x_cstride; xadv = (long)BK * sg.x_cstride;
+    const int tnum = (t0 + s_n) * sg.tmul + sg.toff;
+    bool ok = tnum >= 0;
+    int tin = tnum;
+    if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
+    ok_n = ok && tin < sg.Tin;
+    xp = sg.x + (long)b * sg.x_bstride + (long)(c_n + s_c) * sg.x_cstride + (ok_n ? tin : 0);
+  };
+  {
+    int s = 0, skip = it_beg;
+    while (s + 1 < a.nseg) {
+      const int steps = (a.seg[s].cin + BK - 1) / BK;
+      if (skip < steps) break;
+      skip -= steps; ++s;
+    }
+    seg_i = s;
+    seg_setup(s, skip);
+  }
+  auto advance = [&]() {
+    if (--left <= 0) return;                 // nothing further: later fetches re-read this step (never used)
+    c_n += BK;
+    if (c_n >= cin_n) seg_setup(++seg_i, 0);
+    else { wp += wadv; xp += xadv; }
+  };
+
+  // two register sets (P: even steps, Q: odd steps) so that the fetch of step i+2 is in flight while
+  // step i+1 is split and stored: every wait in the loop is then a counted vmcnt.  The fetches are
+  // unconditional (a branch around them makes hipcc drain to vmcnt(0)).
+  uint4 pa0, pa1, pa2, qa0, qa1, qa2;
+  float pb[CPT], qb[CPT];
+  unsigned pmask, qmask;
+#define X3_FETCH(A0, A1, A2, BV, MASK)                                                      \
+  {                                                                                          \
+    A0 = wp[0]; A1 = wp[wl2]; A2 = wp[2 * wl2];                                              \
+    const int nvalid = cin_n - (c_n + s_c);                                                  \
+    unsigned mk = 0;                                                                         \
+    _Pragma("unroll") for (int e = 0; e < CPT; ++e) {                                        \
+      const bool v = ok_n && e < nvalid;                                                     \
+      const float* src = v ? xp + e * xcs : xsafe;                                           \
+      BV[e] = *src;                                                                          \
+      mk |= v ? (1u << e) : 0u;                                                              \
+    }                                                                                        \
+    MASK = mk;                                                                               \
+    advance();                                                                               \
+  }
+#define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
+  {                                                                                          \
+    uint4* ad = &As[BUF][0][0][0];                                                           \
+    ad[tid] = A0; ad[NT + tid] = A1; ad[2 * NT + tid] = A2;                                  \
+    unsigned hh[CPT / 2], mm[CPT / 2], ll[CPT / 2];                                          \
+    _Pragma("unroll") for (int e = 0; e < CPT; e += 2)                                       \
+      split3((MASK >> e) & 1u ? BV[e] : 0.f, (MASK >> (e + 1)) & 1u ? BV[e + 1] : 0.f,       \
+             hh[e / 2], mm[e / 2], ll[e / 2]);                                               \
+    if constexpr (CPT == 8) {                                                                \
+      Bs[BUF][0][tid >> 7][s_n] = make_uint4(hh[0], hh[1], hh[2], hh[3]);                    \
+      Bs[BUF][1][tid >> 7][s_n] = make_uint4(mm[0], mm[1], mm[2], mm[3]);                    \
+      Bs[BUF][2][tid >> 7][s_n] = make_uint4(ll[0], ll[1], ll[2], ll[3]);                    \
+    } else {                                                                                 \
+      uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][0][tid >> 8][s_n]) + ((tid >> 7) & 1);   \
+      bd[0 * 4 * BN] = make_uint2(hh[0], hh[1]);                                             \
+      bd[1 * 4 * BN] = make_uint2(mm[0], mm[1]);                                             \
+      bd[2 * 4 * BN] = make_uint2(ll[0], ll[1]);                                             \
+    }                                                                                        \
+  }
+  auto mma = [&](auto curc) {
+    constexpr int cur = decltype(curc)::value;
+    bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];                                   // small products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  if (nsteps > 0) {
+    X3_FETCH(pa0, pa1, pa2, pb, pmask);
+    X3_FETCH(qa0, qa1, qa2, qb, qmask);
+    X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);
+    __syncthreads();
+    // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1
+    for (int i = 0; i < nsteps; i += 2) {
+      X3_FETCH(pa0, pa1, pa2, pb, pmask);           // step i + 2
+      mma(I0{});
+      X3_STAGE(qa0, qa1, qa2, qb, qmask, 1);        // step i + 1
+      __syncthreads();
+      if (i + 1 >= nsteps) break;
+      X3_FETCH(qa0, qa1, qa2, qb, qmask);           // step i + 3
+      mma(I1{});
+      X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);        // step i + 2
+      __syncthreads();
+    }
+  }
+#undef X3_FETCH
+#undef X3_STAGE
+  gemm_epilogue<EPI, WM, SPLITK>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
 }
 
 // ---------------------------------------------------------------------------
@@ -781,6 +991,38 @@ struct PackArgs { PackJob job[MAXSEG]; int njob; int bf16; };
 
 __global__ void pack_kernel(const PackArgs pa) {
   const PackJob& j = pa.job[blockIdx.y];
+  if (pa.bf16 == 2) {
+    // mode 2: per tap a slab of Rpad/16 K steps x [piece 3][k-half 2][ldw] 16-byte words, each word
+    // the same piece of 8 consecutive k of one column (conv_gemm_x3_kernel's LDS image)
+    const int groups = j.Rpad / 8;
+    const long total = (long)j.K * groups * j.mspan;
+    const long tap_words = (long)(j.Rpad / 16) * 6 * j.ldw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int mp = (int)(i % j.mspan);
+      const long rest = i / j.mspan;
+      const int kg = (int)(rest % groups);
+      const int tap = (int)(rest / groups);
+      int m = mp;
+      if (j.gate_half) {
+        const int g = mp >> 6, r = mp & 63;
+        m = (r < 32) ? (32 * g + r) : (j.gate_half + 32 * g + (r - 32));
+        if (32 * g + (r & 31) >= j.gate_half) m = j.Cm;
+      }
+      unsigned h[4], md[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int k0 = 8 * kg + e, k1 = k0 + 1;
+        const float v0 = (k0 < j.R && m < j.Cm) ? j.src[(long)k0 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
+        const float v1 = (k1 < j.R && m < j.Cm) ? j.src[(long)k1 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
+        split3(v0, v1, h[e / 2], md[e / 2], l[e / 2]);
+      }
+      uint4* d = reinterpret_cast<uint4*>(j.dst) + tap * tap_words + ((long)(kg >> 1) * 6 + (kg & 1)) * j.ldw + j.m_off + mp;
+      d[0L * j.ldw] = make_uint4(h[0], h[1], h[2], h[3]);
+      d[2L * j.ldw] = make_uint4(md[0], md[1], md[2], md[3]);
+      d[4L * j.ldw] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+    return;
+  }
   // bf16 mode: one 32-bit word holds the pair (k even, k odd); pair-row k/2 sits at row k/2 of the same
   // slab (the slab keeps its fp32 size and offsets, only its first half is used)
   const int rows = pa.bf16 ? j.Rpad / 2 : j.Rpad;
@@ -1269,6 +1511,187 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
   }
 }
 
+// wgrad3_kernel -- wgrad2_kernel's contraction in matmul mode 2 (fp32 products as six bf16 MFMA
+// products of an exact three-way split, see conv_gemm_x3_kernel): same tiles, splits, slabs, loads
+// and bias sums; both operands are activations, so both are split while they are staged, into the
+// [piece][k-half][row] 16-byte-word images the 32x32x16 fragments read with one ds_read_b128.
+template <int WM>
+__global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) {
+  constexpr int NT2 = 128 * WM, BM2 = 64 * WM;
+  constexpr int PA = BM2 + 4, PB = BN + 4;                // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
+  constexpr int NA = BM2 * 4 / NT2, NB = BN * 4 / NT2;    // float4 row loads per thread: 2 and 1 (WM=4) / 2 and 2
+  __shared__ uint4 As[2][3][2][PA];
+  __shared__ uint4 Bs[2][3][2][PB];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
+  const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;       // a.ntile_m counts 128-row slab tiles
+  // XCD-aware order (1-D grid): workgroups that run on one XCD at the same time are consecutive
+  // tiles of ONE split -- the column tiles of a segment pair share their output-gradient rows and
+  // K range, so that operand is fetched into the XCD's L2 once instead of once per column tile
+  int logical;
+  {
+    const int nblk = gridDim.x, id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int ntiles = ntm * a.ntile_n;
+  const int tile = logical % ntiles;
+  const int split = logical / ntiles;
+  const int ntg = tile % a.ntile_n;                        // column tile fastest: neighbours share gy
+  const int mt = tile / a.ntile_n;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i)
+    if (i < a.nseg && ntg >= a.seg[i].tile0) s = i;
+  const WSeg& sg = a.seg[s];
+  const int n0 = (ntg - sg.tile0) * BN;
+  const int m0 = mt * BM2;
+  // K steps of 16 t: two per WBK step of the split plan
+  const int spb = a.steps_per_b * (WBK / W2K);
+  const int g0 = split * a.steps_per_split * (WBK / W2K);
+  const int g1 = min(a.B * spb, g0 + a.steps_per_split * (WBK / W2K));
+  int b = g0 / spb;
+  int tb = (g0 - b * spb) * W2K;
+  const int Tout = a.Tout;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int s_chunk = tid & 3, s_row = tid >> 2;          // staging role: chunk of 4 t, row (+ NT2/4 per extra load)
+  constexpr int RSTEP = NT2 / 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
+
+  const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride + (long)(m0 + s_row) * Tout + 4 * s_chunk;
+  const float* xb = sg.x + (long)b * sg.x_bstride + (long)(n0 + s_row) * sg.x_cstride + 4 * s_chunk + sg.toff;
+  const long a_rstep = (long)RSTEP * Tout, b_rstep = (long)RSTEP * sg.x_cstride;
+  bool a_ok[NA], b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) a_ok[i] = (m0 + s_row + RSTEP * i) < a.M;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
+  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
+
+  float4 ra[NA], rb[NB];
+  auto load = [&]() {
+    const int t = tb + 4 * s_chunk;
+    const bool tin_range = t < Tout;                      // Tout % 4 == 0: a group is in or out as a whole
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tin_range && a_ok[i]) ra[i] = *reinterpret_cast<const float4*>(gyb + i * a_rstep + tb);
+    }
+    const int tin = t + sg.toff;
+    const bool whole = tin_range && tin >= 0 && tin + 3 < sg.Tin;
+    const bool part = tin_range && !whole && tin + 3 >= 0 && tin < sg.Tin;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[i]) {
+        const float* src = xb + i * b_rstep + tb;
+        if (whole) {
+          rb[i] = *reinterpret_cast<const float4*>(src);   // dword-aligned dwordx4: fine on gfx950
+        } else if (part) {                                 // the shifted window crosses the row's first / last sample
+          if (tin >= 0 && tin < sg.Tin) rb[i].x = src[0];
+          if (tin + 1 >= 0 && tin + 1 < sg.Tin) rb[i].y = src[1];
+          if (tin + 2 >= 0 && tin + 2 < sg.Tin) rb[i].z = src[2];
+          if (tin + 3 >= 0 && tin + 3 < sg.Tin) rb[i].w = src[3];
+        }
+      }
+    }
+  };
+  auto advance = [&]() {
+    tb += W2K;
+    if (tb >= spb * W2K) { tb = 0; ++b; gyb += a.gy_bstride; xb += sg.x_bstride; }   // same step count per item as the plan
+  };
+  // staging: this thread's 4 consecutive t of a row are half (s_chunk & 1) of the 8-k group
+  // (s_chunk >> 1) of that row; split into the three bf16 pieces and written as 8 bytes per piece
+  auto put = [&](uint4* plane0, int prow, const float4 v) {     // plane0 = &X[stage][0][s_chunk >> 1][row]
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(v.x, v.y, h0, m0, l0);
+    split3(v.z, v.w, h1, m1, l1);
+    uint2* d = reinterpret_cast<uint2*>(plane0) + (s_chunk & 1);
+    d[2 * (0 * 2 * prow)] = make_uint2(h0, h1);
+    d[2 * (1 * 2 * prow)] = make_uint2(m0, m1);
+    d[2 * (2 * 2 * prow)] = make_uint2(l0, l1);
+  };
+  auto store = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      put(&As[stage][0][s_chunk >> 1][s_row + i * RSTEP], PA, ra[i]);
+      bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) put(&Bs[stage][0][s_chunk >> 1][s_row + i * RSTEP], PB, rb[i]);
+  };
+
+  if (g0 < g1) { load(); store(0); }
+  __syncthreads();
+  for (int g = g0; g < g1; ++g) {
+    const int cur = (g - g0) & 1;
+    const bool more = g + 1 < g1;
+    if (more) { advance(); load(); }
+    bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];                                   // small products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab(s): a 256-row tile is two 128-row slab tiles
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int rowb = wm * 64 + mi * 32;                    // wave-uniform
+    const int mt_slab = (m0 + rowb) / BM;
+    if (mt_slab >= a.ntile_m) continue;
+    float* slab = a.slabs + (((long)split * a.ntile_m + mt_slab) * a.ntile_n + ntg) * (BM * BN);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = wn * 64 + ni * 32 + li;
+        slab[row * BN + col] = acc[mi][ni][r];
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 1, 4);
+      v += __shfl_xor(v, 2, 4);
+      const int row = m0 + s_row + RSTEP * i;              // global row
+      if (s_chunk == 0 && row < a.ntile_m * BM)
+        a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
+    }
+  }
+}
+
 // block = (64 outputs) x (4 split groups): each thread sums every 4th split with
 // 4 independent accumulators, then the 4 groups combine through LDS in fixed order.
 // Outputs [0,total) are weight-gradient entries, [total, total + nseg*Mpad) bias entries.
@@ -1342,6 +1765,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
 // ---------------------------------------------------------------------------
 static inline int pad16(int v) { return (v + 15) / 16 * 16; }
 static inline int pad128(int v) { return (v + 127) / 128 * 128; }
+// rows of `ldw` floats one tap's packed slab occupies: the contraction length padded to whole K
+// steps, and half as much again in mode 2 (three bf16 pieces = 6 bytes per weight instead of 4)
+static inline int slab_rows(int c) { const int r = pad16(c); return g_matmul_dtype == 2 ? r + r / 2 : r; }
 
 static bool seg_vec_ok(const Seg& s) {
   return s.tmul == 1 && s.tdiv == 1 && (s.x_cstride % 4 == 0) && (s.x_bstride % 4 == 0) &&
@@ -1379,7 +1805,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
 
 // split-K plan for a small-grid, long-K linear GEMM (see GemmArgs::ksplit); 1 = no split
 static int plan_ksplit(int M, int Tout, int B, int nk) {
-  if (g_matmul_dtype != 0 || M % 256 == 0) return 1;
+  if (g_matmul_dtype == 1 || M % 256 == 0) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(Tout, BN) * B;
   if (tiles > 128 || nk < 32) return 1;
   long s = 512 / tiles;                     // fill ~half the chip's 1024 slots
@@ -1420,7 +1846,10 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   }
   const long grid = nblk * g.ksplit;
   ProfScope ps(tag, st);
-  if (g_matmul_dtype == 1) {
+  if (g_matmul_dtype == 2) {
+    if (big) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+  } else if (g_matmul_dtype == 1) {
     if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, true>), dim3((unsigned)nblk), dim3(256), 0, st, g);
   } else {
@@ -1443,12 +1872,13 @@ static int launch_pack(PackArgs& pa, hipStream_t st) {
   long mx = 0;
   for (int i = 0; i < pa.njob; ++i) {
     long t = (long)pa.job[i].K * pa.job[i].Rpad * pa.job[i].mspan;
+    if (g_matmul_dtype == 2) t /= 8;
     if (t > mx) mx = t;
   }
   int nb = (int)((mx + 255) / 256);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  pa.bf16 = g_matmul_dtype == 1 ? 1 : 0;
+  pa.bf16 = g_matmul_dtype;
   hipLaunchKernelGGL(pack_kernel, dim3(nb, pa.njob), dim3(256), 0, st, pa);
   VQ_LAUNCH_CHECK();
   return 0;
@@ -1534,10 +1964,14 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
     sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && w.Tout % 4 == 0) ? 1 : 0;
   }
   // fp32, stride-1 segments, 16-B aligned output-gradient rows: the 16-byte-LDS kernel
-  bool fast = (g_matmul_dtype == 0) && av && g_wgrad_impl != 1;
+  bool fast = (g_matmul_dtype != 1) && av && g_wgrad_impl != 1;
   for (int i = 0; i < w.nseg; ++i) fast = fast && w.seg[i].tmul == 1 && w.seg[i].tdiv == 1;
   ProfScope ps(tag, st);
-  if (fast && w.M % 256 == 0) {
+  if (fast && g_matmul_dtype == 2 && w.M % 256 == 0) {
+    hipLaunchKernelGGL(wgrad3_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+  } else if (fast && g_matmul_dtype == 2) {
+    hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+  } else if (fast && w.M % 256 == 0) {
     hipLaunchKernelGGL(wgrad2_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast) {
     hipLaunchKernelGGL(wgrad2_kernel<2>, dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
@@ -1557,7 +1991,7 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
 using namespace vq;
 
 extern "C" int vqvae_set_matmul_dtype(int dtype) {
-  VQ_REQUIRE(dtype == 0 || dtype == 1, "set_matmul_dtype: 0 (fp32) or 1 (bf16 operands)");
+  VQ_REQUIRE(dtype >= 0 && dtype <= 2, "set_matmul_dtype: 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 as six bf16 MFMA products)");
   vq::g_matmul_dtype = dtype;
   return 0;
 }
@@ -1582,8 +2016,8 @@ static int check_conv_desc(const vqvae_conv1d_desc* d) {
 }
 
 static size_t conv_pack_floats(const vqvae_conv1d_desc* d) {
-  size_t f = (size_t)d->K * pad16(d->Cin) * pad128(d->Cout);
-  size_t b = (size_t)d->K * pad16(d->Cout) * pad128(d->Cin);
+  size_t f = (size_t)d->K * slab_rows(d->Cin) * pad128(d->Cout);
+  size_t b = (size_t)d->K * slab_rows(d->Cout) * pad128(d->Cin);
   return f > b ? f : b;
 }
 
@@ -1613,7 +2047,7 @@ extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x,
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(x && W && y && ws, "conv1d_fwd: null pointer");
   hipStream_t st = (hipStream_t)s;
-  const int ldw = pad128(d->Cout), rp = pad16(d->Cin);
+  const int ldw = pad128(d->Cout), rp = slab_rows(d->Cin);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* pk = (float*)ws;
   PackArgs pa; pa.njob = 1;
@@ -1645,7 +2079,7 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(W && gy && gx && ws, "conv1d_bwd_data: null pointer");
   hipStream_t st = (hipStream_t)s;
-  const int ldw = pad128(d->Cin), rp = pad16(d->Cout);
+  const int ldw = pad128(d->Cin), rp = slab_rows(d->Cout);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_bwd_data: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* pk = (float*)ws;
   PackArgs pa; pa.njob = 1;
@@ -1717,13 +2151,13 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
   L.gh = take((size_t)d->B * d->Cd * d->T);
-  L.pk_d = take((size_t)d->K * pad16(d->Cr) * pad128(d->Cd));      // fwd dilated conv
-  L.pk_c = take((size_t)pad16(d->Cc) * pad128(d->Cd));             // fwd cond proj
-  L.pk_o = take((size_t)pad16(Ch) * pad128(d->Cr + d->Cs));        // fwd res|skip
-  L.pk_gz_r = take((size_t)pad16(d->Cr) * pad128(Ch));             // bwd gz from g_res
-  L.pk_gz_s = take((size_t)pad16(d->Cs) * pad128(Ch));             // bwd gz from g_skip
-  L.pk_bd = take((size_t)d->K * pad16(d->Cd) * pad128(d->Cr));     // bwd-data dilated conv
-  L.pk_bc = take((size_t)pad16(d->Cd) * pad128(d->Cc));            // bwd-data cond proj
+  L.pk_d = take((size_t)d->K * slab_rows(d->Cr) * pad128(d->Cd));      // fwd dilated conv
+  L.pk_c = take((size_t)slab_rows(d->Cc) * pad128(d->Cd));             // fwd cond proj
+  L.pk_o = take((size_t)slab_rows(Ch) * pad128(d->Cr + d->Cs));        // fwd res|skip
+  L.pk_gz_r = take((size_t)slab_rows(d->Cr) * pad128(Ch));             // bwd gz from g_res
+  L.pk_gz_s = take((size_t)slab_rows(d->Cs) * pad128(Ch));             // bwd gz from g_skip
+  L.pk_bd = take((size_t)d->K * slab_rows(d->Cd) * pad128(d->Cr));     // bwd-data dilated conv
+  L.pk_bc = take((size_t)slab_rows(d->Cd) * pad128(d->Cc));            // bwd-data cond proj
   int cins[MAXSEG];
   for (int j = 0; j < d->K; ++j) cins[j] = d->Cr;
   cins[d->K] = d->Cc;
@@ -1796,7 +2230,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
   {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.nseg = d->K + (cproj ? 0 : 1);
-    const int rp = pad16(d->Cr);
+    const int rp = slab_rows(d->Cr);
     for (int j = 0; j < d->K; ++j) {
       Seg& sg = g.seg[j];
       sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
@@ -1887,7 +2321,7 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
   if (gx) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.nseg = d->K;
-    const int rp = pad16(d->Cd);
+    const int rp = slab_rows(d->Cd);
     for (int j = 0; j < d->K; ++j) {
       Seg& sg = g.seg[j];
       sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
@@ -1976,8 +2410,8 @@ __global__ void bias_sum_list_kernel(const PtrList bl, int nb, int n, float* out
 extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks) {
   if (!d || nblocks < 1 || nblocks > MAXSEG) return 0;
   const int Ch = d->Cd / 2;
-  size_t skip_pk = (size_t)nblocks * pad16(Ch) * pad128(d->Cs) + pad128(d->Cs);
-  size_t gc_pk = (size_t)nblocks * pad16(d->Cd) * pad128(d->Cc);
+  size_t skip_pk = (size_t)nblocks * slab_rows(Ch) * pad128(d->Cs) + pad128(d->Cs);
+  size_t gc_pk = (size_t)nblocks * slab_rows(d->Cd) * pad128(d->Cc);
   int cz[MAXSEG];
   for (int i = 0; i < nblocks; ++i) cz[i] = Ch;
   // the res-conv gradients skip blocks without a residual output (the last one), and the split
@@ -2004,7 +2438,7 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_skip_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
   const int Ch = d->Cd / 2, T = d->T;
-  const int ld = pad128(d->Cs), rp = pad16(Ch);
+  const int ld = pad128(d->Cs), rp = slab_rows(Ch);
   float* w = (float*)ws;
   float* bsum = w + (size_t)nblocks * rp * ld;
   PackArgs pa; pa.njob = 0;
@@ -2040,7 +2474,7 @@ extern "C" int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblock
   if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_gcond_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
   const int T = d->T;
-  const int ld = pad128(d->Cc), rp = pad16(d->Cd);
+  const int ld = pad128(d->Cc), rp = slab_rows(d->Cd);
   float* w = (float*)ws;
   PackArgs pa; pa.njob = 0;
   for (int l = 0; l < nblocks; ++l)

@@ -6,6 +6,7 @@ vqvae_stream_*).  One process drives one GPU on one stream; every kernel of the
 library is enqueued on ``stream()``.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -34,6 +35,7 @@ def init(device=0):
     _lib.call('vqvae_stream_create', C.byref(s))
     _state['stream'] = s
     _state['device'] = device
+    set_matmul_dtype(default_matmul_dtype())
 
 
 def available():
@@ -110,9 +112,16 @@ def wait_event(s, event):
     _lib.call('vqvae_stream_wait_event', s, event.h)
 
 
+def default_matmul_dtype():
+    """The matmul mode a process starts in: $VQVAE_MATMUL if set, else 'float32'."""
+    return os.environ.get('VQVAE_MATMUL', 'float32')
+
+
 def set_matmul_dtype(name):
-    """'float32' (default, exact fp32 MFMA) or 'bfloat16' (bf16 operands, fp32 accumulate)."""
-    code = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1}[name]
+    """'float32' (fp32 MFMA), 'bfloat16' (operands rounded to bf16, fp32 accumulate) or
+    'float32x3' (fp32 products as six bf16 MFMA products of an exact three-way operand split:
+    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2")."""
+    code = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3': 2, 'fp32x3': 2}[name]
     _lib.call('vqvae_set_matmul_dtype', code)
 
 

@@ -435,22 +435,24 @@ class WaveNet(Chain):
         """modules.py:169-230 as one fused kernel pair."""
         return F.mixture_of_logistics_nll(y, t, self.quantize, self.log_scale_min)
 
-    def __call__(self, x, condition, generating=False):
-        # `generating` is accepted and ignored, as in modules.py:148-160
+    def embed_input(self, x):
+        """The causal embed conv (modules.py:151-152) on whichever form of the input arrived."""
         if np.dtype(x.dtype) == np.int32:
             # device-side input pipeline: x holds mu-law bin indices (B, T) instead of the
             # one-hot (B, q, T, 1) tensor -- the embed conv is a gather of its weight columns
-            x = F.embed_conv_indices(x, self.embed.W, self.embed.b)
-        elif (self.input_dim >= 8 and self.embed.W.data is not None and x.shape[1] == self.embed.W.shape[1]
-              and self.embed.pad[0] == self.embed.ksize[0] - 1 and self.embed.stride[0] == 1
-              and _lib.load().vqvae_get_matmul_dtype() == 0):      # bf16 mode rounds W: dense kernels
+            return F.embed_conv_indices(x, self.embed.W, self.embed.b)
+        if (self.input_dim >= 8 and self.embed.W.data is not None and x.shape[1] == self.embed.W.shape[1]
+                and self.embed.pad[0] == self.embed.ksize[0] - 1 and self.embed.stride[0] == 1
+                and _lib.load().vqvae_get_matmul_dtype() != 1):      # bf16 mode rounds W: dense kernels
             # the reference's one-hot float input (utils.py:85-87): same causal conv, but the device
             # checks for one-hot-ness and then gathers / bincounts instead of multiplying by zeros
-            x = F.embed_conv_onehot(x, self.embed.W, self.embed.b)
-        else:
-            length = x.shape[2]
-            # causal conv: pad 1 then crop to `length` (modules.py:151-152), fused as out_len
-            x = self.embed(x, out_len=length)
+            return F.embed_conv_onehot(x, self.embed.W, self.embed.b)
+        # causal conv: pad 1 then crop to the input length (modules.py:151-152), fused as out_len
+        return self.embed(x, out_len=x.shape[2])
+
+    def __call__(self, x, condition, generating=False):
+        # `generating` is accepted and ignored, as in modules.py:148-160
+        x = self.embed_input(x)
         # residual & skip connections (modules.py:155)
         z = F.relu(self.resnet(x, condition))
         # output (modules.py:158-159); the ReLU after proj1 is fused into its epilogue

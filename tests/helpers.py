@@ -129,7 +129,7 @@ def device_relu_sites(model, x_enc, x_dec, speaker):
         cond = model.condition_embed(e, Variable(backend.to_device(np.ascontiguousarray(speaker))))
         wn = getattr(model.decoder, 'target', model.decoder)
         xd = Variable(backend.to_device(np.ascontiguousarray(x_dec[..., None])))
-        x0 = wn.embed(xd, out_len=x_dec.shape[2])
+        x0 = wn.embed_input(xd)
         s = F.relu(wn.resnet(x0, cond))
         z1 = wn.proj1(s, relu=True)
         return {'enc': enc, 'ce': ce, 's': s.data.get()[..., 0], 'z1': z1.data.get()[..., 0]}

@@ -121,7 +121,7 @@ def _config4_device_step(gpu, batch, bf16, lazy=True, want_sites=False):
         return P, idx, [float(l.data.get()) for l in upd.last_losses], _grads_by_name(model, opt, False), sites, params
     finally:
         F.LAZY_CONDITION = True
-        gpu.set_matmul_dtype('float32')
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
 def _to64(t):
@@ -274,7 +274,7 @@ def test_config4_full_size_properties_bf16(gpu):
             assert y_all.shape == (B, 30, T, 1)
             np.testing.assert_array_equal(y_all[5:6], outputs(slice(5, 6)))
     finally:
-        gpu.set_matmul_dtype('float32')
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
 @pytest.mark.parametrize('shape', [(80, 120, 128, 8192), (300, 120, 64, 512), (70, 120, 64, 16)])

@@ -118,7 +118,9 @@ def test_mol_deep_stack_matches_oracle(gpu):
     g_dev = _grads_by_name(model, opt, False)
     for name, arr in G.items():
         dn = H._dev_name(name, False)
-        assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 2e-4, 'mol grad ' + dn)
+        # 3e-4: the fp32 oracle is itself 4e-5..5e-4 from a float64 evaluation of this loss (the
+        # cdf_plus - cdf_min cancellation; tests/test_gpu_configs.py compares configs[4] with float64)
+        assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 3e-4, 'mol grad ' + dn)
 
 
 def test_snapshot_resume_is_bit_identical(gpu, tmp_path):
@@ -278,7 +280,7 @@ def test_bf16_operand_mode_training_step(gpu):
             return P, [float(l.data.get()) for l in upd.last_losses], _grads_by_name(model, opt, False)
         finally:
             F.LAZY_CONDITION = True
-            gpu.set_matmul_dtype('float32')
+            gpu.set_matmul_dtype(gpu.default_matmul_dtype())
     # (a) operand-rounding oracle
     P, l_dev, g_dev = device_step(lazy=False)
     O.set_bf16(True)

@@ -15,9 +15,12 @@ if which == 'c0':
     P_ema = copy.deepcopy(P['decoder'])
     model.to_gpu(); opt = Adam(2e-4); opt.setup(model)
     batch = O.synth_batch(1, length=T, n_speaker=cfg['n_speaker'], seed=71)
-    upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0); upd.update()
+    upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+    sites = H.device_relu_sites(model, batch[0], batch[1], batch[2])
+    upd.update()
     with TC._limit_blas():
-        losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'], ema=P_ema, ema_decay=0.9999)
+        losses, cache, G, flips = H.oracle_train_step_aligned(P, {}, batch, cfg['n_loop'], cfg['n_layer'], sites, ema=P_ema, ema_decay=0.9999)
+    print('flips', flips)
     g_dev = _grads_by_name(model, opt, True)
     rows = []
     for name, arr in G.items():
