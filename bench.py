@@ -47,6 +47,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chi
 # residual 1x1 conv is a separate launch the extra term is 0.
 ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
                    '+ latent-rate condition lerp + tanh*sigmoid gate)')
+ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
+                      'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
+                      '+ latent-rate condition lerp + tanh*sigmoid gate)')
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense
+X3_PRODUCTS = 6                     # bf16 MFMA products per fp32 product in matmul mode 'float32x3'
 
 
 def FUSED_RES_FLOP_PER_POS(cfg):
@@ -359,6 +364,9 @@ def main():
                          'shape, latency-bound) and ~1 M (default 8738 x 120 = 1 048 560)')
     ap.add_argument('--bf16', action='store_true',
                     help='bf16 MFMA operands with fp32 accumulation (configs[4] precision)')
+    ap.add_argument('--matmul', choices=['float32x3', 'float32'], default=None,
+                    help="fp32 matmul mode: 'float32x3' (default; fp32 products as six bf16 MFMA products of an "
+                         "exact three-way operand split) or 'float32' (v_mfma_f32_32x32x2_f32)")
     ap.add_argument('--index-input', action='store_true',
                     help='feed x_dec as mu-law bin indices produced on the device (device-side input '
                          'pipeline) instead of the reference\'s one-hot float tensor')
@@ -389,6 +397,9 @@ def main():
     backend.init(local)
     if args.bf16:
         backend.set_matmul_dtype('bfloat16')
+    elif args.matmul:
+        backend.set_matmul_dtype(args.matmul)
+    mode = 'bfloat16' if args.bf16 else (args.matmul or backend.default_matmul_dtype())
     if args.no_overlap:
         backend.set_overlap(False)
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
@@ -441,6 +452,20 @@ def main():
     _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
     losses = [float(l.data.get()) for l in upd.last_losses]
     seen = comm.ranks_seen()
+    ref_ms = None
+    if n == 1 and mode == 'float32x3' and not args.no_cpu_baseline:
+        # the same step with the fp32 MFMA kernels, for reference (not part of the timed region above)
+        backend.set_matmul_dtype('float32')
+        for _ in range(2):
+            upd.update()
+        backend.synchronize()
+        k = min(args.steps, 5)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            upd.update()
+        backend.synchronize()
+        ref_ms = 1e3 * (time.perf_counter() - t1) / k
+        backend.set_matmul_dtype(mode)
 
     if rank == 0:
         T = cfg['length']
@@ -452,10 +477,13 @@ def main():
         # contraction (computed once at the latent rate and lerped in the epilogue)
         flop_conv = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
         flop = flop_conv + FUSED_RES_FLOP_PER_POS(cfg) * B * T
-        peak = 2500.0 if args.bf16 else PEAK_FP32_MFMA_TFLOPS      # dense bf16 MFMA peak
+        x3 = mode == 'float32x3'
+        # the pipe that bounds the kernel: fp32 MFMA; the bf16 MFMA pipe ('bfloat16'); or the bf16 pipe
+        # doing X3_PRODUCTS products per algorithmic fp32 product ('float32x3')
+        peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else (PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS)
         avg_ms = tot.value / max(cnt.value, 1)
         ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
-        key = ('c2' if args.workload == 'c2' else 'c5') + ('_bf16' if args.bf16 else '') + '_B%d' % B
+        key = ('c2' if args.workload == 'c2' else 'c5') + ('_bf16' if args.bf16 else ('' if x3 else '_fp32mfma')) + '_B%d' % B
         traffic, tsrc = measured_traffic(key)
         out = {
             'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
@@ -464,6 +492,13 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16 operands, f32 accumulate' if args.bf16 else 'f32',
+            'matmul': {'bfloat16': 'operands rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulate',
+                       'float32': 'v_mfma_f32_32x32x2_f32',
+                       'float32x3': 'fp32 operands, fp32 results: each operand split EXACTLY into three bf16 '
+                                    '(h + m + l), six of the nine products on v_mfma_f32_32x32x16_bf16 with fp32 '
+                                    'accumulate (the dropped three are < 2^-25 relative); error against float64 is at '
+                                    'or below the fp32 MFMA path\'s (tests/test_gpu_kernels.py::'
+                                    'test_float32x3_is_as_accurate_as_fp32_mfma)'}[mode],
             'data': 'synthetic' + (' (x_dec as device-computed bin indices)' if args.index_input else ''),
             'samples_per_sec_per_gpu': value / n,
             'config': {'workload': ('BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
@@ -476,13 +511,21 @@ def main():
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
             'trainable_params': int(n_params),
             'losses_last_step': losses,
-            'roofline': {'bound': 'mfma', 'kernel': ROOFLINE_KERNEL,
+            'roofline': {'bound': 'mfma', 'kernel': ROOFLINE_KERNEL_X3 if x3 else ROOFLINE_KERNEL,
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                         'peak_is': ('dense bf16 MFMA peak' if args.bf16 else
+                                     ('dense bf16 MFMA peak / %d bf16 products per fp32 product; achieved counts '
+                                      'algorithmic fp32 FLOPs' % X3_PRODUCTS if x3 else 'fp32 MFMA peak')),
                          'frac': (ach / peak) if ach else None,
+                         'achieved_vs_fp32_mfma_peak': (ach / PEAK_FP32_MFMA_TFLOPS) if (ach and not args.bf16) else None,
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
         }
+        if ref_ms is not None:
+            out['fp32_mfma_reference'] = {'ms_per_step': ref_ms, 'value': B * T / (ref_ms * 1e-3), 'unit': 'samples/s',
+                                          'note': "the same job with --matmul float32 (v_mfma_f32_32x32x2_f32), "
+                                                  "%d steps after 2 warm-up steps, outside the timed region" % min(args.steps, 5)}
         if n == 1 and not args.no_cpu_baseline and args.workload == 'c2' and not args.bf16:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -1579,33 +1579,37 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
 
+  // Fetches are branch-free (a branch around a load makes hipcc wait vmcnt(0) right behind it, which
+  // exposed every load of the step before the MFMAs): an invalid row or group reads a safe address,
+  // a group of the shifted window that crosses the row's first / last sample is read from the
+  // clamped in-row position; the masks and the shift are applied when the step is staged.
   float4 ra[NA], rb[NB];
+  unsigned vmask = 0;            // bit i: A row i valid; bit 8 + i: B row i has a sample in range
+  int bshift = 0;                // clamped start - wanted start of the B group
+  int btin = 0;                  // wanted start (input time) of the B group
+  const float* safe_a = (sg.gy ? sg.gy : a.gy);
+  const float* safe_b = sg.x;
   auto load = [&]() {
     const int t = tb + 4 * s_chunk;
     const bool tin_range = t < Tout;                      // Tout % 4 == 0: a group is in or out as a whole
+    unsigned mk = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tin_range && a_ok[i]) ra[i] = *reinterpret_cast<const float4*>(gyb + i * a_rstep + tb);
+      const bool v = tin_range && a_ok[i];
+      ra[i] = *reinterpret_cast<const float4*>(v ? gyb + i * a_rstep + tb : safe_a);
+      mk |= v ? (1u << i) : 0u;
     }
     const int tin = t + sg.toff;
-    const bool whole = tin_range && tin >= 0 && tin + 3 < sg.Tin;
-    const bool part = tin_range && !whole && tin + 3 >= 0 && tin < sg.Tin;
+    const bool any = tin_range && tin + 3 >= 0 && tin < sg.Tin;
+    const int tc = min(max(tin, 0), sg.Tin - 4);
+    btin = tin; bshift = tc - tin;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_ok[i]) {
-        const float* src = xb + i * b_rstep + tb;
-        if (whole) {
-          rb[i] = *reinterpret_cast<const float4*>(src);   // dword-aligned dwordx4: fine on gfx950
-        } else if (part) {                                 // the shifted window crosses the row's first / last sample
-          if (tin >= 0 && tin < sg.Tin) rb[i].x = src[0];
-          if (tin + 1 >= 0 && tin + 1 < sg.Tin) rb[i].y = src[1];
-          if (tin + 2 >= 0 && tin + 2 < sg.Tin) rb[i].z = src[2];
-          if (tin + 3 >= 0 && tin + 3 < sg.Tin) rb[i].w = src[3];
-        }
-      }
+      const bool v = any && b_ok[i];
+      rb[i] = *reinterpret_cast<const float4*>(v ? xb + i * b_rstep + tb + (tc - tin) : safe_b);   // dword-aligned dwordx4: fine on gfx950
+      mk |= v ? (1u << (8 + i)) : 0u;
     }
+    vmask = mk;
   };
   auto advance = [&]() {
     tb += W2K;
@@ -1623,13 +1627,30 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
     d[2 * (2 * 2 * prow)] = make_uint2(l0, l1);
   };
   auto store = [&](int stage) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      put(&As[stage][0][s_chunk >> 1][s_row + i * RSTEP], PA, ra[i]);
-      bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+      const float4 v = (vmask >> i) & 1u ? ra[i] : zero4;
+      put(&As[stage][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);
+      bsum[i] += (v.x + v.y) + (v.z + v.w);
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) put(&Bs[stage][0][s_chunk >> 1][s_row + i * RSTEP], PB, rb[i]);
+    for (int i = 0; i < NB; ++i) {
+      float4 v = (vmask >> (8 + i)) & 1u ? rb[i] : zero4;
+      if (bshift != 0) {                                   // the group crosses a row end: element e is loaded[e - bshift]
+        const float l[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int src = e - bshift, tt = btin + e;
+          float pick = l[0];
+          pick = src == 1 ? l[1] : pick; pick = src == 2 ? l[2] : pick; pick = src == 3 ? l[3] : pick;
+          o[e] = (src >= 0 && src < 4 && tt >= 0 && tt < sg.Tin) ? pick : 0.f;
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      put(&Bs[stage][0][s_chunk >> 1][s_row + i * RSTEP], PB, v);
+    }
   };
 
   if (g0 < g1) { load(); store(0); }
@@ -1637,7 +1658,9 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   for (int g = g0; g < g1; ++g) {
     const int cur = (g - g0) & 1;
     const bool more = g + 1 < g1;
-    if (more) { advance(); load(); }
+    if (more) advance();
+    load();                                               // unconditional: the last step re-reads itself (unused)
+    __builtin_amdgcn_sched_barrier(0);                    // keep the fetches above the MFMAs (the scheduler sinks them to their use)
     bf16x8 af[2][3], bf[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -21,3 +21,12 @@ def gpu():
     import vqvae_amd.backend as backend
     backend.init(0)
     return backend
+
+
+@pytest.fixture(params=['float32x3', 'float32'])
+def matmul_mode(request, gpu):
+    """Both fp32-accurate matmul modes: 'float32x3' (six bf16 MFMA products per fp32 product, the
+    default) and 'float32' (fp32 MFMA); 'bfloat16' has its own tests below."""
+    gpu.set_matmul_dtype(request.param)
+    yield request.param
+    gpu.set_matmul_dtype(gpu.default_matmul_dtype())

@@ -38,7 +38,7 @@ def _limit_blas(n=16):
         return contextlib.nullcontext()
 
 
-def test_config0_whole_step_matches_oracle(gpu):
+def test_config0_whole_step_matches_oracle(gpu, matmul_mode):
     import copy
     import vqvae_amd as V
     from vqvae_amd.optimizers import Adam
@@ -132,7 +132,7 @@ def _to64(t):
     return t.astype(np.float64) if isinstance(t, np.ndarray) and t.dtype == np.float32 else t
 
 
-def test_config4_architecture_fp32_whole_step_matches_oracle(gpu):
+def test_config4_architecture_fp32_whole_step_matches_oracle(gpu, matmul_mode):
     """The configs[4] network exactly as configured -- mixture-of-logistics loss, input_dim=1, 30
     output channels, n_loop=4 x n_layer=10 = 40 blocks (grouped ResidualNet contractions), 256
     channels, d=64 k=512 -- one whole training step in fp32 (length 2048: every dilation up to 512

@@ -43,7 +43,7 @@ CONV_CASES = [
 
 @pytest.mark.parametrize('case', CONV_CASES)
 @pytest.mark.parametrize('relu', [False, True])
-def test_conv1d_fwd_bwd(gpu, case, relu):
+def test_conv1d_fwd_bwd(gpu, matmul_mode, case, relu):
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     B, Cin, Tin, Cout, K, stride, pad, dil, crop = case
@@ -117,7 +117,7 @@ def _rb_params(rs, Cr, Cd, Cs, Cc, K):
 
 
 @pytest.mark.parametrize('case', RB_CASES)
-def test_resblock_fwd_bwd(gpu, case):
+def test_resblock_fwd_bwd(gpu, matmul_mode, case):
     from vqvae_amd.core import Variable
     from vqvae_amd.wavenet import ResidualBlockFunction
     B, T, Cr, Cd, Cs, Cc, K, dil = case
@@ -395,6 +395,76 @@ def test_device_input_pipeline(gpu):
     assert_close_scaled(vb2.grad.get(), vb1.grad.get(), 1e-5, 'bincount vs dense bias gradient')
 
 
+def _conv64(x, W, b, stride, pad, dil):
+    B, Cin, Tin = x.shape
+    Cout, _, K = W.shape
+    nat = O.conv_out_len(Tin, K, stride, pad, dil)
+    xp = np.zeros((B, Cin, Tin + 2 * pad), np.float64)
+    xp[:, :, pad:pad + Tin] = x
+    y = np.zeros((B, Cout, nat), np.float64)
+    gy = None
+    for k in range(K):
+        y += np.einsum('oc,bct->bot', W[:, :, k].astype(np.float64), xp[:, :, k * dil: k * dil + (nat - 1) * stride + 1: stride])
+    return y + b.astype(np.float64)[None, :, None]
+
+
+def _bwd64(x, W, gy, stride, pad, dil):
+    B, Cin, Tin = x.shape
+    K = W.shape[2]
+    nat = gy.shape[2]
+    xp = np.zeros((B, Cin, Tin + 2 * pad), np.float64)
+    xp[:, :, pad:pad + Tin] = x
+    gxp = np.zeros_like(xp)
+    gW = np.zeros(W.shape, np.float64)
+    g = gy.astype(np.float64)
+    for k in range(K):
+        sl = slice(k * dil, k * dil + (nat - 1) * stride + 1, stride)
+        gW[:, :, k] = np.einsum('bot,bct->oc', g, xp[:, :, sl])
+        gxp[:, :, sl] += np.einsum('oc,bot->bct', W[:, :, k].astype(np.float64), g)
+    return gxp[:, :, pad:pad + Tin], gW
+
+
+ACC_CASES = [(2, 32, 256, 32, 4, 2, 1, 1), (2, 96, 300, 80, 2, 1, 8, 8), (2, 40, 77, 50, 3, 2, 2, 3),
+             (2, 1280, 120, 192, 1, 1, 0, 1), (3, 520, 90, 70, 3, 1, 2, 2), (1, 256, 1000, 512, 2, 1, 3, 3),
+             (2, 256, 2048, 256, 2, 1, 64, 64), (2, 512, 1024, 512, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize('case', ACC_CASES)
+def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
+    """'float32x3' computes every fp32 product as six bf16 MFMA products of an exact three-way split
+    of both operands (csrc/conv_gemm.hip, matmul mode 2).  It is an fp32 mode, not a reduced-precision
+    one: against a float64 evaluation, forward, backward-data and backward-weight are (1) within
+    2e-6 of the result's scale and (2) no further away than the fp32 MFMA path ('float32') is, up to
+    25 % + 1e-7 of slack for the different summation order."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Tin, Cout, K, stride, pad, dil = case
+    rs = np.random.RandomState(zlib.crc32(repr(case).encode()))
+    x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    y64 = _conv64(x, W, b, stride, pad, dil)
+    gy = rs.standard_normal(y64.shape).astype(np.float32)
+    gx64, gW64 = _bwd64(x, W, gy, stride, pad, dil)
+    err = {}
+    try:
+        for mode in ('float32', 'float32x3'):
+            gpu.set_matmul_dtype(mode)
+            vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+            y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil)
+            ey = np.abs(y.data.get()[..., 0] - y64).max() / np.abs(y64).max()
+            y.grad = _dev(gpu, to4(gy))
+            y.backward()
+            ex = np.abs(vx.grad.get()[..., 0] - gx64).max() / np.abs(gx64).max()
+            ew = np.abs(vW.grad.get()[..., 0] - gW64).max() / np.abs(gW64).max()
+            err[mode] = (ey, ex, ew)
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+    for name, e3, e1 in zip(('y', 'gx', 'gW'), err['float32x3'], err['float32']):
+        assert e3 <= 2e-6, '%s: float32x3 is %.3e of scale from float64' % (name, e3)
+        assert e3 <= 1.25 * e1 + 1e-7, '%s: float32x3 %.3e vs fp32 MFMA %.3e (of scale, against float64)' % (name, e3, e1)
+
+
 @pytest.fixture
 def bf16_mode(gpu):
     gpu.set_matmul_dtype('bfloat16')
@@ -507,7 +577,7 @@ def test_resstack_workspace_queries_cover_every_group_size(gpu):
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 256, 300), (1, 48, 50, 37), (3, 256, 256, 128)])
-def test_embed_conv_onehot_auto_paths(gpu, shape):
+def test_embed_conv_onehot_auto_paths(gpu, matmul_mode, shape):
     """The decoder's embed conv on the reference's one-hot float input (modules.py:127-128,151-152):
     a one-hot tensor takes the gather / bincount forms (forward bit-identical to the dense conv, weight
     gradient vs the oracle), the same call on a tensor that is NOT one-hot (one entry 0.5, one column
@@ -540,7 +610,7 @@ def test_embed_conv_onehot_auto_paths(gpu, shape):
         assert_close(y.data.get()[..., 0], y_ref, 1e-5, 'embed conv fwd (flag %d)' % want_flag)
         if want_flag:
             y_dense = F.convolution_1d(vx, vW, vb, pad=1, out_len=T)
-            if gpu.default_matmul_dtype() == 'float32':
+            if matmul_mode == 'float32':
                 # fp32 MFMA: multiplying by 1.0 and adding zeros -- bit-identical to the gather
                 np.testing.assert_array_equal(y.data.get(), y_dense.data.get())
             else:

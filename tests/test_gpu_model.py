@@ -33,7 +33,7 @@ def _grads_by_name(model, opt, ema):
 
 
 @pytest.mark.parametrize('ema', [False, True])
-def test_train_steps_match_oracle(gpu, ema):
+def test_train_steps_match_oracle(gpu, matmul_mode, ema):
     import vqvae_amd as V
     from vqvae_amd.optimizers import Adam
     cfg = dict(H.SMALL)

@@ -22,6 +22,7 @@ run_pmc() {     # name, counters, bench args...
 }
 run_stats c2 --steps 10 --warmup 3
 run_stats c2_single_stream --steps 10 --warmup 3 --no-overlap
+run_stats c2_fp32mfma --steps 10 --warmup 3 --matmul float32
 run_stats c4 --workload c4 --steps 5 --warmup 2
 run_stats c4_N1920 --workload c4 --vq-rows 1920 --steps 20 --warmup 3
 run_stats c5_bf16 --workload c5 --bf16 --steps 5 --warmup 2
