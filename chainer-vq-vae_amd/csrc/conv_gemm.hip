@@ -802,7 +802,8 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 }
 
 template <int EPI, int WM>
-__global__ __launch_bounds__(128 * WM, 2) void conv_gemm_x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
+  constexpr int SCHED = (WM == 4) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
   constexpr int BM = 64 * WM, NT = 128 * WM;
   constexpr int NQ = NT / 128;            // staging threads per tile column
   constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 (WM = 2) or 4
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_gemm_x3_kernel(const GemmArg
       mk |= v ? (1u << e) : 0u;                                                              \
     }                                                                                        \
     MASK = mk;                                                                               \
-    advance();                                                                               \
+    if (!SCHED) advance();                                                                   \
   }
 #define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
   {                                                                                          \
@@ -948,13 +949,25 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_gemm_x3_kernel(const GemmArg
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
+    if (SCHED) {
+      // one MFMA (32 pipe cycles), then a few of the step's other instructions (the split of the next
+      // step, the addresses of the one after): hipcc otherwise issues 16 of the 24 MFMAs back to back
+      // behind the barrier and everything else after them, with the matrix pipe idle
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SCHED, 0);
+      }
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
   if (nsteps > 0) {
     X3_FETCH(pa0, pa1, pa2, pb, pmask);
+    if (SCHED) advance();
     X3_FETCH(qa0, qa1, qa2, qb, qmask);
+    if (SCHED) advance();
     X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);
     __syncthreads();
     // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1
@@ -962,11 +975,13 @@ __global__ __launch_bounds__(128 * WM, 2) void conv_gemm_x3_kernel(const GemmArg
       X3_FETCH(pa0, pa1, pa2, pb, pmask);           // step i + 2
       mma(I0{});
       X3_STAGE(qa0, qa1, qa2, qb, qmask, 1);        // step i + 1
+      if (SCHED) advance();
       __syncthreads();
       if (i + 1 >= nsteps) break;
       X3_FETCH(qa0, qa1, qa2, qb, qmask);           // step i + 3
       mma(I1{});
       X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);        // step i + 2
+      if (SCHED) advance();
       __syncthreads();
     }
   }
@@ -1579,38 +1594,39 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
 
-  // Fetches are branch-free (a branch around a load makes hipcc wait vmcnt(0) right behind it, which
-  // exposed every load of the step before the MFMAs): an invalid row or group reads a safe address,
-  // a group of the shifted window that crosses the row's first / last sample is read from the
-  // clamped in-row position; the masks and the shift are applied when the step is staged.
-  float4 ra[NA], rb[NB];
-  unsigned vmask = 0;            // bit i: A row i valid; bit 8 + i: B row i has a sample in range
-  int bshift = 0;                // clamped start - wanted start of the B group
-  int btin = 0;                  // wanted start (input time) of the B group
+  // Fetches are branch-free and unconditional (a branch around a load makes hipcc wait vmcnt(0) right
+  // behind it, which exposed every load of the step before the MFMAs): an invalid row or group reads
+  // a safe address, a group of the shifted window that crosses the row's first / last sample is
+  // read from the clamped in-row position; masks and shift are applied when the step is staged.
+  // Two register sets (P: even steps, Q: odd steps): the fetch of step i+2 is in flight while step
+  // i+1 is split and stored, so every wait in the loop is a counted vmcnt.
+  float4 pra[NA], prb[NB], qra[NA], qrb[NB];
+  unsigned pvm = 0, qvm = 0;     // bit i: A row i valid; bit 8 + i: B row i has a sample in range
+  int pbs = 0, qbs = 0;          // clamped start - wanted start of the B group
+  int pbt = 0, qbt = 0;          // wanted start (input time) of the B group
   const float* safe_a = (sg.gy ? sg.gy : a.gy);
   const float* safe_b = sg.x;
-  auto load = [&]() {
-    const int t = tb + 4 * s_chunk;
-    const bool tin_range = t < Tout;                      // Tout % 4 == 0: a group is in or out as a whole
-    unsigned mk = 0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const bool v = tin_range && a_ok[i];
-      ra[i] = *reinterpret_cast<const float4*>(v ? gyb + i * a_rstep + tb : safe_a);
-      mk |= v ? (1u << i) : 0u;
-    }
-    const int tin = t + sg.toff;
-    const bool any = tin_range && tin + 3 >= 0 && tin < sg.Tin;
-    const int tc = min(max(tin, 0), sg.Tin - 4);
-    btin = tin; bshift = tc - tin;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const bool v = any && b_ok[i];
-      rb[i] = *reinterpret_cast<const float4*>(v ? xb + i * b_rstep + tb + (tc - tin) : safe_b);   // dword-aligned dwordx4: fine on gfx950
-      mk |= v ? (1u << (8 + i)) : 0u;
-    }
-    vmask = mk;
-  };
+#define W3_FETCH(RA, RB, VM, BS, BT)                                                          \
+  {                                                                                            \
+    const int t = tb + 4 * s_chunk;                                                            \
+    const bool tin_range = t < Tout;               /* Tout % 4 == 0: a group is in or out as a whole */ \
+    unsigned mk = 0;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
+      const bool v = tin_range && a_ok[i];                                                     \
+      RA[i] = *reinterpret_cast<const float4*>(v ? gyb + i * a_rstep + tb : safe_a);           \
+      mk |= v ? (1u << i) : 0u;                                                                \
+    }                                                                                          \
+    const int tin = t + sg.toff;                                                               \
+    const bool any = tin_range && tin + 3 >= 0 && tin < sg.Tin;                                \
+    const int tc = min(max(tin, 0), sg.Tin - 4);                                               \
+    BT = tin; BS = tc - tin;                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
+      const bool v = any && b_ok[i];      /* dword-aligned dwordx4: fine on gfx950 */          \
+      RB[i] = *reinterpret_cast<const float4*>(v ? xb + i * b_rstep + tb + (tc - tin) : safe_b); \
+      mk |= v ? (1u << (8 + i)) : 0u;                                                          \
+    }                                                                                          \
+    VM = mk;                                                                                   \
+  }
   auto advance = [&]() {
     tb += W2K;
     if (tb >= spb * W2K) { tb = 0; ++b; gyb += a.gy_bstride; xb += sg.x_bstride; }   // same step count per item as the plan
@@ -1626,41 +1642,32 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
     d[2 * (1 * 2 * prow)] = make_uint2(m0, m1);
     d[2 * (2 * 2 * prow)] = make_uint2(l0, l1);
   };
-  auto store = [&](int stage) {
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const float4 v = (vmask >> i) & 1u ? ra[i] : zero4;
-      put(&As[stage][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);
-      bsum[i] += (v.x + v.y) + (v.z + v.w);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      float4 v = (vmask >> (8 + i)) & 1u ? rb[i] : zero4;
-      if (bshift != 0) {                                   // the group crosses a row end: element e is loaded[e - bshift]
-        const float l[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int src = e - bshift, tt = btin + e;
-          float pick = l[0];
-          pick = src == 1 ? l[1] : pick; pick = src == 2 ? l[2] : pick; pick = src == 3 ? l[3] : pick;
-          o[e] = (src >= 0 && src < 4 && tt >= 0 && tt < sg.Tin) ? pick : 0.f;
-        }
-        v = make_float4(o[0], o[1], o[2], o[3]);
-      }
-      put(&Bs[stage][0][s_chunk >> 1][s_row + i * RSTEP], PB, v);
-    }
-  };
-
-  if (g0 < g1) { load(); store(0); }
-  __syncthreads();
-  for (int g = g0; g < g1; ++g) {
-    const int cur = (g - g0) & 1;
-    const bool more = g + 1 < g1;
-    if (more) advance();
-    load();                                               // unconditional: the last step re-reads itself (unused)
-    __builtin_amdgcn_sched_barrier(0);                    // keep the fetches above the MFMAs (the scheduler sinks them to their use)
+#define W3_STAGE(RA, RB, VM, BS, BT, STAGE, REAL)                                             \
+  {                                                                                            \
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
+      const float4 v = (VM >> i) & 1u ? RA[i] : zero4;                                         \
+      put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                              \
+      if (REAL) bsum[i] += (v.x + v.y) + (v.z + v.w);                                          \
+    }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
+      float4 v = (VM >> (8 + i)) & 1u ? RB[i] : zero4;                                         \
+      if (BS != 0) {                /* the group crosses a row end: element e is loaded[e - BS] */ \
+        const float l[4] = {v.x, v.y, v.z, v.w};                                               \
+        float o[4];                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+          const int src = e - BS, tt = BT + e;                                                 \
+          float pick = l[0];                                                                   \
+          pick = src == 1 ? l[1] : pick; pick = src == 2 ? l[2] : pick; pick = src == 3 ? l[3] : pick; \
+          o[e] = (src >= 0 && src < 4 && tt >= 0 && tt < sg.Tin) ? pick : 0.f;                 \
+        }                                                                                      \
+        v = make_float4(o[0], o[1], o[2], o[3]);                                               \
+      }                                                                                        \
+      put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v);                              \
+    }                                                                                          \
+  }
+  auto mma = [&](auto curc) {
+    constexpr int cur = decltype(curc)::value;
     bf16x8 af[2][3], bf[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1682,9 +1689,33 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
-    if (more) store(cur ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  const int nsteps = g1 - g0;
+  if (nsteps > 0) {
+    W3_FETCH(pra, prb, pvm, pbs, pbt);
+    if (nsteps > 1) advance();
+    W3_FETCH(qra, qrb, qvm, qbs, qbt);
+    W3_STAGE(pra, prb, pvm, pbs, pbt, 0, true);
     __syncthreads();
+    // top of a pair (i even): LDS stage 0 holds step i, set Q holds (in flight) step i + 1
+    for (int i = 0; i < nsteps; i += 2) {
+      if (i + 2 < nsteps) advance();
+      W3_FETCH(pra, prb, pvm, pbs, pbt);                  // step i + 2 (past the end: re-reads the last step, unused)
+      mma(I0{});
+      W3_STAGE(qra, qrb, qvm, qbs, qbt, 1, i + 1 < nsteps);
+      __syncthreads();
+      if (i + 1 >= nsteps) break;
+      if (i + 3 < nsteps) advance();
+      W3_FETCH(qra, qrb, qvm, qbs, qbt);                  // step i + 3
+      mma(I1{});
+      W3_STAGE(pra, prb, pvm, pbs, pbt, 0, i + 2 < nsteps);
+      __syncthreads();
+    }
   }
+#undef W3_FETCH
+#undef W3_STAGE
 
   // partial tile -> slab(s): a 256-row tile is two 128-row slab tiles
 #pragma unroll

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 _state = {'stream': None, 'side': None, 'device': None, 'pool': {}, 'live_bytes': 0,
-          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': True}
+          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': os.environ.get('VQVAE_OVERLAP', '1') != '0'}
 
 
 def init(device=0):

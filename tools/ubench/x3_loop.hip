@@ -236,9 +236,25 @@ __global__ __launch_bounds__(NT, 2) void conv_x2(const Args a) {
   X3_LOAD(P_SET, 0);
   X3_LOAD(Q_SET, 1);
   X3_STORE(P_SET, 0);
+  if (MODE & 128) X3_LOAD(P_SET, 2);
   __syncthreads();
   // invariant at the top of the pair (it even): LDS buf0 holds step it; r1 holds (in flight) step it+1
   for (int it = 0; it < nk; it += 2) {
+    if (MODE & 128) {
+      // stage first: the LDS stores of step it+1 are issued at the top of step it (their data was
+      // fetched a whole step ago) and drain under the MFMAs instead of in front of the barrier
+      X3_STORE(Q_SET, 1);
+      X3_LOAD(Q_SET, min(it + 3, nk - 1));
+      mma(I0{});
+      if (MODE & 256) { _Pragma("unroll") for (int q = 0; q < 24; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); } }
+      __syncthreads();
+      X3_STORE(P_SET, 0);
+      X3_LOAD(P_SET, min(it + 4, nk - 2));
+      mma(I1{});
+      if (MODE & 256) { _Pragma("unroll") for (int q = 0; q < 24; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); } }
+      __syncthreads();
+      continue;
+    }
     X3_LOAD(P_SET, min(it + 2, nk - 2));      // unconditional (the tail re-loads a valid step): a branch here makes every wait vmcnt(0)
     mma(I0{});
     X3_STORE(Q_SET, 1);                   // step it+1 (nk is even)
@@ -360,6 +376,241 @@ __global__ __launch_bounds__(256, 2) void conv_x3(const Args a) {
       }
 }
 
+// X5: wave specialisation.  Waves 0-3 (one per SIMD) only run the matrix pipe: wave w owns rows
+// 64w..64w+63 and all 128 columns (8 accumulator tiles), per K step 18 fragment reads and 48 MFMAs.
+// Waves 4-7 only stage: fetch (two K steps ahead), split, write LDS.  One barrier per K step, three
+// LDS stages.  The split VALU work and the LDS writes never sit in an MFMA wave's instruction stream.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_x5(const Args a) {
+  constexpr int NS = 3;
+  __shared__ uint4 As[NS][3][2][BM];
+  __shared__ uint4 Bs[NS][3][2][BN];
+  const long long c_beg = clock64(), w_beg = wall_clock64();
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int ksteps_tap = a.Cin / BK, nk = 2 * ksteps_tap;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  if (wave >= 4) {
+    // ---------------- staging waves ----------------
+    const int st = tid - 256;
+    const int s_n = st & 127, s_lk = st >> 7;
+    uint4 pa0, pa1, pa2, pa3, pa4, pa5, qa0, qa1, qa2, qa3, qa4, qa5;
+    float pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7, qb0, qb1, qb2, qb3, qb4, qb5, qb6, qb7;
+    bool pok, qok;
+#define X5_LOAD(A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, B6, B7, OK, it_)              \
+    {                                                                                          \
+      const uint4* wp = a.wpk + (size_t)(it_) * (3 * 2 * BM) + st;                             \
+      A0 = wp[0]; A1 = wp[256]; A2 = wp[512]; A3 = wp[768]; A4 = wp[1024]; A5 = wp[1280];      \
+      const int tap = (it_) / ksteps_tap, c0 = ((it_) % ksteps_tap) * BK + 8 * s_lk;           \
+      const int ts = t0 + s_n - (1 - tap) * a.dil;                                             \
+      const float* xs = ts >= 0 ? xb + (long)c0 * a.T + ts : xb;                               \
+      const long T = a.T;                                                                      \
+      B0 = xs[0]; B1 = xs[T]; B2 = xs[2 * T]; B3 = xs[3 * T];                                  \
+      B4 = xs[4 * T]; B5 = xs[5 * T]; B6 = xs[6 * T]; B7 = xs[7 * T];                          \
+      OK = ts >= 0;                                                                            \
+    }
+#define X5_STORE(A0, A1, A2, A3, A4, A5, B0, B1, B2, B3, B4, B5, B6, B7, OK, stage)           \
+    {                                                                                          \
+      uint4* ad = &As[stage][0][0][0];                                                         \
+      ad[st] = A0; ad[256 + st] = A1; ad[512 + st] = A2; ad[768 + st] = A3; ad[1024 + st] = A4; ad[1280 + st] = A5; \
+      uint4 h, m, l;                                                                           \
+      const float z = 0.f;                                                                     \
+      split3(OK ? B0 : z, OK ? B1 : z, h.x, m.x, l.x);                                         \
+      split3(OK ? B2 : z, OK ? B3 : z, h.y, m.y, l.y);                                         \
+      split3(OK ? B4 : z, OK ? B5 : z, h.z, m.z, l.z);                                         \
+      split3(OK ? B6 : z, OK ? B7 : z, h.w, m.w, l.w);                                         \
+      Bs[stage][0][s_lk][s_n] = h; Bs[stage][1][s_lk][s_n] = m; Bs[stage][2][s_lk][s_n] = l;  \
+    }
+#define X5P pa0, pa1, pa2, pa3, pa4, pa5, pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7, pok
+#define X5Q qa0, qa1, qa2, qa3, qa4, qa5, qb0, qb1, qb2, qb3, qb4, qb5, qb6, qb7, qok
+#define X5_LOADX(...) X5_LOAD(__VA_ARGS__)
+#define X5_STOREX(...) X5_STORE(__VA_ARGS__)
+    if (MODE == 0) {
+    X5_LOADX(X5P, 0);
+    X5_LOADX(X5Q, 1);
+    X5_STOREX(X5P, 0);
+    __syncthreads();                                   // stage 0 ready
+    // step it: consumers read stage it % 3; we write step it + 1 into stage (it + 1) % 3 and fetch it + 2
+    int sw = 1;
+    for (int it = 0; it < nk; it += 2) {
+      X5_LOADX(X5P, min(it + 2, nk - 2));
+      X5_STOREX(X5Q, sw);
+      sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+      X5_LOADX(X5Q, min(it + 3, nk - 1));
+      X5_STOREX(X5P, sw);
+      sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+    }
+    } else {
+    // four register sets: a fetch is consumed four steps after it was issued
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, sa0, sa1, sa2, sa3, sa4, sa5;
+    float rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
+    bool rok, sok;
+#define X5R ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7, rok
+#define X5S sa0, sa1, sa2, sa3, sa4, sa5, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7, sok
+    X5_LOADX(X5P, 0);
+    X5_LOADX(X5Q, 1);
+    X5_LOADX(X5R, 2);
+    X5_LOADX(X5S, 3);
+    X5_STOREX(X5P, 0);
+    __syncthreads();
+    int sw = 1;
+    for (int it = 0; it < nk; it += 4) {               // nk % 4 == 0 in this harness
+      X5_LOADX(X5P, min(it + 4, nk - 4));
+      X5_STOREX(X5Q, sw); sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+      X5_LOADX(X5Q, min(it + 5, nk - 3));
+      X5_STOREX(X5R, sw); sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+      X5_LOADX(X5R, min(it + 6, nk - 2));
+      X5_STOREX(X5S, sw); sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+      X5_LOADX(X5S, min(it + 7, nk - 1));
+      X5_STOREX(X5P, sw); sw = sw == 2 ? 0 : sw + 1;
+      __syncthreads();
+    }
+    }
+    return;
+  }
+  // ---------------- matrix waves ----------------
+  f32x16 acc[2][4];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();
+  int sr = 0;
+  for (int it = 0; it < nk; ++it) {
+    bf16x8 af[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(bf16x8, As[sr][p][lk][wave * 64 + i * 32 + li]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(bf16x8, Bs[sr][p][lk][j * 32 + li]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+    sr = sr == 2 ? 0 : sr + 1;
+    __syncthreads();
+  }
+  if (lane == 0 && wave == 0) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        yb[(long)row * a.T + t0 + j * 32 + li] = acc[i][j][r];
+      }
+}
+
+// X6: X2 with three LDS stages and the fragments double-buffered in registers.  Within step i a wave
+//   (a) splits and stores the data of step i+2 (fetched two steps ago) into stage (i+2)%3,
+//   (b) fetches step i+4,
+//   (c) reads the fragments of step i+1 from stage (i+1)%3 into the other fragment set,
+//   (d) runs the 24 MFMAs of step i on fragments it read during step i-1.
+// Nothing in the step waits on something issued in the same step, so the MFMAs can be interleaved
+// with everything else and the matrix pipe does not idle through the LDS phases at the step borders
+// (X2: ~380 cycles of fragment reads after every barrier and ~450 of LDS stores before it, with all
+// eight waves in lockstep: 2500 cycles per step for 1536 of MFMA).
+template <int SG>
+__global__ __launch_bounds__(NT, 2) void conv_x6(const Args a) {
+  __shared__ uint4 As[3][3][2][BM];
+  __shared__ uint4 Bs[3][3][2][BN];
+  const long long c_beg = clock64(), w_beg = wall_clock64();
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps_tap = a.Cin / BK, nk = 2 * ksteps_tap;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const int s_n = tid & 127, s_q = tid >> 7;
+  uint4 pa0, pa1, pa2, qa0, qa1, qa2;
+  float pb0, pb1, pb2, pb3, qb0, qb1, qb2, qb3;
+  bool pok, qok;
+  constexpr int MODE = 0;
+  bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];      // fragment sets of even / odd steps
+#define X6_READ(FA, FB, stage)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+      FA[i][p] = __builtin_bit_cast(bf16x8, As[stage][p][lk][wm * 64 + i * 32 + li]);          \
+      FB[i][p] = __builtin_bit_cast(bf16x8, Bs[stage][p][lk][wn * 64 + i * 32 + li]);          \
+    }
+#define X6_MMA(FA, FB)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+      f32x16 c = acc[i][j];                                                                    \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][2], FB[j][0], c, 0, 0, 0);             \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][0], FB[j][2], c, 0, 0, 0);             \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][1], FB[j][1], c, 0, 0, 0);             \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][1], FB[j][0], c, 0, 0, 0);             \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][0], FB[j][1], c, 0, 0, 0);             \
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][0], FB[j][0], c, 0, 0, 0);             \
+      acc[i][j] = c;                                                                           \
+    }
+#define X6_SCHED()                                                                             \
+  if (SG) { _Pragma("unroll") for (int q = 0; q < 24; ++q) {                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x002, SG, 0);                                      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); } }
+  // prologue: steps 0 and 1 staged, 2 and 3 in flight, fragments of step 0 in set 0
+  X3_LOAD(P_SET, 0);
+  X3_LOAD(Q_SET, 1);
+  X3_STORE(P_SET, 0);
+  X3_STORE(Q_SET, 1);
+  X3_LOAD(P_SET, 2);
+  X3_LOAD(Q_SET, 3);
+  __syncthreads();
+  X6_READ(fa0, fb0, 0);
+  // steps in groups of six (two fragment sets x three LDS stages); nk % 6 != 0 handled by the bound checks
+  int it = 0;
+#define X6_STEP(FAc, FBc, FAn, FBn, SETS, st_next, st_store)                                   \
+  {                                                                                            \
+    X3_STORE(SETS, st_store);                        /* step it + 2 -> stage (it + 2) % 3 */   \
+    X3_LOAD(SETS, min(it + 4, nk - 2 + ((it) & 1))); /* step it + 4 */                         \
+    X6_READ(FAn, FBn, st_next);                      /* fragments of step it + 1 */            \
+    X6_MMA(FAc, FBc);                                                                          \
+    X6_SCHED();                                                                                \
+    __syncthreads();                                                                           \
+    ++it;                                                                                      \
+  }
+  while (it < nk) {
+    X6_STEP(fa0, fb0, fa1, fb1, P_SET, 1, 2); if (it >= nk) break;
+    X6_STEP(fa1, fb1, fa0, fb0, Q_SET, 2, 0); if (it >= nk) break;
+    X6_STEP(fa0, fb0, fa1, fb1, P_SET, 0, 1); if (it >= nk) break;
+    X6_STEP(fa1, fb1, fa0, fb0, Q_SET, 1, 2); if (it >= nk) break;
+    X6_STEP(fa0, fb0, fa1, fb1, P_SET, 2, 0); if (it >= nk) break;
+    X6_STEP(fa1, fb1, fa0, fb0, Q_SET, 0, 1);
+  }
+  if (threadIdx.x == 0) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        yb[(long)row * a.T + t0 + wn * 64 + j * 32 + li] = acc[i][j][r];
+      }
+}
+
 // ---- host ------------------------------------------------------------------------------------
 static unsigned short bf16_rne(float f) {
   unsigned u; memcpy(&u, &f, 4);
@@ -401,7 +652,8 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(dw, pw.data(), pw.size() * 2, hipMemcpyHostToDevice));
   unsigned long long* dclk; CHECK(hipMalloc(&dclk, 16 * 4096)); CHECK(hipMemset(dclk, 0, 16 * 4096));
   Args a; a.clk = dclk; a.mode = 0; a.x = dx; a.y = dy; a.wpk = dw; a.Cin = Cin; a.T = T; a.B = B; a.dil = dil; a.ntile_n = T / BN;
-  const int grid = B * (T / BN);
+  const int full_grid = B * (T / BN);
+  const int grid = getenv("X3_GRID") ? atoi(getenv("X3_GRID")) : full_grid;    // fewer workgroups: part of the chip idle (power test)
   const double flop = 2.0 * B * T * BM * Cin * 2;
   std::vector<float> hy((size_t)B * BM * T);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -441,10 +693,14 @@ int main(int argc, char** argv) {
     double cyc = 0, tick = 0;
     for (int i = 0; i < grid; ++i) { cyc += hc[2 * i]; tick += hc[2 * i + 1]; }
     printf("%-6s %.1f us  %.1f TFLOP/s (fp32-equivalent)   main loop of a block: %.1f us at %.0f MHz\n", name, 1e3 * ms / reps,
-           flop / (ms / reps * 1e-3) / 1e12, tick / grid / 100.0, tick > 0 ? cyc / tick * 100.0 : 0.0);
+           flop * grid / full_grid / (ms / reps * 1e-3) / 1e12, tick / grid / 100.0, tick > 0 ? cyc / tick * 100.0 : 0.0);
   };
   run("X1", conv_x1<0>);
   run("X2", conv_x2<0>);
+  run("X2sf", conv_x2<128>);
+  run("X2sfs", conv_x2<384>);
+  run("X5", conv_x5<0>);
+  run("X5d4", conv_x5<1>);
   nthreads = 256;
   run("X3", conv_x3<0>);
   if (argc > 3) { run("X3/1", conv_x3<1>); run("X3/2", conv_x3<2>); run("X3/3", conv_x3<3>); run("X3/8", conv_x3<8>); }
