@@ -801,15 +801,21 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
   l = pack_bf16x2(r0, r1);
 }
 
-template <int EPI, int WM>
+// NB = 128-column blocks per workgroup (a.ntile_n counts NB*128-column tiles).  NB = 2 (256 x 256
+// tiles, 256-row tiles only): every weight word staged serves twice the columns -- the weight
+// stream from L2 is the largest non-MFMA consumer of the power budget the chip runs into (DESIGN.md
+// section 8) -- and a barrier covers 48 MFMAs per wave; each wave then owns two 64 x 64 blocks, 128
+// columns apart, and runs the unchanged epilogue on each.
+template <int EPI, int WM, int NB>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
-  constexpr int SCHED = (WM == 4) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
-  constexpr int BM = 64 * WM, NT = 128 * WM;
-  constexpr int NQ = NT / 128;            // staging threads per tile column
-  constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 (WM = 2) or 4
+  static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
+  constexpr int SCHED = (WM == 4 && NB == 1) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
+  constexpr int BM = 64 * WM, NT = 128 * WM, BNW = BN * NB;
+  constexpr int NQ = NT / BNW;            // staging threads per tile column
+  constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 or 4
   constexpr bool SPLITK = (EPI == EPI_LINEAR && WM == 2);
   __shared__ uint4 As[2][3][2][BM];
-  __shared__ uint4 Bs[2][3][2][BN];
+  __shared__ uint4 Bs[2][3][2][BNW];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
 
   const int nblk = gridDim.x;
@@ -826,18 +832,18 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   const int rest = tile_id / a.ntile_m;
   const int nt = rest % a.ntile_n;
   const int b = rest / a.ntile_n;
-  const int m0 = mt * BM, t0 = nt * BN;
+  const int m0 = mt * BM, t0 = nt * BNW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], acc2[2][2];           // acc2: the second column block (NB == 2), 128 columns to the right
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
   int nk = 0;
   for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   const int nsteps = it_end - it_beg;
 
   // ---- staging state of the next step to fetch (advanced once per fetch) ----------------------
-  const int s_n = tid & 127, s_c = (tid >> 7) * CPT;       // this thread's column and first channel of a step
+  const int s_n = tid % BNW, s_c = (tid / BNW) * CPT;      // this thread's column and first channel of a step
   const int a_hi = tid / BM, a_m = tid % BM;               // A: 16-byte words (2j + a_hi) * BM + a_m, j = 0..2
   int seg_i = 0, c_n = 0, cin_n = 0, left = nsteps;
   const uint4* wp = nullptr;
@@ -916,9 +922,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
       split3((MASK >> e) & 1u ? BV[e] : 0.f, (MASK >> (e + 1)) & 1u ? BV[e + 1] : 0.f,       \
              hh[e / 2], mm[e / 2], ll[e / 2]);                                               \
     if constexpr (CPT == 8) {                                                                \
-      Bs[BUF][0][tid >> 7][s_n] = make_uint4(hh[0], hh[1], hh[2], hh[3]);                    \
-      Bs[BUF][1][tid >> 7][s_n] = make_uint4(mm[0], mm[1], mm[2], mm[3]);                    \
-      Bs[BUF][2][tid >> 7][s_n] = make_uint4(ll[0], ll[1], ll[2], ll[3]);                    \
+      Bs[BUF][0][tid / BNW][s_n] = make_uint4(hh[0], hh[1], hh[2], hh[3]);                   \
+      Bs[BUF][1][tid / BNW][s_n] = make_uint4(mm[0], mm[1], mm[2], mm[3]);                   \
+      Bs[BUF][2][tid / BNW][s_n] = make_uint4(ll[0], ll[1], ll[2], ll[3]);                   \
     } else {                                                                                 \
       uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][0][tid >> 8][s_n]) + ((tid >> 7) & 1);   \
       bd[0 * 4 * BN] = make_uint2(hh[0], hh[1]);                                             \
@@ -936,19 +942,30 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
       }
+    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][3]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];                                   // small products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = ac[i][j];                                   // small products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
+          ac[i][j] = c;
+        }
+    };
+    block(acc, bf);
+    if constexpr (NB == 2) {
+      bf16x8 bg[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+      block(acc2, bg);
+    }
     if (SCHED) {
       // one MFMA (32 pipe cycles), then a few of the step's other instructions (the split of the next
       // step, the addresses of the one after): hipcc otherwise issues 16 of the 24 MFMAs back to back
@@ -988,6 +1005,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 #undef X3_FETCH
 #undef X3_STAGE
   gemm_epilogue<EPI, WM, SPLITK>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
+  if constexpr (NB == 2) {
+    if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1644,11 +1664,12 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   };
 #define W3_STAGE(RA, RB, VM, BS, BT, STAGE, REAL)                                             \
   {                                                                                            \
+    const bool real_ = (REAL);          /* evaluated here: the loops below have their own i */ \
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
       const float4 v = (VM >> i) & 1u ? RA[i] : zero4;                                         \
       put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                              \
-      if (REAL) bsum[i] += (v.x + v.y) + (v.z + v.w);                                          \
+      if (real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                                         \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       float4 v = (VM >> (8 + i)) & 1u ? RB[i] : zero4;                                         \
@@ -1900,9 +1921,16 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   }
   const long grid = nblk * g.ksplit;
   ProfScope ps(tag, st);
-  if (g_matmul_dtype == 2) {
-    if (big) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+  // 256-column tiles when they still give every CU a workgroup (measured at configs[1]: dilated conv
+  // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
+  static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
+  const long nblk2 = (long)g.ntile_m * cdiv(g.Tout, 2 * BN) * g.B;
+  if (g_matmul_dtype == 2 && big && x3_nb == 2 && nblk2 >= 256) {
+    g.ntile_n = cdiv(g.Tout, 2 * BN);
+    hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+  } else if (g_matmul_dtype == 2) {
+    if (big) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
   } else if (g_matmul_dtype == 1) {
     if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, true>), dim3((unsigned)nblk), dim3(256), 0, st, g);
