@@ -1105,12 +1105,14 @@ struct WSeg {
   float* gw; long gw_co_stride, gw_ci_stride;
   float* gb; float* gb2;   // bias-gradient destinations fed by this segment's gy (nullable)
   int tile0;          // first global n-tile of this segment
+  int ptile0;         // first global 256-column tile of this segment (wgrad3_kernel<4, 2>)
 };
 struct WgradArgs {
   const float* gy; long gy_bstride;
   int M, Tout, B;
   WSeg seg[MAXSEG]; int nseg;
   int ntile_m, ntile_n;      // ntile_n = total over segments
+  int ntile_p;               // 256-column tiles, total over segments (every segment starts a new one)
   // split-K over the FLATTENED (batch, time) axis in units of WBK-wide K steps: split s owns global
   // steps [s*steps_per_split, (s+1)*steps_per_split); a step never straddles two batch items
   int steps_per_b, steps_per_split, nsplit;
@@ -1550,11 +1552,15 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // products of an exact three-way split, see conv_gemm_x3_kernel): same tiles, splits, slabs, loads
 // and bias sums; both operands are activations, so both are split while they are staged, into the
 // [piece][k-half][row] 16-byte-word images the 32x32x16 fragments read with one ds_read_b128.
-template <int WM>
+// NC = 128-column blocks per workgroup.  NC = 2 (256 x 256 tiles, WM = 4 only): the output-gradient
+// tile -- fetched, split and stored once per workgroup, and the same for every column tile of the
+// launch -- serves twice the columns; each wave then owns two 64 x 64 blocks 128 columns apart.
+template <int WM, int NC>
 __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) {
-  constexpr int NT2 = 128 * WM, BM2 = 64 * WM;
-  constexpr int PA = BM2 + 4, PB = BN + 4;                // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
-  constexpr int NA = BM2 * 4 / NT2, NB = BN * 4 / NT2;    // float4 row loads per thread: 2 and 1 (WM=4) / 2 and 2
+  static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
+  constexpr int NT2 = 128 * WM, BM2 = 64 * WM, BNC = BN * NC;
+  constexpr int PA = BM2 + 4, PB = BNC + 4;               // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
+  constexpr int NA = BM2 * 4 / NT2, NB = BNC * 4 / NT2;   // float4 row loads per thread: 2 and 1 or 2 (WM=4) / 2 and 2
   __shared__ uint4 As[2][3][2][PA];
   __shared__ uint4 Bs[2][3][2][PB];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
@@ -1568,16 +1574,18 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
     const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
-  const int ntiles = ntm * a.ntile_n;
+  const int ncolt = NC == 1 ? a.ntile_n : a.ntile_p;       // column tiles of this kernel's width
+  const int ntiles = ntm * ncolt;
   const int tile = logical % ntiles;
   const int split = logical / ntiles;
-  const int ntg = tile % a.ntile_n;                        // column tile fastest: neighbours share gy
-  const int mt = tile / a.ntile_n;
+  const int ct = tile % ncolt;                             // column tile fastest: neighbours share gy
+  const int mt = tile / ncolt;
   int s = 0;
 #pragma unroll
   for (int i = 1; i < MAXSEG; ++i)
-    if (i < a.nseg && ntg >= a.seg[i].tile0) s = i;
+    if (i < a.nseg && ct >= (NC == 1 ? a.seg[i].tile0 : a.seg[i].ptile0)) s = i;
   const WSeg& sg = a.seg[s];
+  const int ntg = NC == 1 ? ct : sg.tile0 + NC * (ct - sg.ptile0);    // first 128-column slab tile of this workgroup
   const int n0 = (ntg - sg.tile0) * BN;
   const int m0 = mt * BM2;
   // K steps of 16 t: two per WBK step of the split plan
@@ -1593,13 +1601,13 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   const int s_chunk = tid & 3, s_row = tid >> 2;          // staging role: chunk of 4 t, row (+ NT2/4 per extra load)
   constexpr int RSTEP = NT2 / 4;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], acc2[2][2];           // acc2: the second column block (NC == 2)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
   float bsum[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
@@ -1697,19 +1705,30 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
       }
+    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][3]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];                                   // small products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = ac[i][j];                                   // small products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
+          ac[i][j] = c;
+        }
+    };
+    block(acc, bf);
+    if constexpr (NC == 2) {
+      bf16x8 bg[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+      block(acc2, bg);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -1738,21 +1757,27 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
 #undef W3_FETCH
 #undef W3_STAGE
 
-  // partial tile -> slab(s): a 256-row tile is two 128-row slab tiles
+  // partial tile -> slab(s): a 256-row tile is two 128-row slab tiles, a 256-column tile two 128-column ones
+  auto to_slab = [&](f32x16 (&ac)[2][2], int ntg_h) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int rowb = wm * 64 + mi * 32;                    // wave-uniform
-    const int mt_slab = (m0 + rowb) / BM;
-    if (mt_slab >= a.ntile_m) continue;
-    float* slab = a.slabs + (((long)split * a.ntile_m + mt_slab) * a.ntile_n + ntg) * (BM * BN);
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rowb = wm * 64 + mi * 32;                    // wave-uniform
+      const int mt_slab = (m0 + rowb) / BM;
+      if (mt_slab >= a.ntile_m) continue;
+      float* slab = a.slabs + (((long)split * a.ntile_m + mt_slab) * a.ntile_n + ntg_h) * (BM * BN);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int col = wn * 64 + ni * 32 + li;
-        slab[row * BN + col] = acc[mi][ni][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = wn * 64 + ni * 32 + li;
+          slab[row * BN + col] = ac[mi][ni][r];
+        }
+    }
+  };
+  to_slab(acc, ntg);
+  if constexpr (NC == 2) {
+    if (n0 + BN < sg.cin) to_slab(acc2, ntg + 1);            // the segment may end in an odd 128-column tile
   }
   if (do_bias) {
 #pragma unroll
@@ -2029,7 +2054,12 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   for (int i = 0; i < w.nseg; ++i) any_b = any_b || w.seg[i].gb || w.seg[i].gb2;
   w.bslabs = any_b ? ws + p.slab_floats : nullptr;
   int t0 = 0;
-  for (int i = 0; i < w.nseg; ++i) { w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN); }
+  int p0 = 0;
+  for (int i = 0; i < w.nseg; ++i) {
+    w.seg[i].tile0 = t0; t0 += cdiv(w.seg[i].cin, BN);
+    w.seg[i].ptile0 = p0; p0 += cdiv(w.seg[i].cin, 2 * BN);
+  }
+  w.ntile_p = p0;
   // 16-B row loads: every row start and every chunk start must be 16-B aligned and no float4
   // may straddle a row end
   bool av = (w.Tout % 4 == 0) && (w.gy_bstride % 4 == 0);
@@ -2049,10 +2079,14 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   bool fast = (g_matmul_dtype != 1) && av && g_wgrad_impl != 1;
   for (int i = 0; i < w.nseg; ++i) fast = fast && w.seg[i].tmul == 1 && w.seg[i].tdiv == 1;
   ProfScope ps(tag, st);
-  if (fast && g_matmul_dtype == 2 && w.M % 256 == 0) {
-    hipLaunchKernelGGL(wgrad3_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+  static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
+  const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
+  if (fast && g_matmul_dtype == 2 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
+    hipLaunchKernelGGL((wgrad3_kernel<4, 2>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
+  } else if (fast && g_matmul_dtype == 2 && w.M % 256 == 0) {
+    hipLaunchKernelGGL((wgrad3_kernel<4, 1>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && g_matmul_dtype == 2) {
-    hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+    hipLaunchKernelGGL((wgrad3_kernel<2, 1>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
   } else if (fast && w.M % 256 == 0) {
     hipLaunchKernelGGL(wgrad2_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast) {
