@@ -32,10 +32,11 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 
-// 0: fp32 operands on v_mfma_f32_32x32x2_f32 (default); 1: operands rounded to bf16 (RNE,
-// v_cvt_pk_bf16_f32) when they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-// HBM tensors, epilogues and accumulators stay fp32 in both modes.
-static int g_matmul_dtype = 0;
+// 0: fp32 operands on v_mfma_f32_32x32x2_f32; 1: operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32),
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate; 2 (default): fp32 products as six bf16 MFMA products of an
+// exact three-way split of both operands (conv_gemm_x3_kernel / wgrad3_kernel below).
+// HBM tensors, epilogues and accumulators stay fp32 in every mode.
+static int g_matmul_dtype = 2;
 static int g_wgrad_impl = 0;      // 0: auto; 1: force the generic wgrad_kernel (tests / A-B timing)
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;   // wgrad tiles; conv_gemm derives BM/NT from WM

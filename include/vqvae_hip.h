@@ -81,11 +81,18 @@ int vqvae_prof_enable(int tag_mask);
 int vqvae_prof_reset(void);
 int vqvae_prof_read(int tag, double* total_ms, int* launches);
 
-/* ---- operand precision of every MFMA contraction (convs fwd / bwd-data / bwd-weight,
- *      ResidualBlock / ResidualNet entry points).  0 (default): fp32 operands on
- *      v_mfma_f32_32x32x2_f32 -- exact fp32.  1: operands rounded to bf16 (round-to-nearest-even)
- *      as they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation -- BASELINE configs[4].
- *      Tensors in HBM, biases, gates, losses, optimizer and the vector quantiser stay fp32.     */
+/* ---- arithmetic of every MFMA contraction (convs fwd / bwd-data / bwd-weight, ResidualBlock /
+ *      ResidualNet entry points).  Tensors in HBM, accumulators, biases, gates, losses, optimizer and
+ *      the vector quantiser are fp32 in every mode.
+ *      2 (default): fp32 products on the bf16 matrix pipe -- both operands split EXACTLY into three
+ *        bf16 (h + m + l, each the RNE of the remainder), six of the nine products on
+ *        v_mfma_f32_32x32x16_bf16 with fp32 accumulate; the dropped three are < 2^-25 of the product.
+ *        As accurate as mode 0 (checked against float64), 0.375 of its matrix-pipe time.
+ *      0: fp32 operands on v_mfma_f32_32x32x2_f32.
+ *      1: operands rounded to bf16 (round-to-nearest-even), v_mfma_f32_32x32x16_bf16, fp32
+ *        accumulation -- BASELINE configs[4].
+ *      Workspace sizes depend on the mode (packed weight slabs are 1.5x larger in mode 2): query
+ *      them after setting it.                                                                    */
 int vqvae_set_matmul_dtype(int dtype);
 int vqvae_get_matmul_dtype(void);
 /* weight-gradient kernel choice: 0 = automatic (the 16-byte-LDS fp32 kernel where it applies),

@@ -266,6 +266,29 @@ __global__ __launch_bounds__(NT, 2) void conv_x2(const Args a) {
   }
   if (threadIdx.x == 0) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
   float* yb = a.y + (long)b * BM * a.T;
+  if (MODE & 512) {
+    // wide stores: the accumulators go through LDS (free after the loop) so that a lane writes 4
+    // consecutive columns (16 B) and a wave whole 512-byte row segments, instead of 128-byte ones
+    float* stg = reinterpret_cast<float*>(&As[0][0][0][0]);          // [64 rows][132] floats per wave pair... one wave: 64 x 64 block
+    float* mine = stg + wave * (64 * 68);                            // 8 waves x 17 KB = 136 KB > LDS: do it in two halves of 32 rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lk) * 68 + j * 32 + li] = acc[i][j][r];
+      __syncthreads();
+      // 32 rows x 64 columns: 16 lanes per row (float4 each), 4 rows per pass, 8 passes
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = ps * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&mine[row * 68 + c4]);
+        *reinterpret_cast<float4*>(&yb[(long)(wm * 64 + i * 32 + row) * a.T + t0 + wn * 64 + c4]) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -620,7 +643,7 @@ static unsigned short bf16_rne(float f) {
 static float bf16_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char** argv) {
-  const int B = 16, Cin = 256;
+  const int B = 16, Cin = getenv("X3_CIN") ? atoi(getenv("X3_CIN")) : 256;     // 64: an 8-step contraction, epilogue-dominated
   const int dil = argc > 1 ? atoi(argv[1]) : 64;
   const int T = argc > 2 ? atoi(argv[2]) : 7680;
   const int reps = 20;
@@ -697,8 +720,7 @@ int main(int argc, char** argv) {
   };
   run("X1", conv_x1<0>);
   run("X2", conv_x2<0>);
-  run("X2sf", conv_x2<128>);
-  run("X2sfs", conv_x2<384>);
+  run("X2w", conv_x2<512>);
   run("X5", conv_x5<0>);
   run("X5d4", conv_x5<1>);
   nthreads = 256;
