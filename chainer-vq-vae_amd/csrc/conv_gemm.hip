@@ -1,4 +1,4 @@
-// conv_gemm.hip -- the MFMA contraction kernels of the hot path (gfx950, fp32).
+// conv_gemm.hip -- the MFMA contraction kernels of the hot path (gfx950; fp32 tensors and results).
 //
 // Every convolution on the path is a (K,1) filter over the time axis of a
 // (B, C, T) tensor with T contiguous, i.e. for one batch element
@@ -7,20 +7,23 @@
 // a time-shifted window of X.  Time is the contiguous axis, so the MFMA B
 // fragment (lane -> 32 consecutive t) is read straight out of coalesced rows.
 //
-//   conv_gemm_kernel<EPI>   fwd and bwd-data of every conv (the K dimension is a
-//                           list of up to 4 "segments" = (input tensor, tap shift,
-//                           packed weight slab)); 128x128 output tile per 256-thread
-//                           workgroup, 4 wavefronts as 2x2, each 2x2 tiles of
-//                           v_mfma_f32_32x32x2_f32; LDS double buffer, register
-//                           prefetch, one barrier per K step; XCD-aware tile order.
-//                           Epilogues: linear (+bias, +residual, +=, relu),
-//                           gated tanh*sigmoid (ResidualBlock fwd), gate derivative
-//                           (ResidualBlock bwd).
-//   wgrad_kernel            bwd-weight: contraction over (b, t), split-K over
-//                           batch x time chunks into deterministic partial slabs,
+//   conv_gemm_x3_kernel     fwd and bwd-data of every conv in the default matmul mode 2 (fp32
+//                           products as six bf16 MFMA products of an exact three-way operand
+//                           split) and, with one piece, in mode 1 (operands rounded to bf16).
+//                           The K dimension is a list of "segments" = (input tensor, tap shift,
+//                           packed weight slab); 256 x 256, 256 x 128 or 128 x 128 output tiles,
+//                           wavefronts own 64 x 64 blocks of v_mfma_f32_32x32x16_bf16 tiles; LDS
+//                           double buffer, fetches two K steps ahead, one barrier per step;
+//                           XCD-aware tile order.
+//   conv_gemm_kernel        the same GEMMs in mode 0 on v_mfma_f32_32x32x2_f32.
+//   gemm_epilogue           shared epilogues: linear (+bias, +residual, +=, relu), gated
+//                           tanh*sigmoid (ResidualBlock fwd), gate derivative (ResidualBlock bwd).
+//   wgrad3_kernel / wgrad2_kernel / wgrad_kernel
+//                           bwd-weight (modes 2 and 1 / mode 0 / strided shapes): contraction over
+//                           the flattened (b, t) axis, split-K into deterministic partial slabs,
 //                           reduced in fixed order by wgrad_reduce_kernel.
-//   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A^T
-//                           slabs the GEMM wants ([k][m], m contiguous, zero padded).
+//   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A slabs the GEMMs want
+//                           (mode 0: [k][m] fp32; modes 1, 2: pre-split 16-byte fragment words).
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -387,6 +390,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
 
 template <int EPI, int WM, bool BF16>
 __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(const GemmArgs a) {
+  static_assert(!BF16, "matmul mode 1 runs on conv_gemm_x3_kernel<..., NP = 1>");
   constexpr int BM = 64 * WM, NT = 128 * WM;
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
   int nk = 0;
   for (int s = 0; s < a.nseg; ++s) nk += (a.seg[s].cin + BK - 1) / BK;
 
-  if constexpr (WM == 4 && !BF16) {
+  if constexpr (WM == 4) {
     float4 ra0, ra1;
     float4 rb0, rb1;
     bool rvec = false;
@@ -520,34 +524,16 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
     auto k_step = [&](auto curc, bool more) {
       constexpr int cur = decltype(curc)::value;
       if (more) load_next();
-      if (BF16) {
-        // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
-        // k-group = lk) supplies k = 8*lk .. 8*lk+7
-        bf16x8 af[2], bf[2];
-  #pragma unroll
-        for (int h = 0; h < 2; ++h)
-  #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
-            bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
-          }
-  #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-  #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-      } else {
-  #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-          const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
-          const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
-          const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
-          const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
+        const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
+        const float b0 = Bs[cur][kk * 2 + lk][wn * 64 + li];
+        const float b1 = Bs[cur][kk * 2 + lk][wn * 64 + 32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
       if (more) store_tiles(std::integral_constant<int, cur ^ 1>{});
       __syncthreads();
@@ -563,7 +549,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
       if (it + 1 < nk) k_step(std::integral_constant<int, 1>{}, it + 2 < nk);
     }
 
-  } else if constexpr (!BF16) {
+  } else {
     // 128-row tiles (4 workgroups per CU): the plain per-step staging measured faster here
     float4 ra0, ra1;
     float4 rb0, rb1;
@@ -650,24 +636,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
         if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
         load_tiles(s, c0);
       }
-      if (BF16) {
-        // one 32x32x16 bf16 MFMA per sub-tile covers the whole K step: lane (row/col = li,
-        // k-group = lk) supplies k = 8*lk .. 8*lk+7
-        bf16x8 af[2], bf[2];
-  #pragma unroll
-        for (int h = 0; h < 2; ++h)
-  #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            af[h][j] = (__bf16)As[cur][8 * lk + j][wm * 64 + h * 32 + li];
-            bf[h][j] = (__bf16)Bs[cur][8 * lk + j][wn * 64 + h * 32 + li];
-          }
-  #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-  #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-      } else {
-  #pragma unroll
+#pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         const float a0 = As[cur][kk * 2 + lk][wm * 64 + li];
         const float a1 = As[cur][kk * 2 + lk][wm * 64 + 32 + li];
@@ -678,96 +647,6 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
-      }
-      if (more) store_tiles(cur ^ 1);
-      __syncthreads();
-    }
-
-  } else {
-    // bf16 operands (configs[4] precision): both LDS images hold 32-bit words = (k even, k odd) pairs,
-    // rounded (RNE) once at staging; a fragment (8 consecutive k) is four ds_read_b32 and the K step is
-    // one 32x32x16 MFMA per sub-tile.  The weight slabs arrive pair-packed from pack_kernel.
-    unsigned (*Ap)[8][BM] = reinterpret_cast<unsigned (*)[8][BM]>(&As[0][0][0]);
-    unsigned (*Bp)[8][BN] = reinterpret_cast<unsigned (*)[8][BN]>(&Bs[0][0][0]);
-    constexpr int ACOLS4 = BM / 4;
-    const int a_kp = tid / ACOLS4, a_col = (tid % ACOLS4) * 4;       // A: pair-row a_kp (NT / ACOLS4 == 8)
-    const int p_k = tid >> 5, v_col = (tid & 31) * 4;                 // vector B: pair-row p_k, threads < 256
-    constexpr int BROWS = NT / 128, PR = 8 / BROWS;                   // scalar B: pair-rows b_k + BROWS*i
-    const int b_n = tid & 127, b_k = tid >> 7;
-    uint4 ra;
-    float4 rbe, rbo;          // vector path: channels 2*p_k (even) and 2*p_k + 1 (odd)
-    float rbs[2 * PR];        // scalar path
-    bool rvec = false;
-
-    auto load_tiles = [&](int s, int c0) {
-      const Seg& sg = a.seg[s];
-      ra = *reinterpret_cast<const uint4*>(sg.w + (long)(c0 / 2 + a_kp) * sg.ldw + m0 + a_col);
-      const float* xb = sg.x + (long)b * sg.x_bstride;
-      const int tw = t0 * sg.tmul + sg.toff;
-      rvec = sg.vec && ((tw & 3) == 0) && tw >= 0 && (tw + BN) <= sg.Tin;
-      if (rvec) {
-        rbe = make_float4(0.f, 0.f, 0.f, 0.f);
-        rbo = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < 256) {
-          const int ce = c0 + 2 * p_k;
-          if (ce < sg.cin) rbe = *reinterpret_cast<const float4*>(xb + (long)ce * sg.x_cstride + tw + v_col);
-          if (ce + 1 < sg.cin) rbo = *reinterpret_cast<const float4*>(xb + (long)(ce + 1) * sg.x_cstride + tw + v_col);
-        }
-      } else {
-        const int tnum = (t0 + b_n) * sg.tmul + sg.toff;
-        bool ok = tnum >= 0;
-        int tin = tnum;
-        if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
-        ok = ok && tin < sg.Tin;
-#pragma unroll
-        for (int i = 0; i < PR; ++i) {
-          const int ce = c0 + 2 * (b_k + BROWS * i);
-          rbs[2 * i] = (ok && ce < sg.cin) ? xb[(long)ce * sg.x_cstride + tin] : 0.f;
-          rbs[2 * i + 1] = (ok && ce + 1 < sg.cin) ? xb[(long)(ce + 1) * sg.x_cstride + tin] : 0.f;
-        }
-      }
-    };
-    auto store_tiles = [&](int buf) {
-      *reinterpret_cast<uint4*>(&Ap[buf][a_kp][a_col]) = ra;
-      if (rvec) {
-        if (tid < 256) {
-          uint4 w;
-          w.x = pack_bf16x2(rbe.x, rbo.x); w.y = pack_bf16x2(rbe.y, rbo.y);
-          w.z = pack_bf16x2(rbe.z, rbo.z); w.w = pack_bf16x2(rbe.w, rbo.w);
-          *reinterpret_cast<uint4*>(&Bp[buf][p_k][v_col]) = w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < PR; ++i) Bp[buf][b_k + BROWS * i][b_n] = pack_bf16x2(rbs[2 * i], rbs[2 * i + 1]);
-      }
-    };
-
-    int s = 0, c0 = 0;
-    load_tiles(s, c0);
-    store_tiles(0);
-    __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-      const int cur = it & 1;
-      const bool more = (it + 1) < nk;
-      if (more) {
-        c0 += BK;
-        if (c0 >= a.seg[s].cin) { c0 = 0; ++s; }
-        load_tiles(s, c0);
-      }
-      uint4 af[2], bf[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        af[h].x = Ap[cur][4 * lk + 0][wm * 64 + h * 32 + li]; af[h].y = Ap[cur][4 * lk + 1][wm * 64 + h * 32 + li];
-        af[h].z = Ap[cur][4 * lk + 2][wm * 64 + h * 32 + li]; af[h].w = Ap[cur][4 * lk + 3][wm * 64 + h * 32 + li];
-        bf[h].x = Bp[cur][4 * lk + 0][wn * 64 + h * 32 + li]; bf[h].y = Bp[cur][4 * lk + 1][wn * 64 + h * 32 + li];
-        bf[h].z = Bp[cur][4 * lk + 2][wn * 64 + h * 32 + li]; bf[h].w = Bp[cur][4 * lk + 3][wn * 64 + h * 32 + li];
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]),
-                                                                acc[mi][ni], 0, 0, 0);
       if (more) store_tiles(cur ^ 1);
       __syncthreads();
     }
@@ -807,16 +686,18 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 // stream from L2 is the largest non-MFMA consumer of the power budget the chip runs into (DESIGN.md
 // section 8) -- and a barrier covers 48 MFMAs per wave; each wave then owns two 64 x 64 blocks, 128
 // columns apart, and runs the unchanged epilogue on each.
-template <int EPI, int WM, int NB>
+// NP = bf16 pieces per operand: 3 (mode 2, six products) or 1 (mode 1: operands rounded to bf16, one product).
+template <int EPI, int WM, int NB, int NP>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
-  constexpr int SCHED = (WM == 4 && NB == 1) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
+  static_assert(NP == 1 || NP == 3, "one piece (bf16 operands) or three (exact split)");
+  constexpr int SCHED = (WM == 4 && NB == 1 && NP == 3) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
   constexpr int BM = 64 * WM, NT = 128 * WM, BNW = BN * NB;
   constexpr int NQ = NT / BNW;            // staging threads per tile column
   constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 or 4
   constexpr bool SPLITK = (EPI == EPI_LINEAR && WM == 2);
-  __shared__ uint4 As[2][3][2][BM];
-  __shared__ uint4 Bs[2][3][2][BNW];
+  __shared__ uint4 As[2][NP][2][BM];
+  __shared__ uint4 Bs[2][NP][2][BNW];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
 
   const int nblk = gridDim.x;
@@ -857,7 +738,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 
   // ---- staging state of the next step to fetch (advanced once per fetch) ----------------------
   const int s_n = tid % BNW, s_c = (tid / BNW) * CPT;      // this thread's column and first channel of a step
-  const int a_hi = tid / BM, a_m = tid % BM;               // A: 16-byte words (2j + a_hi) * BM + a_m, j = 0..2
+  const int a_hi = tid / BM, a_m = tid % BM;               // A: 16-byte words (2j + a_hi) * BM + a_m, j = 0..NP-1
   int seg_i = 0, c_n = 0, cin_n = 0, left = nsteps;
   const uint4* wp = nullptr;
   const float* xp = nullptr;
@@ -867,7 +748,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   auto seg_setup = [&](int s, int skip) {
     const Seg& sg = a.seg[s];
     cin_n = sg.cin; c_n = skip * BK;
-    wadv = 6L * sg.ldw; wl2 = 2L * sg.ldw;
+    wadv = 2L * NP * sg.ldw; wl2 = 2L * sg.ldw;
     wp = reinterpret_cast<const uint4*>(sg.w) + (long)skip * wadv + (long)a_hi * sg.ldw + m0 + a_m;
     xcs = sg.x_cstride; xadv = (long)BK * sg.x_cstride;
     const int tnum = (t0 + s_n) * sg.tmul + sg.toff;
@@ -897,12 +778,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   // two register sets (P: even steps, Q: odd steps) so that the fetch of step i+2 is in flight while
   // step i+1 is split and stored: every wait in the loop is then a counted vmcnt.  The fetches are
   // unconditional (a branch around them makes hipcc drain to vmcnt(0)).
-  uint4 pa0, pa1, pa2, qa0, qa1, qa2;
+  uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
   float pb[CPT], qb[CPT];
   unsigned pmask, qmask;
 #define X3_FETCH(A0, A1, A2, BV, MASK)                                                      \
   {                                                                                          \
-    A0 = wp[0]; A1 = wp[wl2]; A2 = wp[2 * wl2];                                              \
+    A0 = wp[0];                                                                              \
+    if constexpr (NP == 3) { A1 = wp[wl2]; A2 = wp[2 * wl2]; }                               \
     const int nvalid = cin_n - (c_n + s_c);                                                  \
     unsigned mk = 0;                                                                         \
     _Pragma("unroll") for (int e = 0; e < CPT; ++e) {                                        \
@@ -917,54 +799,57 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 #define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
   {                                                                                          \
     uint4* ad = &As[BUF][0][0][0];                                                           \
-    ad[tid] = A0; ad[NT + tid] = A1; ad[2 * NT + tid] = A2;                                  \
-    unsigned hh[CPT / 2], mm[CPT / 2], ll[CPT / 2];                                          \
-    _Pragma("unroll") for (int e = 0; e < CPT; e += 2)                                       \
-      split3((MASK >> e) & 1u ? BV[e] : 0.f, (MASK >> (e + 1)) & 1u ? BV[e + 1] : 0.f,       \
-             hh[e / 2], mm[e / 2], ll[e / 2]);                                               \
-    if constexpr (CPT == 8) {                                                                \
-      Bs[BUF][0][tid / BNW][s_n] = make_uint4(hh[0], hh[1], hh[2], hh[3]);                   \
-      Bs[BUF][1][tid / BNW][s_n] = make_uint4(mm[0], mm[1], mm[2], mm[3]);                   \
-      Bs[BUF][2][tid / BNW][s_n] = make_uint4(ll[0], ll[1], ll[2], ll[3]);                   \
-    } else {                                                                                 \
-      uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][0][tid >> 8][s_n]) + ((tid >> 7) & 1);   \
-      bd[0 * 4 * BN] = make_uint2(hh[0], hh[1]);                                             \
-      bd[1 * 4 * BN] = make_uint2(mm[0], mm[1]);                                             \
-      bd[2 * 4 * BN] = make_uint2(ll[0], ll[1]);                                             \
+    ad[tid] = A0;                                                                            \
+    if constexpr (NP == 3) { ad[NT + tid] = A1; ad[2 * NT + tid] = A2; }                     \
+    unsigned pc[3][CPT / 2];                                   /* [piece][channel pair] */   \
+    _Pragma("unroll") for (int e = 0; e < CPT; e += 2) {                                     \
+      const float v0 = (MASK >> e) & 1u ? BV[e] : 0.f, v1 = (MASK >> (e + 1)) & 1u ? BV[e + 1] : 0.f; \
+      if constexpr (NP == 3) split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);       \
+      else pc[0][e / 2] = pack_bf16x2(v0, v1);                                               \
+    }                                                                                        \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                         \
+      if constexpr (CPT == 8) {                                                              \
+        Bs[BUF][p][tid / BNW][s_n] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);     \
+      } else {                                                                               \
+        uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
+        *bd = make_uint2(pc[p][0], pc[p][1]);                                                \
+      }                                                                                      \
     }                                                                                        \
   }
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
-    bf16x8 af[2][3], bf[2][3];
+    bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
       }
-    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][3]) {
+    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          f32x16 c = ac[i][j];                                   // small products first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          f32x16 c = ac[i][j];
+          if constexpr (NP == 3) {                               // small products first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
           ac[i][j] = c;
         }
     };
     block(acc, bf);
     if constexpr (NB == 2) {
-      bf16x8 bg[2][3];
+      bf16x8 bg[2][NP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
       block(acc2, bg);
     }
     if (SCHED) {
@@ -1027,12 +912,14 @@ struct PackArgs { PackJob job[MAXSEG]; int njob; int bf16; };
 
 __global__ void pack_kernel(const PackArgs pa) {
   const PackJob& j = pa.job[blockIdx.y];
-  if (pa.bf16 == 2) {
-    // mode 2: per tap a slab of Rpad/16 K steps x [piece 3][k-half 2][ldw] 16-byte words, each word
-    // the same piece of 8 consecutive k of one column (conv_gemm_x3_kernel's LDS image)
+  if (pa.bf16 != 0) {
+    // modes 1 and 2: per tap a slab of Rpad/16 K steps x [piece NP][k-half 2][ldw] 16-byte words, each
+    // word the same piece of 8 consecutive k of one column (conv_gemm_x3_kernel's LDS image); NP = 3
+    // (mode 2: exact split) or 1 (mode 1: the weight rounded to bf16; the slab keeps its fp32 stride)
+    const int np = pa.bf16 == 2 ? 3 : 1;
     const int groups = j.Rpad / 8;
     const long total = (long)j.K * groups * j.mspan;
-    const long tap_words = (long)(j.Rpad / 16) * 6 * j.ldw;
+    const long tap_words = np == 3 ? (long)(j.Rpad / 16) * 6 * j.ldw : (long)(j.Rpad / 4) * j.ldw;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
       const int mp = (int)(i % j.mspan);
       const long rest = i / j.mspan;
@@ -1052,10 +939,12 @@ __global__ void pack_kernel(const PackArgs pa) {
         const float v1 = (k1 < j.R && m < j.Cm) ? j.src[(long)k1 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
         split3(v0, v1, h[e / 2], md[e / 2], l[e / 2]);
       }
-      uint4* d = reinterpret_cast<uint4*>(j.dst) + tap * tap_words + ((long)(kg >> 1) * 6 + (kg & 1)) * j.ldw + j.m_off + mp;
+      uint4* d = reinterpret_cast<uint4*>(j.dst) + tap * tap_words + ((long)(kg >> 1) * 2 * np + (kg & 1)) * j.ldw + j.m_off + mp;
       d[0L * j.ldw] = make_uint4(h[0], h[1], h[2], h[3]);
-      d[2L * j.ldw] = make_uint4(md[0], md[1], md[2], md[3]);
-      d[4L * j.ldw] = make_uint4(l[0], l[1], l[2], l[3]);
+      if (np == 3) {
+        d[2L * j.ldw] = make_uint4(md[0], md[1], md[2], md[3]);
+        d[4L * j.ldw] = make_uint4(l[0], l[1], l[2], l[3]);
+      }
     }
     return;
   }
@@ -1556,14 +1445,15 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // NC = 128-column blocks per workgroup.  NC = 2 (256 x 256 tiles, WM = 4 only): the output-gradient
 // tile -- fetched, split and stored once per workgroup, and the same for every column tile of the
 // launch -- serves twice the columns; each wave then owns two 64 x 64 blocks 128 columns apart.
-template <int WM, int NC>
+// NP = bf16 pieces per operand: 3 (mode 2) or 1 (mode 1: operands rounded to bf16, one product).
+template <int WM, int NC, int NP>
 __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) {
   static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   constexpr int NT2 = 128 * WM, BM2 = 64 * WM, BNC = BN * NC;
   constexpr int PA = BM2 + 4, PB = BNC + 4;               // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
   constexpr int NA = BM2 * 4 / NT2, NB = BNC * 4 / NT2;   // float4 row loads per thread: 2 and 1 or 2 (WM=4) / 2 and 2
-  __shared__ uint4 As[2][3][2][PA];
-  __shared__ uint4 Bs[2][3][2][PB];
+  __shared__ uint4 As[2][NP][2][PA];
+  __shared__ uint4 Bs[2][NP][2][PB];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;       // a.ntile_m counts 128-row slab tiles
   // XCD-aware order (1-D grid): workgroups that run on one XCD at the same time are consecutive
@@ -1663,13 +1553,17 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   // staging: this thread's 4 consecutive t of a row are half (s_chunk & 1) of the 8-k group
   // (s_chunk >> 1) of that row; split into the three bf16 pieces and written as 8 bytes per piece
   auto put = [&](uint4* plane0, int prow, const float4 v) {     // plane0 = &X[stage][0][s_chunk >> 1][row]
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(v.x, v.y, h0, m0, l0);
-    split3(v.z, v.w, h1, m1, l1);
     uint2* d = reinterpret_cast<uint2*>(plane0) + (s_chunk & 1);
-    d[2 * (0 * 2 * prow)] = make_uint2(h0, h1);
-    d[2 * (1 * 2 * prow)] = make_uint2(m0, m1);
-    d[2 * (2 * 2 * prow)] = make_uint2(l0, l1);
+    if constexpr (NP == 3) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(v.x, v.y, h0, m0, l0);
+      split3(v.z, v.w, h1, m1, l1);
+      d[2 * (0 * 2 * prow)] = make_uint2(h0, h1);
+      d[2 * (1 * 2 * prow)] = make_uint2(m0, m1);
+      d[2 * (2 * 2 * prow)] = make_uint2(l0, l1);
+    } else {
+      d[0] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
   };
 #define W3_STAGE(RA, RB, VM, BS, BT, STAGE, REAL)                                             \
   {                                                                                            \
@@ -1698,36 +1592,38 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   }
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
-    bf16x8 af[2][3], bf[2][3];
+    bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
       }
-    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][3]) {
+    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          f32x16 c = ac[i][j];                                   // small products first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          f32x16 c = ac[i][j];
+          if constexpr (NP == 3) {                               // small products first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
           ac[i][j] = c;
         }
     };
     block(acc, bf);
     if constexpr (NC == 2) {
-      bf16x8 bg[2][3];
+      bf16x8 bg[2][NP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
       block(acc2, bg);
     }
   };
@@ -1906,7 +1802,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
 
 // split-K plan for a small-grid, long-K linear GEMM (see GemmArgs::ksplit); 1 = no split
 static int plan_ksplit(int M, int Tout, int B, int nk) {
-  if (g_matmul_dtype == 1 || M % 256 == 0) return 1;
+  if (M % 256 == 0) return 1;
   const long tiles = (long)cdiv(M, 128) * cdiv(Tout, BN) * B;
   if (tiles > 128 || nk < 32) return 1;
   long s = 512 / tiles;                     // fill ~half the chip's 1024 slots
@@ -1951,17 +1847,24 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
   static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
   const long nblk2 = (long)g.ntile_m * cdiv(g.Tout, 2 * BN) * g.B;
-  if (g_matmul_dtype == 2 && big && x3_nb == 2 && nblk2 >= 256) {
-    g.ntile_n = cdiv(g.Tout, 2 * BN);
-    hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
-  } else if (g_matmul_dtype == 2) {
-    if (big) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
-  } else if (g_matmul_dtype == 1) {
-    if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, true>), dim3((unsigned)nblk), dim3(256), 0, st, g);
-  } else {
-    if (big) hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+  const bool wide = g_matmul_dtype != 0 && big && x3_nb == 2 && nblk2 >= 256;
+  if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
+  // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
+  // not instantiated
+  if constexpr (EPI != EPI_GATE_BWD) {
+    if (big && g_matmul_dtype == 2) {
+      if (wide) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2, 3>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1, 3>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    } else if (big && g_matmul_dtype == 1) {
+      if (wide) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2, 1>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1, 1>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    } else if (big) {
+      hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+    }
+  }
+  if (!big) {
+    if (g_matmul_dtype == 2) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1, 3>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (g_matmul_dtype == 1) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
   }
   VQ_LAUNCH_CHECK();
@@ -1980,7 +1883,7 @@ static int launch_pack(PackArgs& pa, hipStream_t st) {
   long mx = 0;
   for (int i = 0; i < pa.njob; ++i) {
     long t = (long)pa.job[i].K * pa.job[i].Rpad * pa.job[i].mspan;
-    if (g_matmul_dtype == 2) t /= 8;
+    if (g_matmul_dtype != 0) t /= 8;
     if (t > mx) mx = t;
   }
   int nb = (int)((mx + 255) / 256);
@@ -2077,17 +1980,21 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
     sg.vec = (sg.tmul == 1 && sg.tdiv == 1 && w.Tout % 4 == 0) ? 1 : 0;
   }
   // fp32, stride-1 segments, 16-B aligned output-gradient rows: the 16-byte-LDS kernel
-  bool fast = (g_matmul_dtype != 1) && av && g_wgrad_impl != 1;
+  bool fast = av && g_wgrad_impl != 1;
   for (int i = 0; i < w.nseg; ++i) fast = fast && w.seg[i].tmul == 1 && w.seg[i].tdiv == 1;
   ProfScope ps(tag, st);
   static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
   const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
   if (fast && g_matmul_dtype == 2 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
-    hipLaunchKernelGGL((wgrad3_kernel<4, 2>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
+    hipLaunchKernelGGL((wgrad3_kernel<4, 2, 3>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
   } else if (fast && g_matmul_dtype == 2 && w.M % 256 == 0) {
-    hipLaunchKernelGGL((wgrad3_kernel<4, 1>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+    hipLaunchKernelGGL((wgrad3_kernel<4, 1, 3>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && g_matmul_dtype == 2) {
-    hipLaunchKernelGGL((wgrad3_kernel<2, 1>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+    hipLaunchKernelGGL((wgrad3_kernel<2, 1, 3>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+  } else if (fast && g_matmul_dtype == 1 && w.M % 256 == 0) {
+    hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+  } else if (fast && g_matmul_dtype == 1) {
+    hipLaunchKernelGGL((wgrad3_kernel<2, 1, 1>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
   } else if (fast && w.M % 256 == 0) {
     hipLaunchKernelGGL(wgrad2_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast) {

@@ -396,3 +396,41 @@ def test_plot_report_writes_the_three_loss_pngs(tmp_path):
         with open(p, 'rb') as f:
             assert f.read(8) == b'\x89PNG\r\n\x1a\n'
         assert os.path.getsize(p) > 2000
+
+
+def test_hot_kernels_keep_their_staging_in_registers(tmp_path):
+    """The GEMM kernels hold two K steps of operands in registers.  hipcc silently moves small private
+    arrays to scratch or LDS (seen: a uint4[3] refactor cost 18 % of the step with every test green), so
+    the compiled kernels' metadata is part of the contract: the launched instantiations of the conv and
+    weight-gradient kernels use no scratch beyond a few spilled registers and exactly their declared LDS."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'chainer-vq-vae_amd', 'csrc', 'conv_gemm.hip')
+    out = str(tmp_path / 'conv_gemm.s')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+                           '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = {}
+    for m in re.finditer(r'\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+)'
+                         r'.*?\.vgpr_count:\s*(\d+).*?\.vgpr_spill_count:\s*(\d+)', text, re.S):
+        meta[m.group(2)] = tuple(int(m.group(i)) for i in (1, 3, 4, 5))
+    expect_lds = {  # launched instantiations: (kernel substring) -> LDS bytes
+        'conv_gemm_x3_kernelILi0ELi4ELi2ELi3E': 98304, 'conv_gemm_x3_kernelILi1ELi4ELi2ELi3E': 98304,
+        'conv_gemm_x3_kernelILi0ELi4ELi1ELi3E': 73728, 'conv_gemm_x3_kernelILi1ELi4ELi1ELi3E': 73728,
+        'conv_gemm_x3_kernelILi0ELi2ELi1ELi3E': 49152, 'conv_gemm_x3_kernelILi2ELi2ELi1ELi3E': 49152,
+        'conv_gemm_x3_kernelILi0ELi4ELi2ELi1E': 32768, 'conv_gemm_x3_kernelILi1ELi4ELi2ELi1E': 32768,
+        'wgrad3_kernelILi4ELi1ELi3E': 75264, 'wgrad3_kernelILi2ELi1ELi3E': 50688, 'wgrad3_kernelILi4ELi1ELi1E': 25088,
+        'conv_gemm_kernelILi1ELi4ELb0E': 49152, 'wgrad2_kernelILi4E': None,
+    }
+    for key, lds in expect_lds.items():
+        hits = [(n, v) for n, v in meta.items() if key in n]
+        assert hits, 'no kernel matching %s in the compiled module' % key
+        for name, (got_lds, scratch, vgpr, spills) in hits:
+            assert scratch <= 32 and spills <= 8, '%s: %d B of scratch, %d spilled VGPRs' % (name, scratch, spills)
+            assert vgpr <= 256
+            if lds is not None:
+                assert got_lds == lds, '%s: %d B of LDS (private arrays promoted?), expected %d' % (name, got_lds, lds)
