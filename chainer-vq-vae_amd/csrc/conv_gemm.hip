@@ -133,7 +133,8 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 // Epilogue of the conv GEMM kernels: acc[mi][ni] is the wave's 2 x 2 block of 32 x 32 accumulator tiles
 // (rows m0 + wm*64 + mi*32, columns t0 + wn*64 + ni*32) of batch item b.  SPLITK: this instantiation
 // may have been launched with ksplit > 1 (raw partial tiles out, gemm_splitk_reduce_kernel finishes).
-template <int EPI, int WM, bool SPLITK>
+// DEEP: the linear epilogue requests a whole block's operands up front (needs 64 more registers).
+template <int EPI, int WM, bool SPLITK, bool DEEP = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
                                               const int b, const int wm, const int wn, const int li, const int lk,
                                               const int ksp, const int tile_id, const int ntiles_all) {
@@ -186,10 +187,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             for (int r = 0; r < 16; ++r) acc[mi][n2][r] += bias[r];
         }
       }
-      float pv[2][16];
+      if constexpr (DEEP) {
+        // every operand of the block is requested before the first store (64 loads in flight per lane:
+        // the registers of the main loop's staging are free now); a store then only waits for ITS
+        // sub-tile's loads (counted vmcnt).  With one sub-tile of look-ahead the K = 128 residual
+        // projection spent as long in this epilogue as in the rest of the kernel (71 of 142 us).
+        float pv[4][16];
 #pragma unroll
-      for (int q = 0; q <= 4; ++q) {
-        if (q < 4) {                 // request the operands of sub-tile q
+        for (int q = 0; q < 4; ++q) {
           const int mi = q >> 1, ni = q & 1;
           const int mb = m0 + wm * 64 + mi * 32;
           const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
@@ -201,14 +206,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           if (src) {
             const rsrc_t rs = make_rsrc(src);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+            for (int r = 0; r < 16; ++r) pv[q][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
           } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
+            for (int r = 0; r < 16; ++r) pv[q][r] = 0.f;
           }
         }
-        if (q > 0) {                 // finish sub-tile q - 1
-          const int p = q - 1, mi = p >> 1, ni = p & 1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int mi = p >> 1, ni = p & 1;
           const int mb = m0 + wm * 64 + mi * 32;
           const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
           const OutR& od = a.out[o];
@@ -217,9 +223,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][ni][r] + pv[p & 1][r];
+            float v = acc[mi][ni][r] + pv[p][r];
             if (od.relu) v = fmaxf(v, 0.f);
             buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+          }
+        }
+      } else {
+        float pv[2][16];
+#pragma unroll
+        for (int q = 0; q <= 4; ++q) {
+          if (q < 4) {                 // request the operands of sub-tile q
+            const int mi = q >> 1, ni = q & 1;
+            const int mb = m0 + wm * 64 + mi * 32;
+            const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+            const OutR& od = a.out[o];
+            const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+            const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+            const float* src = od.add ? od.add + (long)b * od.add_bstride
+                                      : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
+            if (src) {
+              const rsrc_t rs = make_rsrc(src);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
+            }
+          }
+          if (q > 0) {                 // finish sub-tile q - 1
+            const int p = q - 1, mi = p >> 1, ni = p & 1;
+            const int mb = m0 + wm * 64 + mi * 32;
+            const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+            const OutR& od = a.out[o];
+            const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+            const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+            const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[mi][ni][r] + pv[p & 1][r];
+              if (od.relu) v = fmaxf(v, 0.f);
+              buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+            }
           }
         }
       }
@@ -890,9 +934,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   }
 #undef X3_FETCH
 #undef X3_STAGE
-  gemm_epilogue<EPI, WM, SPLITK>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
+  gemm_epilogue<EPI, WM, SPLITK, WM == 4>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
   if constexpr (NB == 2) {
-    if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
+    if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
 }
 
