@@ -433,7 +433,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
 }
 
 template <int EPI, int WM, bool BF16>
-__global__ __launch_bounds__(128 * WM, (WM == 2 ? 4 : 2)) void conv_gemm_kernel(const GemmArgs a) {
+// (the linear 128-row instantiation carries the split-K path and needs 171 registers: three waves per
+// SIMD; at four it spilled 118 of them)
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? (EPI == EPI_LINEAR ? 3 : 4) : 2)) void conv_gemm_kernel(const GemmArgs a) {
   static_assert(!BF16, "matmul mode 1 runs on conv_gemm_x3_kernel<..., NP = 1>");
   constexpr int BM = 64 * WM, NT = 128 * WM;
   __shared__ float As[2][BK][BM];
