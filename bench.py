@@ -268,6 +268,8 @@ def run_c4(args, rank, n, local):
     from vqvae_amd.backend import DeviceArray
     from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
     backend.init(local)
+    if getattr(args, 'matmul', None):
+        backend.set_matmul_dtype(args.matmul)
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
     d, k, T = 128, 8192, 120
     N = args.vq_rows
@@ -305,6 +307,9 @@ def run_c4(args, rank, n, local):
     _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
     seen = comm.ranks_seen()
     if rank == 0:
+        mode = backend.default_matmul_dtype() if not getattr(args, 'matmul', None) else args.matmul
+        x3 = mode == 'float32x3'
+        peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS
         flop = 2.0 * N * k * d                              # expansion form, re-check not counted
         byts = 4.0 * (N * d + k * d + N + N * d)            # z read, codebook once, idx write, e write
         avg_ms = tot.value / max(cnt.value, 1)
@@ -331,11 +336,15 @@ def run_c4(args, rank, n, local):
                        'parallelism': 'dp%d (independent rows per rank, no data-path collective)' % n},
             'rows_rechecked_exactly': int(nre.get()[0]),
             'indices_match_reference_order_distance_on_64_rows': bool(ok),
-            'roofline': {'bound': 'mfma', 'kernel': 'vqvae_vq_nearest_fwd (vq_wnorm + vq_mfma_reg_kernel '
-                         '+ vq_exact_batched_kernel + gather): MFMA pairwise distance, wavefront argmin, '
-                         'exact re-check of ambiguous rows',
-                         'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
+            'matmul': mode,
+            'roofline': {'bound': 'mfma', 'kernel': 'vqvae_vq_nearest_fwd (vq_wnorm + %s + vq_exact_batched_kernel '
+                         '+ gather): MFMA pairwise distance, wavefront argmin, exact re-check of ambiguous rows'
+                         % ('vq_wsplit + vq_mfma_x3_kernel' if x3 else 'vq_mfma_reg_kernel'),
+                         'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                         'peak_is': ('dense bf16 MFMA peak / %d bf16 products per fp32 product; achieved counts '
+                                     'algorithmic fp32 FLOPs' % X3_PRODUCTS if x3 else 'fp32 MFMA peak'),
+                         'frac': (ach / peak) if ach else None,
+                         'achieved_vs_fp32_mfma_peak': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop,
                          'hbm': {'achieved_algorithmic': gbs, 'peak': 8000.0, 'unit': 'GB/s',

@@ -5,8 +5,10 @@
 //     acc = 0; for c in 0..d-1: acc = acc + (z[c]-W[j][c])**2      (each op rounded)
 // with numpy.argmin's first-minimum rule.  Evaluating that form for all N*k
 // pairs is 3 non-fusable VALU ops per term; instead:
-//   1. vq_mfma_kernel  -- dist'(j,n) = |w_j|^2 - 2 <w_j, z_n> on the fp32 matrix
-//      cores (v_mfma_f32_32x32x2_f32: codes x latents tiles), per-lane running
+//   1. vq_mfma_x3_kernel (matmul mode 2, d = 64 / 128: six bf16 MFMA products of an exact
+//      three-way operand split per fp32 product) or vq_mfma_reg_kernel / vq_mfma_kernel
+//      (v_mfma_f32_32x32x2_f32) -- dist'(j,n) = |w_j|^2 - 2 <w_j, z_n> on the matrix
+//      cores (codes x latents tiles), per-lane running
 //      (min, argmin, runner-up) and a cross-half wavefront reduce.  A row is
 //      CERTAIN when runner-up - min exceeds a rigorous rounding band; otherwise it is
 //      queued for
@@ -208,6 +210,166 @@ __global__ __launch_bounds__(256, 2) void vq_mfma_reg_kernel(
   if (lk == 0 && n < N) {
     const float wmax = __int_as_float(*wmax_bits);
     const float band = 12.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
+    idx[n] = i1;
+    if (!(m2 - m1 > band)) {
+      const int slot = atomicAdd(nflag, 1);
+      flagged[slot] = (int32_t)n;
+    }
+  }
+}
+
+// ---- the same sweep on the bf16 matrix pipe (matmul mode 2, d = 64 or 128) ------------------------
+// <w_j, z_n> as six v_mfma_f32_32x32x16_bf16 products of an exact three-way bf16 split of both
+// operands (csrc/conv_gemm.hip, "matmul mode 2"): 6 x 32 cycles per 16 c instead of 8 x 64.  The
+// codebook is split once per call (vq_wsplit_kernel: [piece][code][d] bf16), the latent fragment of
+// a wavefront's 32 columns is split once and stays in registers for the whole sweep.
+// Rounding band: each kept product is exact, the three dropped ones are < 2^-25 |ab|; an MFMA adds 16
+// exact products to its accumulator -- taken here as no better than 17 individually rounded
+// additions -- so a dot product is within (6d/16 * 17 + d/8) u |w||z| <= 3.3 d u S of the real
+// number (S = |z|^2 + max|w|^2 >= 2|w||z|) and dist' = |w|^2 - 2<w,z> within (6.6 d + d + 2) u S;
+// two such errors separate the reference's argmin from a competitor by < 15.2 (d + 1) u S: 16(d+4)uS.
+using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned vq_pk(float lo, float hi) {
+  bf16x2v v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void vq_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = vq_pk(x0, x1);
+  float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = vq_pk(r0, r1);
+  r0 -= __builtin_bit_cast(float, m << 16); r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+  l = vq_pk(r0, r1);
+}
+// Wp[piece][code][d] bf16 (two per 32-bit word)
+__global__ void vq_wsplit_kernel(const float* __restrict__ W, int k, int d, unsigned* __restrict__ Wp) {
+  const long pairs = (long)k * d / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+    unsigned h, m, l;
+    vq_split3(W[2 * i], W[2 * i + 1], h, m, l);
+    Wp[i] = h; Wp[pairs + i] = m; Wp[2 * pairs + i] = l;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
+    const float* __restrict__ z, const uint4* __restrict__ Wp, const float* __restrict__ wn,
+    const int* __restrict__ wmax_bits, int B, int T, int k,
+    int32_t* __restrict__ idx, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+  constexpr int TILE = 64, KS = D / 16;              // K steps of 16 c
+  constexpr int ROW = D / 8 + 1;                     // 16-byte words per LDS row (+1: conflict-free fragment reads)
+  constexpr int WPR = D / 8;                         // 16-byte words per code row in global memory
+  extern __shared__ uint4 wt[];                      // [2][3][TILE][ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const long N = (long)B * T;
+  const long n = (long)blockIdx.x * 256 + wave * 32 + li;      // this lane's latent column
+  // B fragment of K step s: lane (column li, half lk) holds c = 16 s + 8 lk .. + 7, split in three
+  uint4 zh[KS], zm[KS], zl[KS];
+  float zn = 0.f;
+  {
+    const bool ok = n < N;
+    const long bb = ok ? n / T : 0, t = ok ? n % T : 0;
+    const float* zp = z + (bb * D) * T + t;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = ok ? zp[(long)(16 * s + 8 * lk + e) * T] : 0.f;
+        zn = fmaf(v[e], v[e], zn);
+      }
+      vq_split3(v[0], v[1], zh[s].x, zm[s].x, zl[s].x);
+      vq_split3(v[2], v[3], zh[s].y, zm[s].y, zl[s].y);
+      vq_split3(v[4], v[5], zh[s].z, zm[s].z, zl[s].z);
+      vq_split3(v[6], v[7], zh[s].w, zm[s].w, zl[s].w);
+    }
+    zn += __shfl_xor(zn, 32, 64);           // both halves of the column
+  }
+  // staging: a tile is 3 pieces x 64 codes x WPR words; 512 threads
+  constexpr int WORDS = 3 * TILE * WPR, PER_THREAD = (WORDS + 511) / 512;
+  uint4 st[PER_THREAD];
+  const long piece_words = (long)k * WPR;
+  auto load_tile = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int f = tid + 512 * i;
+      const int p = f / (TILE * WPR), r = (f / WPR) % TILE, c = f % WPR;
+      const int j = jt * TILE + r;
+      st[i] = (f < WORDS && j < k) ? Wp[p * piece_words + (long)j * WPR + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    uint4* dst = wt + (size_t)buf * 3 * TILE * ROW;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < WORDS) {
+        const int p = f / (TILE * WPR), r = (f / WPR) % TILE, c = f % WPR;
+        dst[(p * TILE + r) * ROW + c] = st[i];
+      }
+    }
+  };
+  float m1 = INFINITY, m2 = INFINITY;
+  int i1 = 0x7fffffff;
+  const int ntile = (k + TILE - 1) / TILE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int jt = 0; jt < ntile; ++jt) {
+    const int cur = jt & 1;
+    if (jt + 1 < ntile) load_tile(jt + 1);
+    const uint4* base = wt + (size_t)cur * 3 * TILE * ROW;
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8v w0[3], w1[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        w0[p] = __builtin_bit_cast(bf16x8v, base[(p * TILE + li) * ROW + 2 * s + lk]);
+        w1[p] = __builtin_bit_cast(bf16x8v, base[(p * TILE + 32 + li) * ROW + 2 * s + lk]);
+      }
+      const bf16x8v bh = __builtin_bit_cast(bf16x8v, zh[s]), bm = __builtin_bit_cast(bf16x8v, zm[s]),
+                    bl = __builtin_bit_cast(bf16x8v, zl[s]);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[2], bh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[2], bh, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[0], bl, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[0], bl, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[1], bm, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[1], bm, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[1], bh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[1], bh, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[0], bm, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[0], bm, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[0], bh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[0], bh, a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (j < k) {
+          const float v = fmaf(-2.f, h ? a1[r] : a0[r], wn[j]);
+          if (v < m1) { m2 = m1; m1 = v; i1 = j; }
+          else if (v < m2) { m2 = v; }
+        }
+      }
+    if (jt + 1 < ntile) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  {
+    const float om1 = __shfl_xor(m1, 32, 64);
+    const float om2 = __shfl_xor(m2, 32, 64);
+    const int oi1 = __shfl_xor(i1, 32, 64);
+    if (om1 < m1 || (om1 == m1 && oi1 < i1)) { m2 = fminf(m1, om2); m1 = om1; i1 = oi1; }
+    else { m2 = fminf(m2, om1); }
+  }
+  if (lk == 0 && n < N) {
+    const float wmax = __int_as_float(*wmax_bits);
+    const float band = 16.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {
       const int slot = atomicAdd(nflag, 1);
@@ -600,7 +762,8 @@ using namespace vq;
 
 extern "C" size_t vqvae_vq_workspace_bytes(int B, int d, int T, int k) {
   const size_t N = (size_t)B * T;
-  size_t fwd = align_up((size_t)k * 4, 256) + 256 /*wmax+nflag*/ + align_up(N * 4, 256);
+  size_t fwd = align_up((size_t)k * 4, 256) + 256 /*wmax+nflag*/ + align_up(N * 4, 256) +
+               align_up((size_t)k * d * 6, 256) /*split codebook (matmul mode 2)*/;
   // large-N codebook gradient: part64[k][SPLIT][d] | base[k+1] | cursor[nchunk][k] | sorted[N]
   const size_t nchunk = (N + VQ_GW_CHUNK - 1) / VQ_GW_CHUNK;
   size_t bwd = align_up((size_t)k * VQ_GW_SPLIT * d * 8, 256) + align_up(((size_t)k + 1) * 4, 256) +
@@ -620,7 +783,8 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
   float* wn = (float*)wp; wp += align_up((size_t)k * 4, 256);
   int* wmax_bits = (int*)wp;
   int32_t* nflag = (int32_t*)(wp + 64); wp += 256;
-  int32_t* flagged = (int32_t*)wp;
+  int32_t* flagged = (int32_t*)wp; wp += align_up((size_t)N * 4, 256);
+  unsigned* wsplit = (unsigned*)wp;
   ProfScope ps(VQVAE_PROF_VQ_NEAREST, st);
   if (mode == 0) {
     const int dpad = (d + 1) / 2 * 2;
@@ -629,7 +793,22 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
     hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
-    if (d == 64 || d == 128) {
+    if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() == 2) {
+      int nb = (int)(((long)k * d / 2 + 255) / 256);
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(vq_wsplit_kernel, dim3(nb), dim3(256), 0, st, W, k, d, wsplit);
+      VQ_LAUNCH_CHECK();
+      const size_t lds = 2 * 3 * 64 * (size_t)(d / 8 + 1) * 16;
+      const unsigned grid = (unsigned)((N + 255) / 256);
+      if (d == 64) {
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_mfma_x3_kernel<64>, dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag);
+      } else {
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vq_mfma_x3_kernel<128>, dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag);
+      }
+      VQ_LAUNCH_CHECK();
+    } else if (d == 64 || d == 128) {
       const size_t lds = 2 * 64 * (size_t)(d + 1) * 4;
       const unsigned grid = (unsigned)((N + 127) / 128);
       if (d == 64) {
