@@ -173,7 +173,7 @@ def _run_vq(gpu, z, W, gy, mode):
 
 @pytest.mark.parametrize('name', ['vq_train', 'vq_3d', 'vq_ties'])
 @pytest.mark.parametrize('mode', [0, 1])
-def test_vq_golden(gpu, name, mode):
+def test_vq_golden(gpu, matmul_mode, name, mode):
     g = np.load(os.path.join(GOLD, name + '.npz'))
     e, idx, gx, gW, nre = _run_vq(gpu, g['z'], g['W'], g['gy'], mode)
     np.testing.assert_array_equal(idx, g['idx'])          # bit-exact indices
@@ -184,7 +184,7 @@ def test_vq_golden(gpu, name, mode):
 
 
 @pytest.mark.parametrize('mode', [0, 1])
-def test_vq_golden_stress(gpu, mode):
+def test_vq_golden_stress(gpu, matmul_mode, mode):
     from golden.make_golden import stress_inputs
     g = np.load(os.path.join(GOLD, 'vq_stress.npz'))
     B, d, T, k = [int(v) for v in g['shape']]
@@ -199,7 +199,7 @@ def test_vq_golden_stress(gpu, mode):
     assert not gW[rest].any()
 
 
-def test_vq_mfma_vs_exact_large(gpu):
+def test_vq_mfma_vs_exact_large(gpu, matmul_mode):
     """Size-independent property at the C4 scale the oracle cannot reach in
     seconds: the MFMA + re-check path must equal the all-exact path row for row."""
     from golden.make_golden import stress_inputs
