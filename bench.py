@@ -380,7 +380,9 @@ def main():
                     help='feed x_dec as mu-law bin indices produced on the device (device-side input '
                          'pipeline) instead of the reference\'s one-hot float tensor')
     ap.add_argument('--no-overlap', action='store_true',
-                    help='single stream: no side-stream overlap of the weight-gradient kernels (per-kernel timing)')
+                    help='single stream (the default since the float32x3 kernels; kept for the profile scripts)')
+    ap.add_argument('--overlap', action='store_true',
+                    help='weight gradients of the backward pass on a second stream')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -411,6 +413,8 @@ def main():
     mode = 'bfloat16' if args.bf16 else (args.matmul or backend.default_matmul_dtype())
     if args.no_overlap:
         backend.set_overlap(False)
+    if args.overlap:
+        backend.set_overlap(True)
     comm = RcclCommunicator(rank, n, local) if (n > 1 or args.force_comm) else SingleCommunicator()
 
     # train.py's order (train.py:76-102): construct -> to_gpu -> optimizer.setup -> train.  The

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 _state = {'stream': None, 'side': None, 'device': None, 'pool': {}, 'live_bytes': 0,
-          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': os.environ.get('VQVAE_OVERLAP', '1') != '0'}
+          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': os.environ.get('VQVAE_OVERLAP', '0') == '1'}
 
 
 def init(device=0):
@@ -78,6 +78,11 @@ def pool_stream(i):
 
 
 def overlap_enabled():
+    """Whether backward runs weight gradients on the side stream.  Off by default: with the
+    float32x3 kernels (one 8-wave workgroup per CU, the chip at its power limit) a second stream
+    only interleaves work that cannot co-reside -- measured +0.58 ms per step at configs[1]; it
+    was worth -1.6 ms with round 1's fp32 MFMA kernels and is neutral in that mode now.
+    set_overlap(True) or VQVAE_OVERLAP=1 turns it on."""
     return _state['overlap']
 
 

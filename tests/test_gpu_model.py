@@ -163,6 +163,8 @@ def test_two_stream_backward_is_deterministic_and_equals_single_stream(gpu):
     cfg = dict(H.SMALL, residual=128, dilated=128, skip=128, n_layer=6)
     batches = [O.synth_batch(4, length=2048, n_speaker=cfg['n_speaker'], seed=50 + s) for s in range(2)]
 
+    was = backend.overlap_enabled()
+
     def run(overlap):
         backend.set_overlap(overlap)
         try:
@@ -175,7 +177,7 @@ def test_two_stream_backward_is_deterministic_and_equals_single_stream(gpu):
                 upd.update()
             return opt.params.get(), opt.grads.get()
         finally:
-            backend.set_overlap(True)
+            backend.set_overlap(was)
     p0, g0 = run(True)
     for _ in range(3):
         p1, g1 = run(True)

@@ -21,7 +21,7 @@ run_pmc() {     # name, counters, bench args...
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pp_$name > $OUT/${name}.csv
 }
 run_stats c2 --steps 10 --warmup 3
-run_stats c2_single_stream --steps 10 --warmup 3 --no-overlap
+run_stats c2_two_streams --steps 10 --warmup 3 --overlap
 run_stats c2_fp32mfma --steps 10 --warmup 3 --matmul float32
 run_stats c4 --workload c4 --steps 5 --warmup 2
 run_stats c4_N1920 --workload c4 --vq-rows 1920 --steps 20 --warmup 3
