@@ -465,6 +465,31 @@ def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
         assert e3 <= 1.25 * e1 + 1e-7, '%s: float32x3 %.3e vs fp32 MFMA %.3e (of scale, against float64)' % (name, e3, e1)
 
 
+
+@pytest.mark.parametrize('scale', [1e-15, 1.0, 1e15])
+def test_float32x3_is_scale_invariant(gpu, scale):
+    """The three-way split works on significands: scaling the operands by 2^k-ish factors (here
+    1e-15 .. 1e15, far inside the bf16 = fp32 exponent range) leaves the relative error against
+    float64 where it was.  (Operands below ~2^-110 would lose their low pieces to the denormal
+    range -- gradually, like any fp32 arithmetic near underflow.)"""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Tin, Cout, K, stride, pad, dil = 2, 96, 300, 80, 2, 1, 8, 8
+    rs = np.random.RandomState(11)
+    x = (rs.standard_normal((B, Cin, Tin)) * scale).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K) / scale ** 0.5).astype(np.float32)
+    b = np.zeros(Cout, np.float32)
+    y64 = _conv64(x, W, b, stride, pad, dil)
+    gpu.set_matmul_dtype('float32x3')
+    try:
+        y = F.convolution_1d(Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b)),
+                             stride=stride, pad=pad, dilate=dil)
+        err = np.abs(y.data.get()[..., 0].astype(np.float64) - y64).max() / np.abs(y64).max()
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+    assert err <= 1e-6, 'scale %g: %.3e of scale from float64' % (scale, err)
+
+
 @pytest.fixture
 def bf16_mode(gpu):
     gpu.set_matmul_dtype('bfloat16')
