@@ -9,6 +9,21 @@
 // at 16x the rate of v_mfma_f32_32x32x2_f32, so six of them per 16 k cost 6/16 of the fp32 MFMA time.
 //   X1  256 x 128 tile, 8 waves as 4 x 2 (64 x 64 each: the accumulator layout of csrc/conv_gemm.hip),
 //       weights pre-split and packed in fragment order, activations split while they are staged
+//   X2  X1 with the fetches two K steps ahead (two register sets): the product kernel's loop
+//       (modes: ablations -- no A / B loads, no split, no barrier, no fragment reads; 128: the
+//       LDS stores of the next step issued before the MFMAs; 512: float4 stores through LDS)
+//   X3  4-wave workgroups, 64 x 128 per wave, two workgroups per CU
+//   X5  wave specialisation: 4 MFMA waves + 4 staging waves (d4: fetches four steps ahead)
+//   X6  three LDS stages and the fragments double-buffered in registers (spills 340 VGPRs)
+//   X7  weights by LDS-DMA into a three-stage ring (no staging VGPRs, no ds_write for 2/3 of the bytes)
+// Measured on MI355X (T = 7680, dil 64; fp32 MFMA loop of conv_loop.hip: 285 us): X1 241, X2 202-212,
+// X3 208-218, X5 225, X5d4 213, X2 stage-first 210 (205 with an MFMA/VALU interleave), X7 207-214 us.
+// Ablations of X2: no A loads 162-169, no B loads 147-160, neither 122-124, no fragment reads 180,
+// no split VALU 206, MFMA only 107 (at 1.84 GHz: 94 % of the clock-adjusted matrix pipe).
+// The chip is at its power limit: cycles per tile do not depend on how many workgroups run (80 k for
+// 32 K steps with 32 or with 960 workgroups, X3_GRID), the shader clock does (2.35 GHz -> 1.6-1.7 GHz),
+// and a schedule that saves cycles at low load (stage-first: -5.5 %) gives them back in clock at
+// full load.  What helps is moving fewer bytes per FLOP (the product's 256-column tiles).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 x3_loop.hip -o x3_loop ; run: ./x3_loop [dil] [T]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -634,6 +649,119 @@ __global__ __launch_bounds__(NT, 2) void conv_x6(const Args a) {
       }
 }
 
+// X7: X2 with the pre-split weights brought in by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs,
+// no ds_write for 2/3 of the staged bytes) into a three-stage ring; activations as in X2.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(NT, 2) void conv_x7(const Args a) {
+  __shared__ uint4 As[3][3][2][BM];      // 3 x 24 KB
+  __shared__ uint4 Bs[2][3][2][BN];      // 2 x 12 KB
+  const long long c_beg = clock64(), w_beg = wall_clock64();
+  int b, t0; tile_of(a, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps_tap = a.Cin / BK, nk = 2 * ksteps_tap;
+  const float* xb = a.x + (long)b * a.Cin * a.T;
+  const int s_n = tid & 127, s_q = tid >> 7;
+  const unsigned as_base = (unsigned)(size_t)&As[0][0][0][0];
+  const unsigned uwave = __builtin_amdgcn_readfirstlane(wave);
+  // A of step it -> ring stage it % 3: 24 wave-instructions of 1 KB, 3 per wave
+  auto dma_a = [&](int it, int stage) {
+    const uint4* wp = a.wpk + (size_t)it * (3 * 2 * BM);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int chunk = j * 8 + wave;                       // 1 KB chunk of the 24 KB stage
+      glds16(wp + chunk * 64 + lane, as_base + (unsigned)(stage * 24576 + (j * 8 + uwave) * 1024));
+    }
+  };
+  float pb0, pb1, pb2, pb3, qb0, qb1, qb2, qb3;
+  bool pok, qok;
+#define X7_LOADB(b0, b1, b2, b3, ok, it_)                                                 \
+  {                                                                                        \
+    const int tap = (it_) / ksteps_tap, c0 = ((it_) % ksteps_tap) * BK + 4 * s_q;          \
+    const int ts = t0 + s_n - (1 - tap) * a.dil;                                           \
+    const float* xs = ts >= 0 ? xb + (long)c0 * a.T + ts : xb;                             \
+    b0 = xs[0]; b1 = xs[(long)a.T]; b2 = xs[2L * a.T]; b3 = xs[3L * a.T];                  \
+    ok = ts >= 0;                                                                          \
+  }
+#define X7_STOREB(b0, b1, b2, b3, ok, buf)                                                 \
+  {                                                                                        \
+    unsigned h0, m0, l0, h1, m1, l1;                                                       \
+    split3(ok ? b0 : 0.f, ok ? b1 : 0.f, h0, m0, l0);                                      \
+    split3(ok ? b2 : 0.f, ok ? b3 : 0.f, h1, m1, l1);                                      \
+    uint2* bd = reinterpret_cast<uint2*>(&Bs[buf][0][s_q >> 1][s_n]) + (s_q & 1);          \
+    bd[0 * 2 * 2 * BN] = make_uint2(h0, h1);                                               \
+    bd[1 * 2 * 2 * BN] = make_uint2(m0, m1);                                               \
+    bd[2 * 2 * 2 * BN] = make_uint2(l0, l1);                                               \
+  }
+  auto mma = [&](int sa, auto curc) {
+    constexpr int cur = decltype(curc)::value;
+    bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        af[i][p] = __builtin_bit_cast(bf16x8, As[sa][p][lk][wm * 64 + i * 32 + li]);
+        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  dma_a(0, 0);
+  dma_a(1, 1);
+  X7_LOADB(pb0, pb1, pb2, pb3, pok, 0);
+  X7_LOADB(qb0, qb1, qb2, qb3, qok, 1);
+  X7_STOREB(pb0, pb1, pb2, pb3, pok, 0);          // the compiler's wait for P also covers both DMAs (older)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int sa = 0;
+  for (int it = 0; it < nk; it += 2) {
+    int s2 = sa + 2; if (s2 >= 3) s2 -= 3;
+    dma_a(min(it + 2, nk - 2), s2);               // ring stage of step it + 2: last read in step it - 1
+    X7_LOADB(pb0, pb1, pb2, pb3, pok, min(it + 2, nk - 2));
+    mma(sa, I0{});
+    X7_STOREB(qb0, qb1, qb2, qb3, qok, 1);        // waits (in order) for everything older than Q: the DMA of step it + 1 too
+    __syncthreads();
+    sa = sa == 2 ? 0 : sa + 1;
+    s2 = sa + 2; if (s2 >= 3) s2 -= 3;
+    dma_a(min(it + 3, nk - 1), s2);
+    X7_LOADB(qb0, qb1, qb2, qb3, qok, min(it + 3, nk - 1));
+    mma(sa, I1{});
+    X7_STOREB(pb0, pb1, pb2, pb3, pok, 0);
+    __syncthreads();
+    sa = sa == 2 ? 0 : sa + 1;
+  }
+  if (threadIdx.x == 0) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
+  float* yb = a.y + (long)b * BM * a.T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        yb[(long)row * a.T + t0 + wn * 64 + j * 32 + li] = acc[i][j][r];
+      }
+}
+
 // ---- host ------------------------------------------------------------------------------------
 static unsigned short bf16_rne(float f) {
   unsigned u; memcpy(&u, &f, 4);
@@ -720,7 +848,7 @@ int main(int argc, char** argv) {
   };
   run("X1", conv_x1<0>);
   run("X2", conv_x2<0>);
-  run("X2w", conv_x2<512>);
+  run("X7", conv_x7);
   run("X5", conv_x5<0>);
   run("X5d4", conv_x5<1>);
   nthreads = 256;
