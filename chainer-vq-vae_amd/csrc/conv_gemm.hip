@@ -733,7 +733,12 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 // section 8) -- and a barrier covers 48 MFMAs per wave; each wave then owns two 64 x 64 blocks, 128
 // columns apart, and runs the unchanged epilogue on each.
 // NP = bf16 pieces per operand: 3 (mode 2, six products) or 1 (mode 1: operands rounded to bf16, one product).
-template <int EPI, int WM, int NB, int NP>
+// TAP2: the contraction is exactly two segments over the SAME tensor that differ only in their time
+// shift (the two taps of a dilated conv, forward and backward-data): the K loop alternates the taps
+// channel group by channel group instead of running tap 0 to the end first, so the second fetch of
+// a group's rows follows the first by one step and is served by L1 / L2 instead of HBM / MALL
+// (round 1's gate kernel read x 2.09 times from the fabric).
+template <int EPI, int WM, int NB, int NP, bool TAP2 = false>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(NP == 1 || NP == 3, "one piece (bf16 operands) or three (exact split)");
@@ -788,22 +793,25 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   int seg_i = 0, c_n = 0, cin_n = 0, left = nsteps;
   const uint4* wp = nullptr;
   const float* xp = nullptr;
+  const uint4* wp1 = nullptr;              // TAP2: the second tap's weight / activation cursors
+  const float* xp1 = nullptr;
   const float* xsafe = a.seg[0].x;
   long wadv = 0, wl2 = 0, xadv = 0, xcs = 0;
-  bool ok_n = false;
-  auto seg_setup = [&](int s, int skip) {
+  bool ok_n = false, ok1 = false;
+  auto seg_cursors = [&](int s, int skip, const uint4*& wq, const float*& xq, bool& okq) {
     const Seg& sg = a.seg[s];
     cin_n = sg.cin; c_n = skip * BK;
     wadv = 2L * NP * sg.ldw; wl2 = 2L * sg.ldw;
-    wp = reinterpret_cast<const uint4*>(sg.w) + (long)skip * wadv + (long)a_hi * sg.ldw + m0 + a_m;
+    wq = reinterpret_cast<const uint4*>(sg.w) + (long)skip * wadv + (long)a_hi * sg.ldw + m0 + a_m;
     xcs = sg.x_cstride; xadv = (long)BK * sg.x_cstride;
     const int tnum = (t0 + s_n) * sg.tmul + sg.toff;
     bool ok = tnum >= 0;
     int tin = tnum;
     if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
-    ok_n = ok && tin < sg.Tin;
-    xp = sg.x + (long)b * sg.x_bstride + (long)(c_n + s_c) * sg.x_cstride + (ok_n ? tin : 0);
+    okq = ok && tin < sg.Tin;
+    xq = sg.x + (long)b * sg.x_bstride + (long)(c_n + s_c) * sg.x_cstride + (okq ? tin : 0);
   };
+  auto seg_setup = [&](int s, int skip) { seg_cursors(s, skip, wp, xp, ok_n); };
   {
     int s = 0, skip = it_beg;
     while (s + 1 < a.nseg) {
@@ -813,7 +821,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
     }
     seg_i = s;
     seg_setup(s, skip);
+    if constexpr (TAP2) seg_cursors(1, 0, wp1, xp1, ok1);      // both taps start at channel 0
   }
+  auto advance2 = [&]() {                    // TAP2: both taps of a channel group have been fetched
+    left -= 2;
+    if (left <= 0) return;
+    c_n += BK;
+    wp += wadv; wp1 += wadv; xp += xadv; xp1 += xadv;
+  };
   auto advance = [&]() {
     if (--left <= 0) return;                 // nothing further: later fetches re-read this step (never used)
     c_n += BK;
@@ -827,20 +842,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
   float pb[CPT], qb[CPT];
   unsigned pmask, qmask;
-#define X3_FETCH(A0, A1, A2, BV, MASK)                                                      \
+#define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, MASK, wp, xp, ok_n, !TAP2)
+#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, MASK, wp1, xp1, ok1, false)
+#define X3_FETCH_(A0, A1, A2, BV, MASK, WP, XP, OK, ADV)                                    \
   {                                                                                          \
-    A0 = wp[0];                                                                              \
-    if constexpr (NP == 3) { A1 = wp[wl2]; A2 = wp[2 * wl2]; }                               \
+    A0 = WP[0];                                                                              \
+    if constexpr (NP == 3) { A1 = WP[wl2]; A2 = WP[2 * wl2]; }                               \
     const int nvalid = cin_n - (c_n + s_c);                                                  \
     unsigned mk = 0;                                                                         \
     _Pragma("unroll") for (int e = 0; e < CPT; ++e) {                                        \
-      const bool v = ok_n && e < nvalid;                                                     \
-      const float* src = v ? xp + e * xcs : xsafe;                                           \
+      const bool v = OK && e < nvalid;                                                       \
+      const float* src = v ? XP + e * xcs : xsafe;                                           \
       BV[e] = *src;                                                                          \
       mk |= v ? (1u << e) : 0u;                                                              \
     }                                                                                        \
     MASK = mk;                                                                               \
-    if (!SCHED) advance();                                                                   \
+    if (!SCHED && (ADV)) advance();                                                          \
   }
 #define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
   {                                                                                          \
@@ -914,9 +931,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 
   if (nsteps > 0) {
     X3_FETCH(pa0, pa1, pa2, pb, pmask);
-    if (SCHED) advance();
-    X3_FETCH(qa0, qa1, qa2, qb, qmask);
-    if (SCHED) advance();
+    if (SCHED && !TAP2) advance();
+    if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qmask); advance2(); }
+    else X3_FETCH(qa0, qa1, qa2, qb, qmask);
+    if (SCHED && !TAP2) advance();
     X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);
     __syncthreads();
     // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1
@@ -924,17 +942,20 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
       X3_FETCH(pa0, pa1, pa2, pb, pmask);           // step i + 2
       mma(I0{});
       X3_STAGE(qa0, qa1, qa2, qb, qmask, 1);        // step i + 1
-      if (SCHED) advance();
+      if (SCHED && !TAP2) advance();
       __syncthreads();
       if (i + 1 >= nsteps) break;
-      X3_FETCH(qa0, qa1, qa2, qb, qmask);           // step i + 3
+      if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qmask); advance2(); }
+      else X3_FETCH(qa0, qa1, qa2, qb, qmask);      // step i + 3
       mma(I1{});
       X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);        // step i + 2
-      if (SCHED) advance();
+      if (SCHED && !TAP2) advance();
       __syncthreads();
     }
   }
 #undef X3_FETCH
+#undef X3_FETCH1
+#undef X3_FETCH_
 #undef X3_STAGE
   gemm_epilogue<EPI, WM, SPLITK, WM == 4>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
   if constexpr (NB == 2) {
@@ -1895,24 +1916,42 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   const long nblk2 = (long)g.ntile_m * cdiv(g.Tout, 2 * BN) * g.B;
   const bool wide = g_matmul_dtype != 0 && big && x3_nb == 2 && nblk2 >= 256;
   if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
+  // two taps of one tensor: interleave them channel group by channel group (TAP2).  The choice depends
+  // on the contraction only, never on the tile shape, so that a result does not change with the batch size.
+  static const int x3_tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
+  const bool tap2 = x3_tap2 && g_matmul_dtype != 0 && EPI != EPI_GATE_BWD && g.nseg == 2 && g.ksplit == 1 &&
+                    g.seg[0].x == g.seg[1].x && g.seg[0].cin == g.seg[1].cin && g.seg[0].cin % BK == 0 &&
+                    g.seg[0].x_cstride == g.seg[1].x_cstride && g.seg[0].x_bstride == g.seg[1].x_bstride &&
+                    g.seg[0].Tin == g.seg[1].Tin && g.seg[0].tmul == g.seg[1].tmul && g.seg[0].tdiv == g.seg[1].tdiv &&
+                    g.seg[0].ldw == g.seg[1].ldw;
+#define X3_LAUNCH(WMv, NBv, NPv, blocks, threads)                                                                    \
+  do {                                                                                                                \
+    if (tap2) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, true>), dim3((unsigned)(blocks)), dim3(threads), 0, st, g);  \
+    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, false>), dim3((unsigned)(blocks)), dim3(threads), 0, st, g);      \
+  } while (0)
   // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
   // not instantiated
   if constexpr (EPI != EPI_GATE_BWD) {
     if (big && g_matmul_dtype == 2) {
-      if (wide) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2, 3>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1, 3>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+      if (wide) X3_LAUNCH(4, 2, 3, nblk2, 512);
+      else X3_LAUNCH(4, 1, 3, nblk, 512);
     } else if (big && g_matmul_dtype == 1) {
-      if (wide) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 2, 1>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 4, 1, 1>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+      if (wide) X3_LAUNCH(4, 2, 1, nblk2, 512);
+      else X3_LAUNCH(4, 1, 1, nblk, 512);
     } else if (big) {
       hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
     }
-  }
-  if (!big) {
+    if (!big) {
+      if (g_matmul_dtype == 2) X3_LAUNCH(2, 1, 3, grid, 256);
+      else if (g_matmul_dtype == 1) X3_LAUNCH(2, 1, 1, grid, 256);
+      else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    }
+  } else {
     if (g_matmul_dtype == 2) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1, 3>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (g_matmul_dtype == 1) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, 2, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
   }
+#undef X3_LAUNCH
   VQ_LAUNCH_CHECK();
   if (g.ksplit > 1) {
     const long total = nblk * 128 * 128;
