@@ -16,14 +16,19 @@
 //   X5  wave specialisation: 4 MFMA waves + 4 staging waves (d4: fetches four steps ahead)
 //   X6  three LDS stages and the fragments double-buffered in registers (spills 340 VGPRs)
 //   X7  weights by LDS-DMA into a three-stage ring (no staging VGPRs, no ds_write for 2/3 of the bytes)
+//   X8  persistent workgroups (one per CU), the next tile's first two K steps fetched before the epilogue
 // Measured on MI355X (T = 7680, dil 64; fp32 MFMA loop of conv_loop.hip: 285 us): X1 241, X2 202-212,
-// X3 208-218, X5 225, X5d4 213, X2 stage-first 210 (205 with an MFMA/VALU interleave), X7 207-214 us.
+// X3 208-218, X5 225, X5d4 213, X2 stage-first 210 (205 with an MFMA/VALU interleave), X7 207-214,
+// X8 207-211 us.
 // Ablations of X2: no A loads 162-169, no B loads 147-160, neither 122-124, no fragment reads 180,
 // no split VALU 206, MFMA only 107 (at 1.84 GHz: 94 % of the clock-adjusted matrix pipe).
 // The chip is at its power limit: cycles per tile do not depend on how many workgroups run (80 k for
 // 32 K steps with 32 or with 960 workgroups, X3_GRID), the shader clock does (2.35 GHz -> 1.6-1.7 GHz),
 // and a schedule that saves cycles at low load (stage-first: -5.5 %) gives them back in clock at
-// full load.  What helps is moving fewer bytes per FLOP (the product's 256-column tiles).
+// full load.  At the power limit a stall is free -- an idle CU's share of the budget clocks the others
+// higher -- so hiding latency (X5, X6, X7, X8, deeper prefetch, more workgroups per CU) buys nothing;
+// what helps is spending less energy per FLOP: fewer bytes moved (the product's 256-column tiles, the
+// tap-interleaved K order that keeps the second tap's fetch in L1/L2).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 x3_loop.hip -o x3_loop ; run: ./x3_loop [dil] [T]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -313,6 +318,144 @@ __global__ __launch_bounds__(NT, 2) void conv_x2(const Args a) {
         const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         yb[(long)row * a.T + t0 + wn * 64 + j * 32 + li] = acc[i][j][r];
       }
+}
+
+
+// X8: X2 with persistent workgroups (one per CU) walking the tiles; the first two K steps of the NEXT
+// tile are fetched before the current tile's epilogue, whose stores then drain under the next loop.
+__global__ __launch_bounds__(NT, 2) void conv_x8(const Args a) {
+  constexpr int MODE = 0;
+  __shared__ uint4 As[2][3][2][BM];
+  __shared__ uint4 Bs[2][3][2][BN];
+  const long long c_beg = clock64(), w_beg = wall_clock64();
+  const int ntiles = a.B * a.ntile_n;
+  auto decode = [&](int vb, int& bb, int& tt) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    tt = (logical % a.ntile_n) * BN; bb = logical / a.ntile_n;
+  };
+  int b, t0; decode(blockIdx.x, b, t0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ksteps_tap = a.Cin / BK, nk = 2 * ksteps_tap;
+  const float* xb = a.x + (long)b * a.Cin * a.T;   // (t0, xb): the tile the fetch macros address
+  const int s_n = tid & 127, s_q = tid >> 7;
+  uint4 pa0 = make_uint4(tid, 1, 2, 3), pa1 = pa0, pa2 = pa0, qa0 = pa0, qa1 = pa0, qa2 = pa0;   // register sets P (even steps), Q (odd)
+  float pb0 = tid, pb1 = 1.f, pb2 = 2.f, pb3 = 3.f, qb0 = tid, qb1 = 1.f, qb2 = 2.f, qb3 = 3.f;
+  bool pok = true, qok = true;
+#undef X3_LOAD
+#undef X3_STORE
+#undef X3_LOAD_
+#undef X3_STORE_
+#undef P_SET
+#undef Q_SET
+#define X3_LOAD(...) X3_LOAD_(__VA_ARGS__)
+#define X3_STORE(...) X3_STORE_(__VA_ARGS__)
+#define X3_LOAD_(a0, a1, a2, b0, b1, b2, b3, ok, it_)                                   \
+  {                                                                                     \
+    const uint4* wp = a.wpk + (size_t)(it_) * (3 * 2 * BM) + tid;                       \
+    if (!(MODE & 1)) { a0 = wp[0]; a1 = wp[NT]; a2 = wp[2 * NT]; }                      \
+    const int tap = (it_) / ksteps_tap, c0 = ((it_) % ksteps_tap) * BK + 4 * s_q;       \
+    const int ts = t0 + s_n - (1 - tap) * a.dil;                                        \
+    const float* xs = (MODE & 32) ? a.x + (long)(4 * s_q) * a.T + s_n : (ts >= 0 ? xb + (long)c0 * a.T + ts : xb); \
+    if (MODE & 64) { const float4 v = *reinterpret_cast<const float4*>(xb + (long)(c0 >> 2) * a.T + ((t0 + 4 * s_n) & ~3)); b0 = v.x; b1 = v.y; b2 = v.z; b3 = v.w; } \
+    else if (!(MODE & 2)) { b0 = xs[0]; b1 = xs[(long)a.T]; b2 = xs[2L * a.T]; b3 = xs[3L * a.T]; } \
+    ok = ts >= 0;                                                                       \
+  }
+#define X3_STORE_(a0, a1, a2, b0, b1, b2, b3, ok, buf)                                   \
+  {                                                                                     \
+    uint4* ad = &As[buf][0][0][0];                                                      \
+    ad[tid] = a0; ad[NT + tid] = a1; ad[2 * NT + tid] = a2;                             \
+    unsigned h0, m0, l0, h1, m1, l1;                                                    \
+    if (MODE & 4) {                                                                     \
+      h0 = m0 = l0 = __builtin_bit_cast(unsigned, b0) ^ __builtin_bit_cast(unsigned, b1); \
+      h1 = m1 = l1 = __builtin_bit_cast(unsigned, b2) ^ __builtin_bit_cast(unsigned, b3); \
+    } else {                                                                            \
+      split3(ok ? b0 : 0.f, ok ? b1 : 0.f, h0, m0, l0);                                 \
+      split3(ok ? b2 : 0.f, ok ? b3 : 0.f, h1, m1, l1);                                 \
+    }                                                                                   \
+    uint2* bd = reinterpret_cast<uint2*>(&Bs[buf][0][s_q >> 1][s_n]) + (s_q & 1);       \
+    bd[0 * 2 * 2 * BN] = make_uint2(h0, h1);                                            \
+    bd[1 * 2 * 2 * BN] = make_uint2(m0, m1);                                            \
+    bd[2 * 2 * 2 * BN] = make_uint2(l0, l1);                                            \
+  }
+#define P_SET pa0, pa1, pa2, pb0, pb1, pb2, pb3, pok
+#define Q_SET qa0, qa1, qa2, qb0, qb1, qb2, qb3, qok
+  auto mma = [&](auto curc) {
+    constexpr int cur = decltype(curc)::value;
+    bf16x8 af[2][3], bf[2][3];
+    if (MODE & 16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { af[i][p] = __builtin_bit_cast(bf16x8, pa0); bf[i][p] = __builtin_bit_cast(bf16x8, qa0); }
+    } else
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  X3_LOAD(P_SET, 0);
+  X3_LOAD(Q_SET, 1);
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int cb = b, ct0 = t0;                      // the tile being computed
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    X3_STORE(P_SET, 0);
+    __syncthreads();
+    for (int it = 0; it < nk; it += 2) {
+      X3_LOAD(P_SET, min(it + 2, nk - 2));
+      mma(I0{});
+      X3_STORE(Q_SET, 1);
+      __syncthreads();
+      X3_LOAD(Q_SET, min(it + 3, nk - 1));
+      mma(I1{});
+      if (it + 2 < nk) X3_STORE(P_SET, 0);
+      __syncthreads();
+    }
+    // the next tile's first two steps travel while this tile's results are stored
+    if (vb + (int)gridDim.x < ntiles) {
+      decode(vb + gridDim.x, b, t0);
+      xb = a.x + (long)b * a.Cin * a.T;
+    }
+    X3_LOAD(P_SET, 0);
+    X3_LOAD(Q_SET, 1);
+    float* yb = a.y + (long)cb * BM * a.T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          yb[(long)row * a.T + ct0 + wn * 64 + j * 32 + li] = acc[i][j][r];
+        }
+  }
+  if (threadIdx.x == 0) { a.clk[2 * blockIdx.x] = clock64() - c_beg; a.clk[2 * blockIdx.x + 1] = wall_clock64() - w_beg; }
 }
 
 // X3: 4-wave workgroups (one wave per SIMD), 256 x 128 tile, every wave 64 rows x all 128 columns
@@ -829,7 +972,10 @@ int main(int argc, char** argv) {
            worst < 2e-6 ? "ok" : "WRONG");
   };
   int nthreads = NT;
+  int launch_grid = 0;         // 0: one workgroup per tile; else a persistent grid of this many workgroups
   auto run = [&](const char* name, void (*kern)(const Args)) {
+    const int grid_tiles = grid;
+    const int grid = launch_grid ? launch_grid : grid_tiles;
     CHECK(hipMemset(dy, 0, hy.size() * 4));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), 0, 0, a);
     CHECK(hipDeviceSynchronize());
@@ -844,11 +990,12 @@ int main(int argc, char** argv) {
     double cyc = 0, tick = 0;
     for (int i = 0; i < grid; ++i) { cyc += hc[2 * i]; tick += hc[2 * i + 1]; }
     printf("%-6s %.1f us  %.1f TFLOP/s (fp32-equivalent)   main loop of a block: %.1f us at %.0f MHz\n", name, 1e3 * ms / reps,
-           flop * grid / full_grid / (ms / reps * 1e-3) / 1e12, tick / grid / 100.0, tick > 0 ? cyc / tick * 100.0 : 0.0);
+           flop * grid_tiles / full_grid / (ms / reps * 1e-3) / 1e12, tick / grid / 100.0, tick > 0 ? cyc / tick * 100.0 : 0.0);
   };
   run("X1", conv_x1<0>);
   run("X2", conv_x2<0>);
   run("X7", conv_x7);
+  launch_grid = 256; run("X8", conv_x8); launch_grid = 0;
   run("X5", conv_x5<0>);
   run("X5d4", conv_x5<1>);
   nthreads = 256;
