@@ -964,6 +964,175 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 }
 
 // ---------------------------------------------------------------------------
+// lin128_stream_kernel -- the K = 128 -> M = 256 1x1 projection with residual add (ResidualBlock's
+// `res` conv, modules.py:50-52; 19 launches per configs[1] step) as a STREAMING kernel.
+//
+// The shape is HBM-bound (315 MB per launch against 8 GFLOP), and the tiled GEMM kernel ran it at
+// 2.4 TB/s: eight K steps are too short a loop to reach a steady state, and with one 98 KB workgroup
+// per CU nothing overlapped a tile's 0.5 MB read-modify-write epilogue.  Here:
+//   * one persistent 8-wave workgroup per CU walks 256 x NC column tiles;
+//   * the WHOLE weight matrix lives in registers for the life of the workgroup: wave w owns rows
+//     32w..32w+31, i.e. the A fragments of all 8 K steps (8 x NP 16-byte words per lane, read once from
+//     the packed slab) -- no weight traffic, no A staging, no A LDS reads per tile;
+//   * memory-level parallelism comes from registers, a whole tile ahead: the z tile (128 x NC fp32) of
+//     tile i+2 is in flight while tile i+1 is multiplied; tile i+1 is split and written to the other LDS
+//     buffer right behind tile i's MFMAs; the residual operands of tile i+1 are requested before tile
+//     i's MFMAs; tile i's stores drain behind tile i+1's MFMAs.  One barrier per tile, every wait a
+//     counted vmcnt.
+// Products, K order and the epilogue's (acc + bias) + x are those of conv_gemm_x3_kernel, so the
+// result is the same to the last bit whichever kernel the launch picks.
+// ---------------------------------------------------------------------------
+struct Lin128Args {
+  const uint4* w; int ldw;                 // packed slab (pack_kernel, modes 1 / 2), one tap, K = 128
+  const float* z; long z_bstride;          // (B, 128, T)
+  const float* add; long add_bstride;      // (B, 256, T) residual, HAS_ADD only
+  float* y; long y_bstride;                // (B, 256, T)
+  const float* bias;                       // 256 or null
+  int T, tiles_per_b, ntiles;
+};
+
+template <int NP, int NC, bool HAS_ADD>
+__global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args a) {
+  constexpr int KS = 8, NCB = NC / 32;
+  constexpr int CPC = NC / 16;                     // columns per staging thread: 16 column groups x 32 channel quads = 512 threads
+  constexpr int STEPW = NP * 2 * NC;               // 16-byte words per K step of the B image
+  __shared__ uint4 Bs[2][KS * STEPW];              // [buf][s][piece][k-half][col]
+  __shared__ float4 bias_s[64];                    // 256 biases
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+  const int T = a.T;
+
+  // ---- the weights: this wave's 32 rows x 128 k, as MFMA A fragments, for the whole launch ----
+  uint4 af[KS][NP];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) af[s][p] = a.w[((long)(s * NP + p) * 2 + lk) * a.ldw + 32 * wave + li];
+  if (tid < 256) reinterpret_cast<float*>(bias_s)[tid] = a.bias ? a.bias[tid] : 0.f;
+
+  // ---- staging role: CPC consecutive columns x 4 consecutive channels per thread ----
+  const int cg = tid & 15, kq = tid >> 4;
+  const int k0 = 4 * kq;
+  // word (s, piece, k-half, col) holds k = 16 s + 8 half .. + 7; this thread fills 8-byte half `sub` of it
+  const int st_word = ((k0 >> 4) * NP * 2 + ((k0 >> 3) & 1)) * NC + CPC * cg;
+  const int st_sub = (k0 >> 2) & 1;
+  float zr[4][CPC];
+  const int last = a.ntiles - 1;
+#define L128_FETCH(TILE)                                                                       \
+  {                                                                                            \
+    const int tl_ = min((TILE), last);          /* past the end: re-read the last tile, unused */ \
+    const int b_ = tl_ / a.tiles_per_b, t_ = (tl_ - b_ * a.tiles_per_b) * NC;                  \
+    const float* p_ = a.z + (long)b_ * a.z_bstride + (long)k0 * T + t_ + CPC * cg;             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      if constexpr (CPC == 4) {                                                                \
+        const float4 v_ = *reinterpret_cast<const float4*>(p_ + (long)j * T);                  \
+        zr[j][0] = v_.x; zr[j][1] = v_.y; zr[j][2] = v_.z; zr[j][3] = v_.w;                    \
+      } else {                                                                                 \
+        const float2 v_ = *reinterpret_cast<const float2*>(p_ + (long)j * T);                  \
+        zr[j][0] = v_.x; zr[j][1] = v_.y;                                                      \
+      }                                                                                        \
+    }                                                                                          \
+  }
+#define L128_STAGE(BUF)                                                                        \
+  {                                                                                            \
+    uint4* base_ = &Bs[BUF][st_word];                                                          \
+    _Pragma("unroll") for (int c = 0; c < CPC; ++c) {                                          \
+      uint2* d_ = reinterpret_cast<uint2*>(base_ + c) + st_sub;                                \
+      if constexpr (NP == 3) {                                                                 \
+        unsigned h0, m0, l0, h1, m1, l1;                                                       \
+        split3(zr[0][c], zr[1][c], h0, m0, l0);                                                \
+        split3(zr[2][c], zr[3][c], h1, m1, l1);                                                \
+        d_[0] = make_uint2(h0, h1);                                                            \
+        d_[2 * (2 * NC)] = make_uint2(m0, m1);                                                 \
+        d_[2 * (4 * NC)] = make_uint2(l0, l1);                                                 \
+      } else {                                                                                 \
+        d_[0] = make_uint2(pack_bf16x2(zr[0][c], zr[1][c]), pack_bf16x2(zr[2][c], zr[3][c]));  \
+      }                                                                                        \
+    }                                                                                          \
+  }
+  // residual operands of a tile, in the accumulator layout (requested a whole tile ahead)
+  const unsigned voff = 4u * (unsigned)(4 * lk * T + li);
+#define L128_XLOAD(XV, TILE)                                                                   \
+  if constexpr (HAS_ADD) {                                                                     \
+    const int tl_ = min((TILE), last);                                                         \
+    const int b_ = tl_ / a.tiles_per_b, t_ = (tl_ - b_ * a.tiles_per_b) * NC;                  \
+    const rsrc_t rx_ = make_rsrc(a.add + (long)b_ * a.add_bstride);                           \
+    const unsigned sb_ = 4u * (unsigned)(32 * wave * T + t_);                                  \
+    _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+        XV[cb][r] = buf_ld(rx_, voff, sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T)); \
+  }
+  // one tile: MFMAs on LDS buffer CUR, next tile's z -> the other buffer, epilogue with XCUR while
+  // XNXT (the next tile's residual) and the z tile after the next travel
+#define L128_TILE(CUR, XCUR, XNXT)                                                             \
+  {                                                                                            \
+    const int b = tile / a.tiles_per_b, t0 = (tile - b * a.tiles_per_b) * NC;                  \
+    L128_XLOAD(XNXT, tile + stride);                                                           \
+    f32x16 acc[NCB];                                                                           \
+    _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;                         \
+    const uint4* bb = &Bs[CUR][lk * NC + li];                                                  \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                           \
+      _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) {                                     \
+        bf16x8 bq[NP];                                                                         \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) bq[p] = __builtin_bit_cast(bf16x8, bb[s * STEPW + p * 2 * NC + cb * 32]); \
+        f32x16 c = acc[cb];                                                                    \
+        if constexpr (NP == 3) {                               /* small products first (as conv_gemm_x3_kernel) */ \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][2]), bq[0], c, 0, 0, 0); \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[2], c, 0, 0, 0); \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][1]), bq[1], c, 0, 0, 0); \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][1]), bq[0], c, 0, 0, 0); \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[1], c, 0, 0, 0); \
+        }                                                                                      \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[0], c, 0, 0, 0); \
+        acc[cb] = c;                                                                           \
+      }                                                                                        \
+    }                                                                                          \
+    L128_STAGE(CUR ^ 1);                                                                       \
+    {                                                                                          \
+      const rsrc_t ry = make_rsrc(a.y + (long)b * a.y_bstride);                                \
+      const unsigned sbase = 4u * (unsigned)(32 * wave * T + t0);                              \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+        const float4 bq4 = bias_s[8 * wave + 2 * q + lk];         /* rows 32w + 8q + 4lk .. + 3 */ \
+        const float bv[4] = {bq4.x, bq4.y, bq4.z, bq4.w};                                      \
+        _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                     \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
+            const int r = 4 * q + j;                                                           \
+            float v = acc[cb][r] + bv[j];                                                      \
+            if constexpr (HAS_ADD) v += XCUR[cb][r];                                           \
+            buf_st(v, ry, voff, sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T));           \
+          }                                                                                    \
+      }                                                                                        \
+    }                                                                                          \
+    /* the tile after the next goes in flight behind this tile's stores (VMEM retires in order: the  \
+       next STAGE's wait also covers these stores, which have had a whole MFMA phase to drain) */   \
+    L128_FETCH(tile + 2 * stride);                                                             \
+    __syncthreads();                                                                           \
+  }
+
+  int tile = blockIdx.x;
+  const int stride = gridDim.x;
+  if (tile >= a.ntiles) return;
+  float xa[NCB][16], xb[NCB][16];
+  L128_FETCH(tile);
+  L128_XLOAD(xa, tile);
+  L128_STAGE(0);
+  __syncthreads();
+  L128_FETCH(tile + stride);
+  while (true) {
+    L128_TILE(0, xa, xb);
+    tile += stride;
+    if (tile >= a.ntiles) break;
+    L128_TILE(1, xb, xa);
+    tile += stride;
+    if (tile >= a.ntiles) break;
+  }
+#undef L128_FETCH
+#undef L128_STAGE
+#undef L128_XLOAD
+#undef L128_TILE
+}
+
+// ---------------------------------------------------------------------------
 // weight packing: dst[(tap*Rpad + k)*ldw + m_off + mp] = src[k*s_k + m*s_m + tap*s_tap]
 // where m = unpermute(mp) (gate interleave) ; zero for k >= R or m >= Cm.
 // ---------------------------------------------------------------------------
@@ -1910,6 +2079,41 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   }
   const long grid = nblk * g.ksplit;
   ProfScope ps(tag, st);
+  // the K = 128 -> 256-row projection with residual add (the ResidualBlock `res` conv): streaming kernel
+  if constexpr (EPI == EPI_LINEAR) {
+    static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;   // 0: off; 32 / 64: column tile
+    const Seg& s0 = g.seg[0];
+    if (lin128 && g_matmul_dtype != 0 && g.nseg == 1 && g.M == 256 && s0.cin == 128 && g.out[1].y == nullptr &&
+        !g.out[0].relu && !g.out[0].accumulate && s0.tmul == 1 && s0.tdiv == 1 && s0.toff == 0 && s0.Tin == g.Tout &&
+        s0.x_cstride == g.Tout && g.Tout % 64 == 0 && s0.vec && s0.ldw >= 256 && g.lerp.P == nullptr &&
+        g.skip_flag == nullptr && g.ksplit == 1) {
+      Lin128Args la;
+      la.w = reinterpret_cast<const uint4*>(s0.w); la.ldw = s0.ldw;
+      la.z = s0.x; la.z_bstride = s0.x_bstride;
+      la.add = g.out[0].add; la.add_bstride = g.out[0].add_bstride;
+      la.y = g.out[0].y; la.y_bstride = g.out[0].y_bstride;
+      la.bias = g.out[0].bias;
+      la.T = g.Tout;
+      const int nc = lin128 == 32 ? 32 : 64;
+      la.tiles_per_b = g.Tout / nc; la.ntiles = la.tiles_per_b * g.B;
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+      }
+      const unsigned nwg = (unsigned)(la.ntiles < n_cu ? la.ntiles : n_cu);
+#define L128_LAUNCH(NPv, NCv)                                                                                        \
+      do {                                                                                                           \
+        if (la.add) hipLaunchKernelGGL((lin128_stream_kernel<NPv, NCv, true>), dim3(nwg), dim3(512), 0, st, la);     \
+        else hipLaunchKernelGGL((lin128_stream_kernel<NPv, NCv, false>), dim3(nwg), dim3(512), 0, st, la);           \
+      } while (0)
+      if (g_matmul_dtype == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
+      else { if (nc == 32) L128_LAUNCH(1, 32); else L128_LAUNCH(1, 64); }
+#undef L128_LAUNCH
+      VQ_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // 256-column tiles when they still give every CU a workgroup (measured at configs[1]: dilated conv
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
   static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;

@@ -101,112 +101,208 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, long gy_bstrid
   }
 }
 
-// one workgroup per (b,c) row: the weighted row (g*w0 | g*w1) is staged through LDS with
-// coalesced loads, then thread (v, part) sums one contributing range with four
-// independent fp64 accumulators in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(
+// one workgroup per (b,c) row: the weighted row (g*w0 | g*w1) is staged through LDS with coalesced
+// 16-B loads, then every output v = sum_{t in R1(v)} g*w1 + sum_{t in R0(v)} g*w0 (two adjacent ranges of
+// ~Tout/Tin elements) is summed in float64 by a FIXED-ORDER tree over eight lanes: four lanes per range,
+// lane q taking elements q, q+4, ... in ascending order with two interleaved accumulators, combined as
+// ((q0+q1)+(q2+q3)) per range and then range0 + range1 by three butterfly shuffles -- deterministic, and
+// Tin*8 = 960 short chains on 1024 threads instead of round 2's 240 chains of ~64 on 256 threads (2 waves
+// per SIMD could not hide the LDS latency of a serial chain: 2.7 TB/s).  Workgroups are persistent, two
+// per CU (64 VGPRs), the NEXT row's loads are in flight while the current row is summed.  (The decoder's
+// 64x pull-back takes upsample_bwd_seg_kernel below; this form serves the small ratios.)
+constexpr int UPB_NT = 1024, UPB_KV = 2;      // threads, float4 per thread and pass
+__global__ __launch_bounds__(UPB_NT, 8) void upsample_bwd_rows_kernel(
     const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
     const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
     const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
     const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride) {
-  extern __shared__ float sm[];             // [2][Tpad] products, index t + (t >> 5)
-  const int Tpad = Tout + (Tout >> 5) + 1;
+  // [2][Tpad] products at index t + (t >> 3): one pad word per 8 elements makes both access patterns
+  // conflict-free -- the staging writes (lane stride 4 t -> 4.5 words) and the range sums (the four lanes
+  // of a range read 4 consecutive t, the ranges of a wave sit ~64.5 t = 72.6 words apart).
+  extern __shared__ float sm[];
+  const int Tpad = Tout + (Tout >> 3) + 8;
   float* r0 = sm;
   float* r1 = sm + Tpad;
-  double* ps = (double*)(sm + 2 * Tpad + (Tpad & 1));   // [2][Tin] partial sums
   const int rows = B * C;
+  const int tid = threadIdx.x;
   const bool vec = (Tout % 4 == 0) && (gy_bstride % 4 == 0) && (((uintptr_t)gy) % 16 == 0) &&
                    (((uintptr_t)w0) % 16 == 0) && (((uintptr_t)w1) % 16 == 0);
   const int n4 = Tout >> 2;
-  // Pipelined form (a whole row fits one pass of 8 float4 per thread): the workgroups are
-  // persistent (2 per CU) and the NEXT row's loads are in flight while the current row is summed,
-  // so a row costs max(load, sum) instead of load + sum + a workgroup launch.
-  const bool pipe = vec && n4 <= 256 * 8;
-  float4 v[8];
+  const bool pipe = vec && n4 <= UPB_NT * UPB_KV;       // a whole row in one pass of UPB_KV float4 per thread
+  float4 v[UPB_KV];
   auto fetch = [&](int r) {
     const int b = r / C, c = r % C;
     const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int q = k * 256 + threadIdx.x;
+    for (int k = 0; k < UPB_KV; ++k) {
+      const int q = k * UPB_NT + tid;
       v[k] = q < n4 ? reinterpret_cast<const float4*>(g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto stage = [&]() {          // products of the fetched row -> LDS (same roundings as the scalar form)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int q = k * 256 + threadIdx.x;
-      if (q < n4) {
-        const int t = q << 2;
-        const float4 a = reinterpret_cast<const float4*>(w0)[q];
-        const float4 bq = reinterpret_cast<const float4*>(w1)[q];
-        const int o = t + (t >> 5);          // 4 consecutive t never straddle a 32-block
-        r0[o] = __fmul_rn(v[k].x, a.x); r0[o + 1] = __fmul_rn(v[k].y, a.y);
-        r0[o + 2] = __fmul_rn(v[k].z, a.z); r0[o + 3] = __fmul_rn(v[k].w, a.w);
-        r1[o] = __fmul_rn(v[k].x, bq.x); r1[o + 1] = __fmul_rn(v[k].y, bq.y);
-        r1[o + 2] = __fmul_rn(v[k].z, bq.z); r1[o + 3] = __fmul_rn(v[k].w, bq.w);
-      }
-    }
+  auto stage4 = [&](int q, const float4 gv, const float4 a, const float4 bq) {   // products of 4 consecutive t -> LDS
+    const int t = q << 2;
+    const int o = t + (t >> 3);                  // 4 consecutive t never straddle an 8-block
+    r0[o] = __fmul_rn(gv.x, a.x); r0[o + 1] = __fmul_rn(gv.y, a.y);
+    r0[o + 2] = __fmul_rn(gv.z, a.z); r0[o + 3] = __fmul_rn(gv.w, a.w);
+    r1[o] = __fmul_rn(gv.x, bq.x); r1[o + 1] = __fmul_rn(gv.y, bq.y);
+    r1[o + 2] = __fmul_rn(gv.z, bq.z); r1[o + 3] = __fmul_rn(gv.w, bq.w);
   };
+  // this thread's share of the sums: output (tid >> 3) [+ UPB_NT/8 per pass], range (tid >> 2) & 1
+  // (0: the w1 range, which comes first in t; 1: the w0 range), lane (tid & 3) of the range
+  const int npass = (Tin * 8 + UPB_NT - 1) / UPB_NT;
   if (pipe && blockIdx.x < rows) fetch(blockIdx.x);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int b = r / C, c = r % C;
     const float* g = gy + (long)b * gy_bstride + (long)c * Tout;
     __syncthreads();
     if (pipe) {
-      stage();
-    } else if (vec) {     // 16-B loads, eight in flight per thread before the first LDS write
-      for (int base = 0; base < n4; base += 256 * 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int q = base + k * 256 + threadIdx.x;
-          v[k] = q < n4 ? reinterpret_cast<const float4*>(g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int q = base + k * 256 + threadIdx.x;
-          if (q < n4) {
-            const int t = q << 2;
-            const float4 a = reinterpret_cast<const float4*>(w0)[q];
-            const float4 bq = reinterpret_cast<const float4*>(w1)[q];
-            const int o = t + (t >> 5);          // 4 consecutive t never straddle a 32-block
-            r0[o] = __fmul_rn(v[k].x, a.x); r0[o + 1] = __fmul_rn(v[k].y, a.y);
-            r0[o + 2] = __fmul_rn(v[k].z, a.z); r0[o + 3] = __fmul_rn(v[k].w, a.w);
-            r1[o] = __fmul_rn(v[k].x, bq.x); r1[o + 1] = __fmul_rn(v[k].y, bq.y);
-            r1[o + 2] = __fmul_rn(v[k].z, bq.z); r1[o + 3] = __fmul_rn(v[k].w, bq.w);
-          }
-        }
+      for (int k = 0; k < UPB_KV; ++k) {
+        const int q = k * UPB_NT + tid;
+        if (q < n4) stage4(q, v[k], reinterpret_cast<const float4*>(w0)[q], reinterpret_cast<const float4*>(w1)[q]);
       }
+    } else if (vec) {
+      for (int q = tid; q < n4; q += UPB_NT)
+        stage4(q, reinterpret_cast<const float4*>(g)[q], reinterpret_cast<const float4*>(w0)[q], reinterpret_cast<const float4*>(w1)[q]);
     } else {
-      for (int t = threadIdx.x; t < Tout; t += 256) {
+      for (int t = tid; t < Tout; t += UPB_NT) {
         const float vv = g[t];
-        r0[t + (t >> 5)] = __fmul_rn(vv, w0[t]);
-        r1[t + (t >> 5)] = __fmul_rn(vv, w1[t]);
+        r0[t + (t >> 3)] = __fmul_rn(vv, w0[t]);
+        r1[t + (t >> 3)] = __fmul_rn(vv, w1[t]);
       }
     }
     __syncthreads();
     if (pipe && r + (int)gridDim.x < rows) fetch(r + gridDim.x);      // in flight during the sums below
-    for (int i = threadIdx.x; i < 2 * Tin; i += 256) {
-      const int part = i >= Tin ? 1 : 0;
-      const int vi = part ? i - Tin : i;
-      const float* rr = part ? r1 : r0;
-      const int lo = part ? lo1[vi] : lo0[vi];
-      const int hi = part ? hi1[vi] : hi0[vi];
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int t = lo;
-      for (; t + 3 < hi; t += 4) {
-        a0 += (double)rr[t + (t >> 5)];
-        a1 += (double)rr[t + 1 + ((t + 1) >> 5)];
-        a2 += (double)rr[t + 2 + ((t + 2) >> 5)];
-        a3 += (double)rr[t + 3 + ((t + 3) >> 5)];
+    for (int p = 0; p < npass; ++p) {          // wave-uniform trip count: the shuffles need all eight lanes
+      const int vi = (p * UPB_NT + tid) >> 3, part0 = (tid >> 2) & 1, qt = tid & 3;
+      const bool ok = vi < Tin;
+      const int vc = ok ? vi : 0;
+      const float* rr = part0 ? r0 : r1;
+      const int lo = part0 ? lo0[vc] : lo1[vc];
+      const int hi = ok ? (part0 ? hi0[vc] : hi1[vc]) : lo;
+      int t = lo + qt;
+      double a0 = 0.0, a1 = 0.0;
+      for (; t + 4 < hi; t += 8) {
+        a0 += (double)rr[t + (t >> 3)];
+        a1 += (double)rr[t + 4 + ((t + 4) >> 3)];
       }
-      for (; t < hi; ++t) a0 += (double)rr[t + (t >> 5)];
-      ps[part * Tin + vi] = (a0 + a1) + (a2 + a3);
+      if (t < hi) a0 += (double)rr[t + (t >> 3)];
+      double sacc = a0 + a1;
+      sacc += __shfl_xor(sacc, 1, 64);       // (q0+q1) | (q2+q3)
+      sacc += __shfl_xor(sacc, 2, 64);       // (q0+q1)+(q2+q3): fp64 addition commutes, all four lanes agree
+      sacc += __shfl_xor(sacc, 4, 64);       // w1-range sum + w0-range sum
+      if (ok && (tid & 7) == 0) gx[(long)b * gx_bstride + (long)c * Tin + vi] = (float)sacc;
     }
-    __syncthreads();
-    for (int vi = threadIdx.x; vi < Tin; vi += 256)
-      gx[(long)b * gx_bstride + (long)c * Tin + vi] = (float)(ps[vi] + ps[Tin + vi]);
   }
+}
+
+// The decoder's latent pull-back (Tout >= 8 Tin, e.g. 7680 -> 120; 21 launches per configs[1] step) without
+// staging the row: every thread keeps its 4 consecutive t (one 16-B load, next row prefetched) and its
+// interpolation weights in registers, multiplies, and reduces its four products to at most two partial
+// sums per weight -- "lo" (the elements that share the source index v0 of its first element) and "hi"
+// (the rest: the next source index; nonzero for the ~Tin threads that straddle a boundary).  The
+// partials go to LDS (16 B per thread instead of 32 B per 4 elements), and output v is the sum of the
+// ~Tout/(4 Tin) lo partials of its w0 range, the one hi partial below it, and the same for the w1
+// range -- eight lanes per v (four per range, lane j taking partials j, j+4, ... in ascending order),
+// combined by three butterfly shuffles: a FIXED-ORDER fp32 tree (4 -> ~17 -> 2), deterministic, within a few
+// ulp of the float64 sum.  LDS is double-buffered by row parity: one barrier per row.  ~30
+// instructions per thread and row against ~150 for the LDS-staged float64 form above.
+constexpr int UPS_NT = 1024, UPS_PITCH = 2048 + 128;
+__global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
+    const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
+    const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
+    const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
+    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride) {
+  __shared__ float S[2][4][UPS_PITCH];       // [row parity][w0 lo, w0 hi, w1 lo, w1 hi][q + (q >> 4)]
+  const int tid = threadIdx.x, n4 = Tout >> 2, rows = B * C;
+  // phase-1 constants: weights and the lo / hi split point of this thread's column groups q = tid, tid + 1024
+  float4 wa[2], wb[2];
+  int ks[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = k * UPS_NT + tid;
+    const bool ok = q < n4;
+    wa[k] = ok ? reinterpret_cast<const float4*>(w0)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wb[k] = ok ? reinterpret_cast<const float4*>(w1)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // source index of element 4q: the v whose w0 range [lo0[v], hi0[v]) holds it (the ranges tile [0, Tout)
+    // in order); floor(t (Tin-1) / (Tout-1)) is right to within one -- three independent table reads
+    // settle it (a binary search here was seven dependent L2 round trips before the first row)
+    const int t = ok ? 4 * q : 0;
+    const int e = min(max((int)(((long)t * (Tin - 1)) / (Tout - 1)), 1), Tin - 2);
+    const int hm = hi0[e - 1], h0 = hi0[e], hp = hi0[min(e + 1, Tin - 1)];
+    const int hend = t < hm ? hm : (t < h0 ? h0 : hp);
+    ks[k] = max(1, min(4, hend - t));
+  }
+  // phase-2 constants: output vi = tid >> 3 (+ 128 per pass), range (tid >> 2) & 1, lane tid & 3
+  const int npass = (Tin * 8 + UPS_NT - 1) / UPS_NT;
+  const int part = (tid >> 2) & 1, j4 = tid & 3;
+  // the loads of rows r + stride and r + 2 stride are in flight while row r is reduced (rotating register
+  // sets; with the row loop unrolled by two instead the kernel needs > 64 registers, i.e. one workgroup
+  // per CU: measured 53 us against 34)
+  float4 va[2], vb[2];
+#define UPS_FETCH(V, R)                                                                        \
+  {                                                                                            \
+    const int rr_ = min((R), rows - 1);           /* past the end: re-read the last row, unused */ \
+    const float* g_ = gy + (long)(rr_ / C) * gy_bstride + (long)(rr_ % C) * Tout;              \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
+      const int q = k * UPS_NT + tid;                                                          \
+      V[k] = q < n4 ? reinterpret_cast<const float4*>(g_)[q] : make_float4(0.f, 0.f, 0.f, 0.f); \
+    }                                                                                          \
+  }
+#define UPS_ROW(V, PAR)                                                                        \
+  {                                                                                            \
+    const int b = r / C, c = r % C;                                                            \
+    float (*Sp)[UPS_PITCH] = S[PAR];                                                           \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
+      const int q = k * UPS_NT + tid;                                                          \
+      if (q < n4) {                                                                            \
+        const float p0[4] = {__fmul_rn(V[k].x, wa[k].x), __fmul_rn(V[k].y, wa[k].y), __fmul_rn(V[k].z, wa[k].z), __fmul_rn(V[k].w, wa[k].w)}; \
+        const float p1[4] = {__fmul_rn(V[k].x, wb[k].x), __fmul_rn(V[k].y, wb[k].y), __fmul_rn(V[k].z, wb[k].z), __fmul_rn(V[k].w, wb[k].w)}; \
+        float l0, h0 = 0.f, l1, h1 = 0.f;                                                      \
+        if (ks[k] >= 4) {                                                                      \
+          l0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);                                              \
+          l1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);                                              \
+        } else {                 /* the group straddles a source boundary after ks elements (1..3) */ \
+          l0 = p0[0]; l1 = p1[0];                                                              \
+          if (ks[k] >= 2) { l0 += p0[1]; l1 += p1[1]; } else { h0 = p0[1]; h1 = p1[1]; }       \
+          if (ks[k] >= 3) { l0 += p0[2]; l1 += p1[2]; } else { h0 += p0[2]; h1 += p1[2]; }     \
+          h0 += p0[3]; h1 += p1[3];                                                            \
+        }                                                                                      \
+        const int o = q + (q >> 4);                                                            \
+        Sp[0][o] = l0; Sp[1][o] = h0; Sp[2][o] = l1; Sp[3][o] = h1;                            \
+      }                                                                                        \
+    }                                                                                          \
+    __syncthreads();                                                                           \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) V[k] = vb[k];      /* the row fetched one row ago */ \
+    UPS_FETCH(vb, r + 2 * stride);                /* two rows in flight */ \
+    for (int p = 0; p < npass; ++p) {   /* wave-uniform trip count: the shuffles need all eight lanes */ \
+      const int vi = (p * UPS_NT + tid) >> 3;                                                  \
+      const bool ok = vi < Tin;                                                                \
+      const int vc = ok ? vi : 0;                                                              \
+      const int tl = part ? lo1[vc] : lo0[vc];                                                 \
+      const int th = ok ? (part ? hi1[vc] : hi0[vc]) : tl;                                     \
+      const float* Sl = Sp[2 * part];                                                          \
+      const float* Sh = Sp[2 * part + 1];                                                      \
+      float acc = 0.f;                                                                         \
+      const int qe = (th + 3) >> 2;                                                            \
+      for (int q = ((tl + 3) >> 2) + j4; q < qe; q += 4) acc += Sl[q + (q >> 4)];              \
+      if (j4 == 0 && th > tl && (tl & 3)) { const int q = tl >> 2; acc += Sh[q + (q >> 4)]; }  \
+      acc += __shfl_xor(acc, 1, 64);                                                           \
+      acc += __shfl_xor(acc, 2, 64);                                                           \
+      acc += __shfl_xor(acc, 4, 64);              /* w1-range sum + w0-range sum */            \
+      if (ok && (tid & 7) == 0) gx[(long)b * gx_bstride + (long)c * Tin + vi] = acc;           \
+    }                                                                                          \
+    /* no second barrier: the next row writes the other parity, and nobody can reach the row after  \
+       that (which overwrites this parity) before every thread has passed the next row's barrier */ \
+  }
+  const int stride = gridDim.x;
+  int r = blockIdx.x;
+  if (r >= rows) return;
+  UPS_FETCH(va, r);
+  UPS_FETCH(vb, r + stride);
+  for (int par = 0; r < rows; r += stride, par ^= 1) UPS_ROW(va, par);
+#undef UPS_FETCH
+#undef UPS_ROW
 }
 
 // ---- speaker embedding broadcast -----------------------------------------
@@ -780,15 +876,24 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               long gx_bstride, vqvae_stream_t s) {
   VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd: null pointer");
   const size_t n = (size_t)B * C * Tin;
-  const size_t tpad = (size_t)Tout + Tout / 32 + 1;
-  const size_t lds = (2 * tpad + 2) * sizeof(float) + 2 * (size_t)Tin * sizeof(double);
-  if (lds <= 96 * 1024) {
+  static const int seg_on = getenv("VQVAE_UPS_SEG") ? atoi(getenv("VQVAE_UPS_SEG")) : 1;
+  if (seg_on && Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 &&
+      ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0) {
+    int nb = B * C;
+    if (nb > 512) nb = 512;                      // persistent: 2 workgroups per CU
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+    VQ_LAUNCH_CHECK();
+    return 0;
+  }
+  const size_t tpad = (size_t)Tout + Tout / 8 + 8;
+  const size_t lds = (2 * tpad + 2) * sizeof(float);
+  if (lds <= 78 * 1024) {                      // two workgroups per CU
     int nb = B * C;
     if (nb > 8192) nb = 8192;
-    const bool pipe = (Tout % 4 == 0) && (Tout / 4 <= 256 * 8);
+    const bool pipe = (Tout % 4 == 0) && (Tout / 4 <= UPB_NT * UPB_KV);
     if (pipe && nb > 512) nb = 512;            // persistent: 2 workgroups per CU, next row prefetched
     VQ_CHECK_HIP(hipFuncSetAttribute((const void*)upsample_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(nb), dim3(256), lds, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+    hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(nb), dim3(UPB_NT), lds, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   } else {
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   }

@@ -14,9 +14,14 @@
 //      queued for
 //   2. vq_exact_kernel -- all k codes re-evaluated in the reference's operation
 //      order (contraction off), ties to the lowest index.  Typically 1-3 % of rows.
-// The band: both forms are within (2d+3)*u*2S of the real-number distance, with
-// u = 2^-24 and S = |z|^2 + max_j |w_j|^2, so any code that can be the reference
-// argmin has dist' <= min dist' + 8(d+2)uS; we use 12(d+4)uS.
+// The band: the reference's sequential form and the fp32 expansion form are each within
+// E = (2d+3)*u*2S = (4d+6)uS of the real-number distance (u = 2^-24, S = |z|^2 + max_j |w_j|^2).
+// A row is CERTAIN only if no other code can win in the REFERENCE's arithmetic: with
+// ours_j = true_j - |z|^2 + e_j (|e_j| <= E_ours) and ref_j = true_j + r_j (|r_j| <= E_ref),
+// ours_j - ours_i1 > band implies ref_j - ref_i1 > band - 2 E_ours - 2 E_ref, so the band must
+// cover 2 (E_ours + E_ref) = (16d + 24) uS for the fp32 MFMA sweep: we use 16(d+4)uS.  (Round 2
+// used 12(d+4)uS, which covered 2 E_ours + E_ref only.)  The bf16-pipe sweep has a larger E_ours
+// and a wider band, see vq_mfma_x3_kernel.
 #include "common.h"
 
 namespace vq {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(64 * NW) void vq_mfma_kernel(
     float zn = 0.f;
     for (int c = 0; c < d; ++c) { const float v = Zs[c * NC + wave * 32 + li]; zn = fmaf(v, v, zn); }
     const float wmax = __int_as_float(*wmax_bits);
-    const float band = 12.f * (float)(d + 4) * 5.9604645e-8f * (zn + wmax);
+    const float band = 16.f * (float)(d + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {           // also catches NaN
       const int slot = atomicAdd(nflag, 1);
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void vq_mfma_reg_kernel(
   }
   if (lk == 0 && n < N) {
     const float wmax = __int_as_float(*wmax_bits);
-    const float band = 12.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
+    const float band = 16.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {
       const int slot = atomicAdd(nflag, 1);
@@ -226,8 +231,12 @@ __global__ __launch_bounds__(256, 2) void vq_mfma_reg_kernel(
 // Rounding band: each kept product is exact, the three dropped ones are < 2^-25 |ab|; an MFMA adds 16
 // exact products to its accumulator -- taken here as no better than 17 individually rounded
 // additions -- so a dot product is within (6d/16 * 17 + d/8) u |w||z| <= 3.3 d u S of the real
-// number (S = |z|^2 + max|w|^2 >= 2|w||z|) and dist' = |w|^2 - 2<w,z> within (6.6 d + d + 2) u S;
-// two such errors separate the reference's argmin from a competitor by < 15.2 (d + 1) u S: 16(d+4)uS.
+// number (S = |z|^2 + max|w|^2 >= 2|w||z|) and dist' = |w|^2 - 2<w,z> within E_ours = (7.6 d + 2) u S.
+// The reference's own sequential fp32 sum is within E_ref = (4 d + 6) u S of the real number, and a row
+// may skip the exact re-check only if no competitor can win in the REFERENCE's arithmetic: the band
+// must cover 2 (E_ours + E_ref) = (23.2 d + 16) u S -> 24(d+4)uS.  (Round 2 used 16(d+4)uS = 2 E_ours
+// only.)  The accumulation order inside the MFMA is not documented; the 17-roundings-per-MFMA model is
+// the pessimistic end (every product added with its own rounding), so the bound does not rest on it.
 using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
 __device__ __forceinline__ unsigned vq_pk(float lo, float hi) {
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   }
   if (lk == 0 && n < N) {
     const float wmax = __int_as_float(*wmax_bits);
-    const float band = 16.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
+    const float band = 24.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {
       const int slot = atomicAdd(nflag, 1);

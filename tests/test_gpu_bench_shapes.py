@@ -1,0 +1,164 @@
+"""The kernel INSTANTIATIONS bench.py measures, compared with the oracle directly.
+
+launch_gemm picks its tile shape from the launch size: the 256 x 256-column `conv_gemm_x3_kernel<...,
+NB = 2, ...>` (gate kernel, backward-data of the dilated conv) only runs when a launch has >= 256 such
+tiles, i.e. B >= 9 at T = 7680, and the streaming `lin128_stream_kernel` (the K = 128 residual
+projection) / `dilconv` window kernels are chosen from the channel counts of configs[1].  Every
+oracle-compared case of test_gpu_kernels.py has B <= 3, so until round 3 those instantiations were
+pinned only transitively (batch independence, shard sums).  Here: ResidualBlock.__call__
+(modules.py:30-56) and the ResidualNet chain (modules.py:89-96) at B = 16, T = 7680, 256 channels
+against oracle.resblock_fwd / resblock_bwd, and one whole configs[1] step (B = 16) against
+oracle.train_step (updaters.py:6-19)."""
+import numpy as np
+import pytest
+
+import helpers as H
+import vqvae_oracle as O
+from helpers import assert_close, assert_close_scaled, to4
+from test_gpu_kernels import _rb_params
+
+pytestmark = pytest.mark.gpu
+
+B, T = 16, 7680
+
+
+def _dev(gpu, a):
+    return gpu.to_device(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize('dil', [1, 512])
+def test_resblock_b16_vs_oracle(gpu, matmul_mode, dil):
+    """One ResidualBlock at the benchmarked launch shape (B = 16 -> 480 256 x 256 tiles: the NB = 2,
+    TAP2 gate and backward-data kernels), dilation 1 (both taps inside one tile's window) and 512
+    (taps two tiles apart), forward and backward, 1e-4."""
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualBlockFunction
+    rs = np.random.RandomState(100 + dil)
+    p = _rb_params(rs, 256, 256, 256, 192, 2)
+    x = rs.standard_normal((B, 256, T)).astype(np.float32)
+    c = rs.standard_normal((B, 192, T)).astype(np.float32)
+    res_ref, skip_ref, cache = O.resblock_fwd(p, x, c, dil)
+    g_res = rs.standard_normal(res_ref.shape).astype(np.float32)
+    g_skip = rs.standard_normal(skip_ref.shape).astype(np.float32)
+    gx_ref, gc_ref, gr = O.resblock_bwd(p, cache, c, dil, g_res, g_skip)
+    order = ['conv', 'condition_proj', 'res', 'skip']
+    vs = [Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(c)))]
+    for n in order:
+        vs += [Variable(_dev(gpu, to4(p[n][0]))), Variable(_dev(gpu, p[n][1]))]
+    res, skip = ResidualBlockFunction(dil).apply(vs)
+    assert_close(res.data.get(), res_ref, 1e-4, 'res')
+    assert_close(skip.data.get(), skip_ref, 1e-4, 'skip')
+    gouts = res.creator.backward(tuple(range(10)), (Variable(_dev(gpu, to4(g_res))), Variable(_dev(gpu, to4(g_skip)))))
+    assert_close_scaled(gouts[0].get(), gx_ref, 1e-4, 'gx')
+    assert_close_scaled(gouts[1].get(), gc_ref, 1e-4, 'gcond')
+    for i, n in enumerate(order):
+        assert_close_scaled(gouts[2 + 2 * i].get(), gr[n][0], 1e-4, 'gW ' + n)
+        assert_close_scaled(gouts[3 + 2 * i].get(), gr[n][1], 1e-4, 'gb ' + n)
+
+
+def test_resstack_b16_vs_oracle(gpu, matmul_mode):
+    """ResidualNet's chain as bench.py runs it: ResidualStackFunction over a LAZY (latent-rate)
+    condition -- condition projection at the latent rate + epilogue lerp, the streaming residual
+    1x1 (`res` conv alone, K = 128 -> 256 rows, + x), the skip sum as one GEMM, batched weight
+    gradients, the latent pull-back -- three blocks (dilations 1, 2, 512) at B = 16, T = 7680 against
+    the oracle's per-block restatement fed the materialised (B, 192, T) condition."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualStackFunction
+    dils = [1, 2, 512]
+    Tl, Cl, G, nspk = T // 64, 64, 128, 7
+    rs = np.random.RandomState(7)
+    blocks = [_rb_params(rs, 256, 256, 256, Cl + G, 2) for _ in dils]
+    x = rs.standard_normal((B, 256, T)).astype(np.float32)
+    local = rs.standard_normal((B, Cl, Tl)).astype(np.float32)
+    E = rs.standard_normal((nspk, G)).astype(np.float32)
+    ids = rs.randint(0, nspk, B).astype(np.int32)
+    gy = rs.standard_normal((B, 256, T)).astype(np.float32)
+    # oracle: full-rate condition (net.py:54-63), block by block (modules.py:89-96)
+    cond = np.concatenate([O.upsample_fwd(local, T), np.repeat(E[ids][:, :, None], T, axis=2)], axis=1).astype(np.float32)
+    h, caches, skip_ref = x, [], None
+    for blk, d in zip(blocks, dils):
+        h, sk, cch = O.resblock_fwd(blk, h, cond, d)
+        caches.append(cch)
+        skip_ref = sk if skip_ref is None else skip_ref + sk
+    g_res, gcond_ref, bg = None, np.zeros_like(cond), [None] * len(dils)
+    for i in range(len(dils) - 1, -1, -1):
+        g_res, gc, bg[i] = O.resblock_bwd(blocks[i], caches[i], cond, dils[i], g_res, gy)
+        gcond_ref += gc
+    glocal_ref = O.upsample_bwd(gcond_ref[:, :Cl], Tl)
+    gE_ref = np.zeros_like(E, dtype=np.float64)
+    np.add.at(gE_ref, ids, gcond_ref[:, Cl:].sum(axis=2, dtype=np.float64))
+    # device
+    vx = Variable(_dev(gpu, to4(x)))
+    vlocal, vE = Variable(_dev(gpu, to4(local))), Variable(_dev(gpu, E))
+    vcond = F.condition_assemble(vlocal, vE, _dev(gpu, ids), 64)
+    assert isinstance(vcond.data, F.LazyUpsampled)
+    order = ['conv', 'condition_proj', 'res', 'skip']
+    pv = []
+    for blk in blocks:
+        for n in order:
+            pv += [Variable(_dev(gpu, to4(blk[n][0]))), Variable(_dev(gpu, blk[n][1]))]
+    skip = ResidualStackFunction(dils).apply([vx, vcond] + pv)[0]
+    assert_close(skip.data.get()[..., 0], skip_ref, 1e-4, 'skip_connections')
+    skip.grad = _dev(gpu, to4(gy))
+    skip.backward()
+    assert_close_scaled(vx.grad.get()[..., 0], g_res, 1e-4, 'gx')
+    assert_close_scaled(vlocal.grad.get()[..., 0], glocal_ref, 1e-4, 'g local condition')
+    assert_close_scaled(vE.grad.get(), gE_ref, 1e-4, 'g speaker embedding')
+    last = len(dils) - 1
+    for i in range(len(dils)):
+        for j, n in enumerate(order):
+            gW, gb = pv[8 * i + 2 * j].grad, pv[8 * i + 2 * j + 1].grad
+            if i == last and n == 'res':          # unused residual branch of the last block (modules.py:89-96)
+                assert gW is None and gb is None
+                continue
+            assert_close_scaled(gW.get().reshape(bg[i][n][0].shape), bg[i][n][0], 1e-4, 'block %d gW %s' % (i, n))
+            assert_close_scaled(gb.get(), bg[i][n][1], 1e-4, 'block %d gb %s' % (i, n))
+
+
+def test_config1_whole_step_matches_oracle(gpu):
+    """BASELINE configs[1] as configured (batch 16, length 7680, d=64 k=512, 20 blocks, 256 channels,
+    EMA on): one VQVAE_StandardUpdater.update() against oracle.train_step -- 1 920 argmin indices
+    bit-exact, losses 1e-4, every gradient 2e-4 of its scale (tensors above 1e-4 are listed), every
+    parameter after Adam 1e-4.  The B = 1 twin of this test is test_gpu_configs.py::test_config0_..."""
+    import copy
+    import vqvae_amd as V
+    from vqvae_amd.optimizers import Adam
+    from test_gpu_configs import CFG0, _limit_blas
+    from test_gpu_model import _Iter, _grads_by_name
+    cfg = dict(CFG0)
+    P, model = H.build_model(cfg, seed=1, ema_decay=0.9999)
+    P_ema = copy.deepcopy(P['decoder'])
+    model.to_gpu()
+    opt = Adam(2e-4)
+    opt.setup(model)
+    batch = O.synth_batch(B, length=T, n_speaker=cfg['n_speaker'], seed=73)
+    upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
+    sites = H.device_relu_sites(model, batch[0], batch[1], batch[2])
+    upd.update()
+    with _limit_blas():
+        losses, cache, G, flips = H.oracle_train_step_aligned(P, {}, batch, cfg['n_loop'], cfg['n_layer'], sites,
+                                                              ema=P_ema, ema_decay=0.9999)
+    print('configs[1]: %d ReLU kink elements (of ~90 M) took the other side on the device' % flips)
+    assert flips <= 1024
+    idx_dev = model.vq._cache[3][0].get()
+    np.testing.assert_array_equal(idx_dev.reshape(cache['idx'].shape), cache['idx'])
+    assert cache['idx'].size == 16 * 120
+    l_dev = [float(l.data.get()) for l in upd.last_losses]
+    for i, (a, b) in enumerate(zip(l_dev, losses)):
+        assert_close(a, float(b), 1e-4, 'configs[1] loss%d' % (i + 1))
+    g_dev = _grads_by_name(model, opt, True)
+    over = []
+    for name, arr in G.items():
+        dn = H._dev_name(name, True)
+        got = g_dev[dn].reshape(arr.shape).astype(np.float64)
+        err = float(np.abs(got - arr).max() / max(np.abs(arr).max(), 1e-30))
+        if err > 1e-4:
+            over.append((err, dn))
+        assert err <= 2e-4, 'configs[1] grad %s: %.3e of scale' % (dn, err)
+    print('configs[1]: %d of %d gradient tensors are between 1e-4 and 2e-4 of scale: %s'
+          % (len(over), len(G), sorted(over, reverse=True)[:8]))
+    named = dict(model.namedparams())
+    for name, arr in O.flatten_params(P):
+        dn = H._dev_name(name, True)
+        assert_close(named[dn].data.get().reshape(arr.shape), arr, 1e-4, 'configs[1] param ' + dn)

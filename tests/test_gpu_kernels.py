@@ -38,6 +38,7 @@ CONV_CASES = [
     (3, 130, 64, 300, 2, 1, 1, 1, 64),       # wgrad2_kernel<2>: three 128-row tiles, the last one ragged
     (2, 96, 20, 256, 1, 1, 0, 1, None),      # wgrad2_kernel<4>: 256 rows, fewer positions than one K step pair
     (1, 256, 1000, 512, 2, 1, 3, 3, 1000),   # wgrad2_kernel<4>: two 256-row tiles, shifted window (dilation 3)
+    (3, 128, 192, 256, 1, 1, 0, 1, None),    # lin128_stream_kernel<.., HAS_ADD = false>: K = 128 -> 256 rows, T % 64 == 0
 ]
 
 
@@ -181,6 +182,44 @@ def test_vq_golden(gpu, matmul_mode, name, mode):
     np.testing.assert_array_equal(gW, g['gW'])            # fp64-accumulated, rounded once
     if name == 'vq_ties' and mode == 0:
         assert nre > 0                                    # ties must take the exact path
+
+
+def test_vq_near_ties_around_the_certainty_band(gpu, matmul_mode):
+    """Adversarial rows for the MFMA search's CERTAIN / re-check decision (vq.hip): every latent row
+    has its own pair of codes whose reference-order distances differ by a chosen multiple of the
+    certainty band -- from exact fp32 near-ties (1e-7 relative) through 0.5x, 0.9x, 1.1x, 2x the
+    band of the bf16-pipe sweep (24 (d+4) u S) -- hidden among far codes.  Indices must equal the
+    reference arithmetic's argmin (utils.py:189-203) for every row, whichever side of the band it
+    falls, and every row closer than 0.9 x the fp32 band must have gone through the exact re-check."""
+    from vqvae_amd.core import Variable
+    from vqvae_amd.utils import StraightThrough
+    d, Bq, Tq = 64, 16, 128
+    N = Bq * Tq
+    k = 2 * N + 2048
+    rs = np.random.RandomState(123)
+    rows = rs.standard_normal((N, d)).astype(np.float32)
+    W = (2.0 * rs.standard_normal((k, d))).astype(np.float32)          # far codes: distance ~ 5 d
+    u = 2.0 ** -24
+    S = float((rows.astype(np.float64) ** 2).sum(1).max() + (W.astype(np.float64) ** 2).sum(1).max())
+    band_x3, band_f32 = 24.0 * (d + 4) * u * S, 16.0 * (d + 4) * u * S
+    mult = np.array([1e-7, 1e-4, 0.5, 0.9, 1.1, 2.0, 8.0])[rs.randint(0, 7, N)]
+    gap = np.where(mult < 1e-3, mult, mult * band_x3)
+    perm = rs.permutation(k)[:2 * N]
+    for n in range(N):
+        ua, ub = rs.standard_normal(d), rs.standard_normal(d)
+        ua /= np.linalg.norm(ua); ub /= np.linalg.norm(ub)
+        W[perm[2 * n]] = (rows[n] + ua).astype(np.float32)                          # |.|^2 = 1
+        W[perm[2 * n + 1]] = (rows[n] + np.sqrt(1.0 + gap[n]) * ub).astype(np.float32)
+    z = np.ascontiguousarray(rows.reshape(Bq, Tq, d).transpose(0, 2, 1))[..., None]
+    _, idx_ref = O.vq_forward_chunked(z, W, chunk=1)
+    st = StraightThrough()
+    (e,) = st.apply((Variable(_dev(gpu, z)), Variable(_dev(gpu, W))))
+    idx = st.indexes.get()
+    np.testing.assert_array_equal(idx.reshape(idx_ref.shape), idx_ref)
+    nre = int(st.n_rechecked.get()[0])
+    must = int((gap < 0.9 * band_f32).sum())
+    assert nre >= must, (nre, must)
+    assert nre < N                      # and the far side of the band stays on the fast path
 
 
 @pytest.mark.parametrize('mode', [0, 1])
