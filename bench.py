@@ -248,6 +248,24 @@ def spawn_ranks(n, argv):
     raise SystemExit(rc)
 
 
+def pin_rank_to_cores(local_rank, n_local):
+    """One contiguous slice of the visible cores per rank (the host side of a step is ~500 Python-driven
+    kernel launches: eight unpinned ranks migrating across sockets show up as rank skew).  Returns the
+    (first, last, count) it pinned to, or None when the platform has no sched_setaffinity / one rank."""
+    if n_local <= 1 or not hasattr(os, 'sched_setaffinity') or os.environ.get('VQVAE_NO_AFFINITY'):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // n_local
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return [mine[0], mine[-1], len(mine)]
+    except OSError:
+        return None
+
+
 def vq_stress_inputs(N, d, k):
     """SURVEY 8d C4 inputs: half the rows N(0,1), half W[j] + 0.5 N(0,1); W ~ N(0, 1/d); seeds 1/2."""
     rw = np.random.RandomState(2)
@@ -383,6 +401,12 @@ def main():
                     help='single stream (the default since the float32x3 kernels; kept for the profile scripts)')
     ap.add_argument('--overlap', action='store_true',
                     help='weight gradients of the backward pass on a second stream')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="N > 1: 'weak' = --batch samples per GPU (configs[2]: 16/GPU, global 128 at N = 8); "
+                         "'strong' = global batch 128 split over the N ranks (128/N per GPU)")
+    ap.add_argument('--overlap-comm', action='store_true',
+                    help='exchange the decoder / condition-embed gradient bucket on the side stream while the '
+                         'codebook and commitment losses still back-propagate (VQVAE_ParallelUpdater(overlap_comm=True))')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -399,6 +423,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     n = world
+    affinity = pin_rank_to_cores(local, n)
+    if args.scaling == 'strong':
+        if 128 % n:
+            raise SystemExit('bench.py: --scaling strong splits a global batch of 128: --gpus must divide it')
+        cfg['batch_per_gpu'] = 128 // n
     if args.workload == 'c4':
         return run_c4(args, rank, n, local)
 
@@ -435,7 +464,8 @@ def main():
         else:
             shards.append(V.concat_examples(ex, device=local))
     it = ResidentIterator(shards)
-    upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local)
+    upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local,
+                                  overlap_comm=args.overlap_comm)
 
     for _ in range(max(args.warmup, 1)):
         upd.update()
@@ -448,16 +478,28 @@ def main():
     lib = _lib.load()
     lib.vqvae_prof_reset()
     lib.vqvae_prof_enable(1 << tag)
+    timed_comm = hasattr(comm, 'time_comm')
+    if timed_comm:
+        comm.time_comm = True            # HIP events around every all-reduce, on the stream it runs on
     comm.barrier()
     backend.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         upd.update()
     backend.synchronize()
+    dt_local = time.perf_counter() - t0  # this rank alone (before the closing barrier): rank skew shows here
     comm.barrier()
     dt = time.perf_counter() - t0
     lib.vqvae_prof_enable(0)
+    comm_ms, comm_calls = comm.comm_time_ms() if timed_comm else (0.0, 0)
+    if timed_comm:
+        comm.time_comm = False
     dt = comm.max_scalar(dt)
+    # diagnostics of a multi-rank run: slowest / fastest rank's own step time, slowest rank's all-reduce time
+    rank_ms = 1e3 * dt_local / args.steps
+    rank_ms_max, rank_ms_min = comm.max_scalar(rank_ms), -comm.max_scalar(-rank_ms)
+    comm_ms_step_max = comm.max_scalar(comm_ms / args.steps)
+    comm_ms_step_min = -comm.max_scalar(-comm_ms / args.steps)
 
     import ctypes as C
     tot = C.c_double(0)
@@ -503,7 +545,18 @@ def main():
             'value': value, 'unit': 'samples/s', 'n_gpus': n, 'ranks_seen_by_rccl': seen,
             'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'comm_ms_per_step': comm_ms_step_max if timed_comm else None,
+            'multi_rank_diagnostics': None if not timed_comm else {
+                'allreduce_ms_per_step_max_over_ranks': comm_ms_step_max,
+                'allreduce_ms_per_step_min_over_ranks': comm_ms_step_min,
+                'allreduce_calls_per_step': comm_calls / float(args.steps),
+                'allreduce_bytes_per_step': 4 * int(opt.n_train),
+                'allreduce_overlapped_with_backward': bool(args.overlap_comm),
+                'rank_ms_per_step_max': rank_ms_max, 'rank_ms_per_step_min': rank_ms_min,
+                'note': 'all-reduce time = HIP events around ncclAllReduce on its stream (includes waiting for the '
+                        'slowest rank to arrive); rank_ms = each rank\'s own wall time per step before the closing barrier',
+                'cpu_affinity_rank0': affinity},
             'dtype': 'bf16 operands, f32 accumulate' if args.bf16 else 'f32',
             'matmul': {'bfloat16': 'operands rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulate',
                        'float32': 'v_mfma_f32_32x32x2_f32',
@@ -520,7 +573,7 @@ def main():
                        if args.workload == 'c2' else
                        ('BASELINE configs[4]: mixture-of-logistics decoder (use_logistic, input_dim=1, '
                         '10 logistics), n_loop=4 n_layer=10 (40 blocks), batch %d/GPU, length 7680' % B),
-                       'global_batch': n * B, 'length': T,
+                       'global_batch': n * B, 'length': T, 'scaling': args.scaling,
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
             'trainable_params': int(n_params),
             'losses_last_step': losses,

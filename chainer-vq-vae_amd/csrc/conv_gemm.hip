@@ -1753,52 +1753,59 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
 #pragma unroll
   for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
 
-  const float* gyb = (sg.gy ? sg.gy : a.gy) + (long)b * a.gy_bstride + (long)(m0 + s_row) * Tout + 4 * s_chunk;
-  const float* xb = sg.x + (long)b * sg.x_bstride + (long)(n0 + s_row) * sg.x_cstride + 4 * s_chunk + sg.toff;
-  const long a_rstep = (long)RSTEP * Tout, b_rstep = (long)RSTEP * sg.x_cstride;
-  bool a_ok[NA], b_ok[NB];
+  // Fetches are buffer loads (see conv_gemm_x3_kernel): descriptors in SGPRs, per-thread offsets fixed
+  // for the whole launch (row, 4-t chunk, tap shift), one wave-uniform SGPR offset per operand that walks
+  // the flattened (b, t) axis.  An invalid row has an offset beyond the extent and reads 0.  A 16-t step
+  // whose shifted window stays inside the input row needs no per-thread arithmetic at all; a step that
+  // touches the row's first / last sample (two per row and tap) reads every 4-t group from the clamped
+  // in-row position and re-aligns it when it is staged.  Fetches are unconditional, two K steps ahead
+  // (two register sets): every wait in the loop is a counted vmcnt.
+  constexpr unsigned OOB = 0x80000000u;
+  const rsrc_t ra = make_rsrc(sg.gy ? sg.gy : a.gy), rbx = make_rsrc(sg.x);
+  unsigned voa[NA], vrow[NB], vobk[NB];
+  bool b_ok[NB];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) a_ok[i] = (m0 + s_row + RSTEP * i) < a.M;
+  for (int i = 0; i < NA; ++i)
+    voa[i] = (m0 + s_row + RSTEP * i) < a.M ? 4u * (unsigned)((m0 + s_row + RSTEP * i) * Tout + 4 * s_chunk) : OOB;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
+  for (int i = 0; i < NB; ++i) {
+    b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
+    vrow[i] = 4u * (unsigned)((n0 + s_row + RSTEP * i) * sg.x_cstride);
+    vobk[i] = b_ok[i] ? vrow[i] + 16u * (unsigned)s_chunk : OOB;          // interior steps: the tap shift rides in the scalar offset
+  }
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
+  const bool ragged = (Tout % W2K) != 0;                 // the last step of a row holds groups beyond Tout
 
-  // Fetches are branch-free and unconditional (a branch around a load makes hipcc wait vmcnt(0) right
-  // behind it, which exposed every load of the step before the MFMAs): an invalid row or group reads
-  // a safe address, a group of the shifted window that crosses the row's first / last sample is
-  // read from the clamped in-row position; masks and shift are applied when the step is staged.
-  // Two register sets (P: even steps, Q: odd steps): the fetch of step i+2 is in flight while step
-  // i+1 is split and stored, so every wait in the loop is a counted vmcnt.
   float4 pra[NA], prb[NB], qra[NA], qrb[NB];
-  unsigned pvm = 0, qvm = 0;     // bit i: A row i valid; bit 8 + i: B row i has a sample in range
+  unsigned pvm = 0, qvm = 0;     // 1: this thread's 4-t group lies inside [0, Tout)
   int pbs = 0, qbs = 0;          // clamped start - wanted start of the B group
   int pbt = 0, qbt = 0;          // wanted start (input time) of the B group
-  const float* safe_a = (sg.gy ? sg.gy : a.gy);
-  const float* safe_b = sg.x;
+  // (every offset handed to a load is non-negative: the scalar part carries tb + toff only on interior steps)
 #define W3_FETCH(RA, RB, VM, BS, BT)                                                          \
   {                                                                                            \
-    const int t = tb + 4 * s_chunk;                                                            \
-    const bool tin_range = t < Tout;               /* Tout % 4 == 0: a group is in or out as a whole */ \
-    unsigned mk = 0;                                                                           \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
-      const bool v = tin_range && a_ok[i];                                                     \
-      RA[i] = *reinterpret_cast<const float4*>(v ? gyb + i * a_rstep + tb : safe_a);           \
-      mk |= v ? (1u << i) : 0u;                                                                \
+    const unsigned soa = 4u * (unsigned)((long)b * a.gy_bstride + tb);                         \
+    const bool interior = tb + sg.toff >= 0 && tb + W2K + sg.toff <= sg.Tin && !ragged;        /* wave-uniform */ \
+    const unsigned sob = 4u * (unsigned)((long)b * sg.x_bstride + (interior ? tb + sg.toff : 0)); \
+    VM = (!ragged || tb + 4 * s_chunk < Tout) ? 1u : 0u;                                       \
+    unsigned vo_[NB];                                                                          \
+    if (interior) {                                                                            \
+      BS = 0; BT = 0;                                                                          \
+      _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = vobk[i];                         \
+    } else {                                                                                   \
+      const int tin = tb + 4 * s_chunk + sg.toff;                                              \
+      const bool any = VM != 0u && tin + 3 >= 0 && tin < sg.Tin;                               \
+      const int tc = min(max(tin, 0), sg.Tin - 4);                                             \
+      BT = tin; BS = tc - tin;                                                                 \
+      _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = (any && b_ok[i]) ? vrow[i] + 4u * (unsigned)tc : OOB; \
     }                                                                                          \
-    const int tin = t + sg.toff;                                                               \
-    const bool any = tin_range && tin + 3 >= 0 && tin < sg.Tin;                                \
-    const int tc = min(max(tin, 0), sg.Tin - 4);                                               \
-    BT = tin; BS = tc - tin;                                                                   \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
-      const bool v = any && b_ok[i];      /* dword-aligned dwordx4: fine on gfx950 */          \
-      RB[i] = *reinterpret_cast<const float4*>(v ? xb + i * b_rstep + tb + (tc - tin) : safe_b); \
-      mk |= v ? (1u << (8 + i)) : 0u;                                                          \
-    }                                                                                          \
-    VM = mk;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
+      RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, 0)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i)                                             \
+      RB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbx, vo_[i], sob, 0)); \
   }
   auto advance = [&]() {
     tb += W2K;
-    if (tb >= spb * W2K) { tb = 0; ++b; gyb += a.gy_bstride; xb += sg.x_bstride; }   // same step count per item as the plan
+    if (tb >= spb * W2K) { tb = 0; ++b; }   // same step count per item as the plan
   };
   // staging: this thread's 4 consecutive t of a row are half (s_chunk & 1) of the 8-k group
   // (s_chunk >> 1) of that row; split into the three bf16 pieces and written as 8 bytes per piece
@@ -1820,12 +1827,12 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
     const bool real_ = (REAL);          /* evaluated here: the loops below have their own i */ \
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
-      const float4 v = (VM >> i) & 1u ? RA[i] : zero4;                                         \
+      const float4 v = VM ? RA[i] : zero4;          /* invalid rows arrived as 0; VM: ragged Tout only */ \
       put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                              \
       if (real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                                         \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
-      float4 v = (VM >> (8 + i)) & 1u ? RB[i] : zero4;                                         \
+      float4 v = RB[i];                               /* invalid rows / groups arrived as 0 */ \
       if (BS != 0) {                /* the group crosses a row end: element e is loaded[e - BS] */ \
         const float l[4] = {v.x, v.y, v.z, v.w};                                               \
         float o[4];                                                                            \
@@ -2286,6 +2293,9 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   // fp32, stride-1 segments, 16-B aligned output-gradient rows: the 16-byte-LDS kernel
   bool fast = av && g_wgrad_impl != 1;
   for (int i = 0; i < w.nseg; ++i) fast = fast && w.seg[i].tmul == 1 && w.seg[i].tdiv == 1;
+  // wgrad3_kernel addresses both operands with 32-bit buffer offsets from the tensor base
+  fast = fast && (g_matmul_dtype == 0 || (long)w.B * w.gy_bstride * 4 < (1L << 31));
+  for (int i = 0; i < w.nseg; ++i) fast = fast && (g_matmul_dtype == 0 || (long)w.B * w.seg[i].x_bstride * 4 < (1L << 31));
   ProfScope ps(tag, st);
   static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
   const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
@@ -2522,11 +2532,13 @@ extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
   return rb_layout(d).total * sizeof(float) + 256;
 }
 
-extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
-                                  const float* x, const float* cond,
-                                  const vqvae_resblock_cproj* cproj, float* res, float* skip,
-                                  int skip_accumulate, float* gates, float* z, void* ws,
-                                  size_t ws_bytes, vqvae_stream_t s) {
+// `packed`: this block's weight slabs as vqvae_resstack_pack laid them out (the [pk_d, slabs) region of
+// RbLayout), or NULL: pack into the workspace now.
+static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                             const float* x, const float* cond,
+                             const vqvae_resblock_cproj* cproj, float* res, float* skip,
+                             int skip_accumulate, float* gates, float* z, void* ws,
+                             size_t ws_bytes, const float* packed, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(p && x && (cond || cproj) && gates && z && ws, "resblock_fwd: null pointer");
   VQ_REQUIRE(p->Wd && (cproj || p->Wc) && (skip == nullptr || p->Ws) && (res == nullptr || p->Wr), "resblock_fwd: null weight");
@@ -2534,13 +2546,15 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
   hipStream_t st = (hipStream_t)s;
   RbLayout L = rb_layout(d);
   if (L.total * sizeof(float) > ws_bytes) { set_error("resblock_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
-  float* w = (float*)ws;
+  float* w = packed ? const_cast<float*>(packed) - L.pk_d : (float*)ws;       // only the pk_* offsets are used through w
   const int Ch = d->Cd / 2, T = d->T;
   const int ldd = pad128(d->Cd);
   const int Mo = (res ? d->Cr : 0) + (skip ? d->Cs : 0);
   const int ldo = pad128(Mo > 0 ? Mo : 1);
+  if (packed) VQ_REQUIRE(cproj && !skip, "resblock_fwd_packed: the packed form serves ResidualNet's chain (latent-rate condition, no per-block skip)");
 
   PackArgs pa; pa.njob = 0;
+  if (!packed) {
   pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p->Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
   if (!cproj) pa.job[pa.njob++] = pack_fwd_job(w + L.pk_c, p->Wc, d->Cd, d->Cc, 1, Ch, ldd, 0, ldd);
   if (res && skip) {
@@ -2553,6 +2567,7 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
     pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p->Ws, d->Cs, Ch, 1, 0, ldo, 0, ldo);
   }
   if (int e = launch_pack(pa, st)) return e;
+  }
 
   // K1: h = dilconv(x) + cond_proj(c) + biases -> gate
   {
@@ -2603,12 +2618,68 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
   return 0;
 }
 
-extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                  const float* x, const float* cond,
+                                  const vqvae_resblock_cproj* cproj, float* res, float* skip,
+                                  int skip_accumulate, float* gates, float* z, void* ws,
+                                  size_t ws_bytes, vqvae_stream_t s) {
+  return resblock_fwd_impl(d, p, x, cond, cproj, res, skip, skip_accumulate, gates, z, ws, ws_bytes, nullptr, s);
+}
+
+extern "C" int vqvae_resblock_fwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                         const float* x, const vqvae_resblock_cproj* cproj, float* res,
+                                         float* gates, float* z, void* ws, size_t ws_bytes,
+                                         const void* packed, vqvae_stream_t s) {
+  VQ_REQUIRE(packed, "resblock_fwd_packed: null packed slabs");
+  return resblock_fwd_impl(d, p, x, nullptr, cproj, res, nullptr, 0, gates, z, ws, ws_bytes, (const float*)packed, s);
+}
+
+extern "C" size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d) {
+  if (!d || d->Cd <= 0) return 0;
+  const RbLayout L = rb_layout(d);
+  return (L.slabs - L.pk_d) * sizeof(float);
+}
+
+// Every weight slab the chain of ResidualNet needs for one training step -- forward (gated dilated conv,
+// res 1x1) and backward (gz from g_res / g_skip, dilated-conv backward-data) of every block -- re-laid in
+// ceil(5 nblocks / 24) launches, once per step: the weights only change in the optimizer.  (Round 2
+// re-packed inside every resblock_fwd / resblock_bwd call: 74 launches per configs[1] step.)
+extern "C" int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
+                                   const vqvae_resblock_params* params, const int* has_res,
+                                   void* packed, size_t packed_bytes, vqvae_stream_t s) {
+  if (int e = check_rb(d)) return e;
+  VQ_REQUIRE(nblocks >= 1 && params && has_res && packed, "resstack_pack: null pointer / no blocks");
+  const RbLayout L = rb_layout(d);
+  const size_t per = L.slabs - L.pk_d;
+  if (per * sizeof(float) * nblocks > packed_bytes) { set_error("resstack_pack: packed buffer too small"); return VQVAE_E_WORKSPACE; }
+  hipStream_t st = (hipStream_t)s;
+  const int Ch = d->Cd / 2;
+  const int ldd = pad128(d->Cd), ldz = pad128(Ch), ldr = pad128(d->Cr);
+  PackArgs pa; pa.njob = 0;
+  auto flush = [&]() -> int { if (pa.njob == 0) return 0; const int e = launch_pack(pa, st); pa.njob = 0; return e; };
+  for (int l = 0; l < nblocks; ++l) {
+    float* w = (float*)packed + (size_t)l * per - L.pk_d;
+    const vqvae_resblock_params& p = params[l];
+    VQ_REQUIRE(p.Wd && p.Ws && (!has_res[l] || p.Wr), "resstack_pack: null weight in block %d", l);
+    if (pa.njob + 5 > MAXSEG) { if (int e = flush()) return e; }
+    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p.Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
+    if (has_res[l]) {
+      const int ldo = pad128(d->Cr);
+      pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p.Wr, d->Cr, Ch, 1, 0, ldo, 0, ldo);
+      pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_r, p.Wr, d->Cr, Ch, 1, ldz);
+    }
+    pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_s, p.Ws, d->Cs, Ch, 1, ldz);
+    pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bd, p.Wd, d->Cd, d->Cr, d->K, ldr);
+  }
+  return flush();
+}
+
+static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                                   const float* x, const float* cond, const float* gates,
                                   const float* z, const float* g_res, const float* g_skip,
                                   float* gx, float* gcond, int gcond_accumulate, float* gh_out,
                                   const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
-                                  size_t ws_bytes, vqvae_stream_t s) {
+                                  size_t ws_bytes, const float* packed, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(p && x && gates && z && g_skip && ws && gr, "resblock_bwd: null pointer");
   VQ_REQUIRE(cond || (!gcond && !gr->gWc && !gr->gbc), "resblock_bwd: condition gradients requested without a condition tensor");
@@ -2619,13 +2690,18 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
   const int Ch = d->Cd / 2, T = d->T;
   float* gh = gh_out ? gh_out : w + L.gh;
   const int ldz = pad128(Ch), ldr = pad128(d->Cr), ldc = pad128(d->Cc);
+  // packed slabs (vqvae_resstack_pack): only the pk_* offsets are read through wpk
+  float* wpk = packed ? const_cast<float*>(packed) - L.pk_d : w;
+  if (packed) VQ_REQUIRE(!gcond && gh_out, "resblock_bwd_packed: the packed form serves ResidualNet's chain (no per-block condition gradient, gh kept)");
 
+  if (!packed) {
   PackArgs pa; pa.njob = 0;
   if (g_res) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_r, p->Wr, d->Cr, Ch, 1, ldz);
   pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_s, p->Ws, d->Cs, Ch, 1, ldz);
   if (gx) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bd, p->Wd, d->Cd, d->Cr, d->K, ldr);
   if (gcond) pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bc, p->Wc, d->Cd, d->Cc, 1, ldc);
   if (int e = launch_pack(pa, st)) return e;
+  }
 
   // K3: gz = Wr^T g_res + Ws^T g_skip ; gh = gate'(gz)
   {
@@ -2634,11 +2710,11 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
     if (g_res) {
       Seg& sg = g.seg[n++];
       sg.x = g_res; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
-      sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + L.pk_gz_r; sg.ldw = ldz;
+      sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = wpk + L.pk_gz_r; sg.ldw = ldz;
     }
     Seg& ss = g.seg[n++];
     ss.x = g_skip; ss.x_bstride = (long)d->Cs * T; ss.x_cstride = T; ss.cin = d->Cs; ss.Tin = T;
-    ss.tmul = 1; ss.toff = 0; ss.tdiv = 1; ss.w = w + L.pk_gz_s; ss.ldw = ldz;
+    ss.tmul = 1; ss.toff = 0; ss.tdiv = 1; ss.w = wpk + L.pk_gz_s; ss.ldw = ldz;
     g.nseg = n;
     g.M = Ch; g.Tout = T; g.B = d->B;
     g.out[0].y = gh; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].rows = Ch;
@@ -2654,7 +2730,7 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
       Seg& sg = g.seg[j];
       sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
       sg.tmul = 1; sg.toff = (d->K - 1 - j) * d->dil; sg.tdiv = 1;
-      sg.w = w + L.pk_bd + (size_t)j * rp * ldr; sg.ldw = ldr;
+      sg.w = wpk + L.pk_bd + (size_t)j * rp * ldr; sg.ldw = ldr;
     }
     g.M = d->Cr; g.Tout = T; g.B = d->B;
     g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
@@ -2715,6 +2791,28 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
     if (int e = launch_wgrad(wa, which ? L.p_s : L.p_r, w + L.slabs, VQVAE_PROF_RESBLOCK_WGRAD, st)) return e;
   }
   return 0;
+}
+
+extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                  const float* x, const float* cond, const float* gates,
+                                  const float* z, const float* g_res, const float* g_skip,
+                                  float* gx, float* gcond, int gcond_accumulate, float* gh_out,
+                                  const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
+                                  size_t ws_bytes, vqvae_stream_t s) {
+  return resblock_bwd_impl(d, p, x, cond, gates, z, g_res, g_skip, gx, gcond, gcond_accumulate, gh_out, gr,
+                           grads_accumulate, ws, ws_bytes, nullptr, s);
+}
+
+// the chain part of a block's backward (gz, gate derivative -> gh_out, backward-data -> gx) on packed slabs
+extern "C" int vqvae_resblock_bwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                                         const float* x, const float* gates, const float* z,
+                                         const float* g_res, const float* g_skip, float* gx, float* gh_out,
+                                         void* ws, size_t ws_bytes, const void* packed, vqvae_stream_t s) {
+  VQ_REQUIRE(packed, "resblock_bwd_packed: null packed slabs");
+  vqvae_resblock_grads none;
+  memset(&none, 0, sizeof(none));
+  return resblock_bwd_impl(d, p, x, nullptr, gates, z, g_res, g_skip, gx, nullptr, 0, gh_out, &none, 0, ws, ws_bytes,
+                           (const float*)packed, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -99,6 +99,13 @@ PROTOTYPES = {
                                    P, P, P, P, c_int, P, C.POINTER(ResblockGrads), c_int, P,
                                    c_size_t, P]),
     'vqvae_resblock_wgrad': (c_int, [C.POINTER(ResblockDesc), P, P, P, P, c_int, P, c_size_t, P]),
+    'vqvae_resstack_packed_bytes': (c_size_t, [C.POINTER(ResblockDesc)]),
+    'vqvae_resstack_pack': (c_int, [C.POINTER(ResblockDesc), c_int, C.POINTER(ResblockParams),
+                                    C.POINTER(c_int), P, c_size_t, P]),
+    'vqvae_resblock_fwd_packed': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P,
+                                          C.POINTER(ResblockCproj), P, P, P, P, c_size_t, P, P]),
+    'vqvae_resblock_bwd_packed': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P,
+                                          P, P, P, P, P, c_size_t, P, P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
                                         c_size_t, P]),

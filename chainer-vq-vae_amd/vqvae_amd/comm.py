@@ -40,7 +40,7 @@ class SingleCommunicator(object):
     def ranks_seen(self):
         return None          # no communicator, no RCCL: nothing to report
 
-    def allreduce_grad(self, flat):
+    def allreduce_grad(self, flat, stream=None):
         return flat
 
     def barrier(self):
@@ -48,6 +48,9 @@ class SingleCommunicator(object):
 
     def max_scalar(self, v):
         return v
+
+    def comm_time_ms(self):
+        return 0.0, 0
 
 
 def _rendezvous_dir():
@@ -146,6 +149,8 @@ class RcclCommunicator(object):
             os.dup2(saved, 1)
             os.close(saved)
         self._comm = comm
+        self.time_comm = False
+        self._timed = []
         self._scalar = backend.zeros((1,), np.float32)
         self.barrier()
         if self.rank == 0:
@@ -154,11 +159,28 @@ class RcclCommunicator(object):
             except OSError:
                 pass
 
-    def allreduce_grad(self, flat):
-        """In-place sum over ranks of a flat fp32 DeviceArray."""
-        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, flat.ptr, flat.size,
-                       self._backend.stream())
+    def allreduce_grad(self, flat, stream=None):
+        """In-place sum over ranks of a flat fp32 DeviceArray, enqueued on ``stream`` (default: the
+        process stream).  With ``time_comm`` set, every call is bracketed by HIP events on its
+        stream; comm_time_ms() adds them up (after a synchronize) -- bench.py's comm_ms_per_step."""
+        st = self._backend.stream() if stream is None else stream
+        if self.time_comm:
+            e0 = self._backend.Event().record(st)
+        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, flat.ptr, flat.size, st)
+        if self.time_comm:
+            self._timed.append((e0, self._backend.Event().record(st)))
         return flat
+
+    def comm_time_ms(self):
+        """(total ms, calls) of the timed all-reduces so far; call after backend.synchronize()."""
+        tot = 0.0
+        ms = C.c_float(0)
+        for e0, e1 in self._timed:
+            self._lib.call('vqvae_event_elapsed_ms', C.byref(ms), e0.h, e1.h)
+            tot += ms.value
+        n = len(self._timed)
+        self._timed = []
+        return tot, n
 
     def barrier(self):
         self._scalar.fill_zero()

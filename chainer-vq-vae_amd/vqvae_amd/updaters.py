@@ -78,10 +78,32 @@ class VQVAE_ParallelUpdater(StandardUpdater):
     optimizer's alpha must already be lr/n (train.py:101)."""
 
     def __init__(self, iterator, optimizer, comm=None, converter=concat_examples, device=0,
-                 loss_func=None):
+                 loss_func=None, overlap_comm=False):
         super(VQVAE_ParallelUpdater, self).__init__(iterator, optimizer, converter, device,
                                                     loss_func)
         self.comm = comm or SingleCommunicator()
+        # opt-in: exchange the gradients that are final after the reconstruction loss's backward (decoder,
+        # condition embed: 95 % of the arena) on the side stream while the codebook / commitment losses
+        # still back-propagate into vq.W and the encoder; fixed bucket order, same sums
+        self.overlap_comm = overlap_comm
+        self._buckets = None
+
+    def _grad_buckets(self, optimizer):
+        """(early, late): contiguous [offset, size) runs of the gradient arena.  `late` = what
+        loss2 / loss3 still write (vq.W, the encoder: updaters.py:16-18), `early` = the rest."""
+        key = core.param_epoch('layout')
+        if self._buckets is None or self._buckets[0] != key:
+            early, late = [], []
+            for name, off, size in optimizer.layout():
+                if off + size > optimizer.n_train:
+                    continue                       # EMA shadows: no gradient
+                dst = late if (name.startswith('/encoder') or name.startswith('/vq')) else early
+                if dst and dst[-1][0] + dst[-1][1] == off:
+                    dst[-1] = (dst[-1][0], dst[-1][1] + size)
+                else:
+                    dst.append((off, size))
+            self._buckets = (key, early, late)
+        return self._buckets[1], self._buckets[2]
 
     def update_core(self):
         optimizer = self.get_optimizer('main')
@@ -92,6 +114,9 @@ class VQVAE_ParallelUpdater(StandardUpdater):
 
         with core.force_backprop_mode():
             self.last_losses = (self.loss_func or model)(*in_arrays)
+        exchange = n > 1 or getattr(self.comm, 'always_reduce', False)
+        if self.overlap_comm and exchange:
+            return self._update_overlapped(optimizer, model)
         three_loss_backward(model, self.last_losses)
 
         # parameters created during this forward (lazily shaped links, net.py:34-43) join the
@@ -99,6 +124,27 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         adopt = getattr(optimizer, 'adopt_new_params', None)
         if adopt is not None:
             adopt()
-        if n > 1 or getattr(self.comm, 'always_reduce', False):
+        if exchange:
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place
+        optimizer.update()
+
+    def _update_overlapped(self, optimizer, model):
+        """three_loss_backward with the exchange of the early bucket on the side stream."""
+        loss1, loss2, loss3 = self.last_losses
+        model.cleargrads()
+        loss1.backward()
+        model.vq.cleargrads()
+        adopt = getattr(optimizer, 'adopt_new_params', None)
+        if adopt is not None:
+            adopt()
+        early, late = self._grad_buckets(optimizer)
+        main, side = backend.stream(), backend.side_stream()
+        backend.wait_event(side, backend.Event().record(main))      # loss1's gradients are complete
+        for off, size in early:
+            self.comm.allreduce_grad(optimizer.grads.flat_view(off, size), stream=side)
+        loss2.backward()
+        loss3.backward()
+        for off, size in late:
+            self.comm.allreduce_grad(optimizer.grads.flat_view(off, size))
+        backend.wait_event(main, backend.Event().record(side))      # join before the optimizer reads the arena
         optimizer.update()

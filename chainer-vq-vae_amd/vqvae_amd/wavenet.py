@@ -9,6 +9,7 @@ WaveNet level -- initialize(n) / generate(x, condition) / generate_sequence(...)
 per-block push/pop fused into one device-side step (generation.py, csrc/generate.hip).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -18,6 +19,7 @@ from .core import Chain, ChainList, FunctionNode, type_expect
 
 _S = backend.stream
 DIL_WGRAD_GROUP = 5      # blocks per batched dilated-conv weight-gradient launch
+PACK_ONCE = os.environ.get('VQVAE_PACK_ONCE', '1') != '0'     # weight slabs of the whole chain re-laid once per step
 
 
 def _p(a):
@@ -144,6 +146,18 @@ class ResidualStackFunction(FunctionNode):
             _lib.call('vqvae_conv1d_fwd', C.byref(self.pdesc), lat.ptr, self.Wc_all.ptr, bc_all.ptr,
                       P_all.ptr, ws.ptr, ws.nbytes, _S())
             tb = F.resize_tables(Tl, x.shape[2])
+        self.packed = None
+        if self.lat is not None and PACK_ONCE:
+            # every block's weight slabs (forward and backward forms), re-laid once for this step
+            d0 = _rb_desc(x, cond, inputs[2], inputs[8], self.dilations[0])
+            per = _lib.load().vqvae_resstack_packed_bytes(C.byref(d0))
+            self.packed = DeviceArray((nb * per // 4,), np.float32)
+            self.packed_stride = per
+            prms = (_lib.ResblockParams * nb)(*[
+                _lib.ResblockParams(*[inputs[2 + 8 * i + j].ptr for j in range(8)]) for i in range(nb)])
+            has_res = (C.c_int * nb)(*([1] * (nb - 1) + [0]))
+            _lib.call('vqvae_resstack_pack', C.byref(d0), nb, prms, has_res, self.packed.ptr,
+                      self.packed.nbytes, _S())
         for i, dil in enumerate(self.dilations):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs[2 + 8 * i: 10 + 8 * i]
             d = _rb_desc(h, cond, Wd, Ws, dil)
@@ -156,8 +170,13 @@ class ResidualStackFunction(FunctionNode):
             if self.lat is not None:
                 cp = _lib.ResblockCproj(P_all.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, Tl,
                                         tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
-                _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, None, C.byref(cp),
-                          _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
+                if self.packed is not None:
+                    _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), h.ptr, C.byref(cp),
+                              _p(res), gates.ptr, z.ptr, ws.ptr, ws.nbytes,
+                              self.packed.ptr + i * self.packed_stride, _S())
+                else:
+                    _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, None, C.byref(cp),
+                              _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
             else:
                 _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, cond.ptr, None,
                           _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
@@ -276,10 +295,15 @@ class ResidualStackFunction(FunctionNode):
             ws = _rb_workspace(d)
             if lat is not None:
                 # chain on the main stream: gz, gate derivative -> gh, then gx
-                none = _lib.ResblockGrads(*([None] * 8))
-                _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, None, gates.ptr,
-                          z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(none), 0,
-                          ws.ptr, ws.nbytes, _S())
+                if self.packed is not None:
+                    _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), h.ptr, gates.ptr,
+                              z.ptr, _p(g_res), g_skip.ptr, _p(gx), gh.ptr, ws.ptr, ws.nbytes,
+                              self.packed.ptr + i * self.packed_stride, _S())
+                else:
+                    none = _lib.ResblockGrads(*([None] * 8))
+                    _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, None, gates.ptr,
+                              z.ptr, _p(g_res), g_skip.ptr, _p(gx), None, 0, gh.ptr, C.byref(none), 0,
+                              ws.ptr, ws.nbytes, _S())
                 ghs[i] = gh
                 gdil[i] = (gp[0], gp[1])
                 dil_pending.append(i)
@@ -348,6 +372,7 @@ class ResidualStackFunction(FunctionNode):
             grads[2 + 8 * i + 6] = gWs[i]
             grads[2 + 8 * i + 7] = gbs[i]
         self.saved = None                      # release activations
+        self.packed = None
         grads[0] = g_res if 0 in indexes else None
         return tuple(grads)
 

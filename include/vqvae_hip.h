@@ -192,6 +192,32 @@ int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params
                        const vqvae_resblock_grads* g, int grads_accumulate, void* ws,
                        size_t ws_bytes, vqvae_stream_t s);
 
+/* ---- pack once per step (ResidualNet's chain, WaveNet/modules.py:89-96).
+ *      The GEMM kernels read weights as re-laid "slabs"; vqvae_resblock_fwd / _bwd re-lay them into the
+ *      workspace on every call.  The weights only change in the optimizer, so ResidualNet packs the
+ *      slabs of ALL its blocks once per training step (forward + backward forms: gated dilated conv, res
+ *      1x1, gz from g_res / g_skip, dilated-conv backward-data) and hands every block its slice:
+ *        packed = nblocks x vqvae_resstack_packed_bytes(d) bytes of device memory;
+ *        params = HOST array of nblocks vqvae_resblock_params (device pointers), has_res[l] = 0 for a
+ *        block whose residual output is unused (the last one);
+ *        block l's slice starts at packed + l * vqvae_resstack_packed_bytes(d).
+ *      The _packed entry points are the latent-rate-condition chain only (cproj given, no per-block
+ *      skip output, no per-block condition / parameter gradients: ResidualNet batches those).   */
+size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
+int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
+                        const vqvae_resblock_params* params, const int* has_res, void* packed,
+                        size_t packed_bytes, vqvae_stream_t s);
+int vqvae_resblock_fwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                              const float* x, const vqvae_resblock_cproj* cproj, float* res,
+                              float* gates, float* z, void* ws, size_t ws_bytes,
+                              const void* packed, vqvae_stream_t s);
+/* gz = Wr^T g_res + Ws^T g_skip, gate derivative -> gh_out (B,Cd,T), gx = g_res + conv^T(gh_out);
+ * g_res / gx may be NULL as in vqvae_resblock_bwd.                                            */
+int vqvae_resblock_bwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
+                              const float* x, const float* gates, const float* z,
+                              const float* g_res, const float* g_skip, float* gx, float* gh_out,
+                              void* ws, size_t ws_bytes, const void* packed, vqvae_stream_t s);
+
 /* Weight gradients of the dilated conv only: gWd (+)= gh x_taps^T, gbd (+)= rowsum(gh), from
  * the gh that vqvae_resblock_bwd wrote to gh_out.  Split out so ResidualNet can run it on a
  * second stream, concurrently with the next block's backward-data chain.              */

@@ -38,7 +38,10 @@ class HostStagedCommunicator(object):
     def _path(self, call, rank):
         return os.path.join(self.dir, 'ar_%d_rank%d.npy' % (call, rank))
 
-    def allreduce_grad(self, flat):
+    def allreduce_grad(self, flat, stream=None):
+        if stream is not None:                 # side-stream bucket: everything enqueued so far must have run
+            from vqvae_amd import backend
+            backend.synchronize()
         host = flat.get()
         tmp = self._path(self.calls, self.rank) + '.tmp.npy'
         np.save(tmp, host)
@@ -87,14 +90,15 @@ def _build(n):
     return model, opt
 
 
-def run_rank(rank, n, directory):
+def run_rank(rank, n, directory, overlap=False):
     import vqvae_amd as V
     model, opt = _build(n)
     comm = HostStagedCommunicator(rank, n, directory)
-    upd = V.VQVAE_ParallelUpdater(_Iter(_examples()), opt, comm=comm, device=0)
+    comm.always_reduce = True
+    upd = V.VQVAE_ParallelUpdater(_Iter(_examples()), opt, comm=comm, device=0, overlap_comm=overlap)
     for _ in range(STEPS):
         upd.update()
-    assert comm.calls == STEPS
+    assert comm.calls == STEPS * (len(upd._grad_buckets(opt)[0]) + len(upd._grad_buckets(opt)[1]) if overlap else 1)
     np.save(os.path.join(directory, 'params_rank%d.npy' % rank), opt.params.get())
     np.save(os.path.join(directory, 'losses_rank%d.npy' % rank),
             np.array([float(l.data.get()) for l in upd.last_losses]))
@@ -128,7 +132,7 @@ def run_single(n, directory):
 
 
 if __name__ == '__main__':
-    if sys.argv[1] == 'rank':
-        run_rank(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    if sys.argv[1] in ('rank', 'rank_overlap'):
+        run_rank(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], overlap=sys.argv[1] == 'rank_overlap')
     else:
         run_single(int(sys.argv[2]), sys.argv[3])

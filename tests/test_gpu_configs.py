@@ -262,9 +262,16 @@ def test_config4_full_size_properties_bf16(gpu):
         _, _, _, g_a = grads(slice(0, B, 2))
         _, _, _, g_b = grads(slice(1, B, 2))
         for name, g in g_all.items():
-            # 5e-4: the three evaluations split their contractions differently (batch 16 vs 8), and the
-            # encoder's first-layer gradient is a 1e-4-scale difference of O(1) sums (seen: 2.3e-4)
-            assert_close_scaled(g, 0.5 * (g_a[name] + g_b[name]), 5e-4, 'configs[4] shard sum ' + name)
+            # 5e-4 of the tensor's scale: the three evaluations split their contractions differently (batch 16
+            # vs 8).  The encoder's gradients are 1e-4-scale DIFFERENCES of O(1) sums (commitment loss against
+            # the decoder's pull), so for them one fp32 rounding of a summand (eps = 1.2e-7 absolute) is already
+            # 5e-4 of the result: those tensors are held to 4 eps absolute instead (seen: 1.5e-7 = 6.1e-4 of
+            # scale on /encoder/conv2/W; 2.3e-4 in round 2 -- the figure moves with every reordering upstream)
+            want = 0.5 * (g_a[name] + g_b[name])
+            err = float(np.abs(g - want).max())
+            tol = max(5e-4 * float(np.abs(want).max()), 4 * 1.1920929e-07)
+            assert err <= tol, 'configs[4] shard sum %s: max abs err %.3e (tol %.3e, scale %.3e)' % (
+                name, err, tol, float(np.abs(want).max()))
         x_enc, x_dec, spk, t = batch
         with V.using_config('train', False), V.core.no_backprop_mode():
             def outputs(sl):

@@ -19,11 +19,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def test_two_process_parallel_updater_on_one_gpu(gpu, tmp_path):
+@pytest.mark.parametrize('mode', ['rank', 'rank_overlap'])
+def test_two_process_parallel_updater_on_one_gpu(gpu, tmp_path, mode):
+    """mode 'rank_overlap': VQVAE_ParallelUpdater(overlap_comm=True) -- the decoder / condition-embed bucket
+    of the arena is exchanged on the side stream while loss2 / loss3 back-propagate; same bits."""
     d = str(tmp_path)
     worker = os.path.join(HERE, 'dp_gpu_worker.py')
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    procs = [subprocess.Popen([sys.executable, worker, 'rank', str(r), '2', d], env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, mode, str(r), '2', d], env=env) for r in range(2)]
     try:
         for p in procs:
             assert p.wait(timeout=900) == 0
@@ -43,7 +46,7 @@ def test_two_process_parallel_updater_on_one_gpu(gpu, tmp_path):
     lb = np.load(os.path.join(d, 'losses_rank1.npy'))
     assert np.any(la != lb)
     # all-reduce traffic really went through: every step has both ranks' files
-    for step in range(3):
+    for step in range(3 if mode == 'rank' else 6):
         for r in range(2):
             assert os.path.exists(os.path.join(d, 'ar_%d_rank%d.npy' % (step, r)))
 
