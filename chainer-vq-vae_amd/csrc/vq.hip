@@ -260,11 +260,20 @@ __global__ void vq_wsplit_kernel(const float* __restrict__ W, int k, int d, unsi
   }
 }
 
-template <int D>
+// CAND = false: the sweep over every latent row (blockIdx * 256 + ...): idx, and for an ambiguous row a slot in
+//   `flagged` plus its minimum and band in fminb[2 slot], [2 slot + 1].
+// CAND = true: the same sweep over the FLAGGED rows only (row ids from `flagged`, one slot per lane): instead
+//   of the argmin it lists, per row, every code whose distance lies within the band of the row's minimum --
+//   the only codes the reference's arithmetic can prefer -- into cand[slot][VQ_CAP] (ccount[slot] entries;
+//   more than VQ_CAP: the row keeps count > VQ_CAP and takes the all-codes re-check).  The distances are
+//   the first pass's to the last bit (same fragments, same MFMA order).
+constexpr int VQ_CAP = 16;
+template <int D, bool CAND>
 __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
     const float* __restrict__ z, const uint4* __restrict__ Wp, const float* __restrict__ wn,
     const int* __restrict__ wmax_bits, int B, int T, int k,
-    int32_t* __restrict__ idx, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+    int32_t* __restrict__ idx, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag,
+    float* __restrict__ fminb, int32_t* __restrict__ cand, int32_t* __restrict__ ccount) {
   constexpr int TILE = 64, KS = D / 16;              // K steps of 16 c
   constexpr int ROW = D / 8 + 1;                     // 16-byte words per LDS row (+1: conflict-free fragment reads)
   constexpr int WPR = D / 8;                         // 16-byte words per code row in global memory
@@ -272,12 +281,21 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long N = (long)B * T;
-  const long n = (long)blockIdx.x * 256 + wave * 32 + li;      // this lane's latent column
+  long n = (long)blockIdx.x * 256 + wave * 32 + li;            // this lane's latent column (CAND: its slot)
+  const long slot = n;
+  float thr = 0.f;                                             // CAND: minimum + band of this row
+  bool ok_row = n < N;
+  if constexpr (CAND) {
+    ok_row = slot < (long)(*nflag);
+    if (!__syncthreads_or(ok_row ? 1 : 0)) return;             // this workgroup's slots are all beyond the list
+    n = ok_row ? (long)flagged[slot] : 0;
+    thr = ok_row ? fminb[2 * slot] + fminb[2 * slot + 1] : -INFINITY;
+  }
   // B fragment of K step s: lane (column li, half lk) holds c = 16 s + 8 lk .. + 7, split in three
   uint4 zh[KS], zm[KS], zl[KS];
   float zn = 0.f;
   {
-    const bool ok = n < N;
+    const bool ok = ok_row;
     const long bb = ok ? n / T : 0, t = ok ? n % T : 0;
     const float* zp = z + (bb * D) * T + t;
 #pragma unroll
@@ -362,13 +380,25 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
         const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (j < k) {
           const float v = fmaf(-2.f, h ? a1[r] : a0[r], wn[j]);
-          if (v < m1) { m2 = m1; m1 = v; i1 = j; }
-          else if (v < m2) { m2 = v; }
+          if constexpr (CAND) {
+            if (v <= thr) {                                    // (never for lanes without a row: thr = -inf)
+              const int c = atomicAdd(&ccount[slot], 1);
+              if (c < VQ_CAP) cand[slot * VQ_CAP + c] = j;
+            }
+          } else {
+            // (m1 <= m2) and a new value: the index moves only on a strict improvement (j ascends within
+            // a lane, so the first minimum is kept); runner-up = the median of the three -- 5 VALU per
+            // distance instead of the 7 of the compare / select ladder, beside 96 MFMAs per 32 distances
+            i1 = v < m1 ? j : i1;
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
+            m1 = fminf(m1, v);
+          }
         }
       }
     if (jt + 1 < ntile) store_tile(cur ^ 1);
     __syncthreads();
   }
+  if constexpr (CAND) return;
   {
     const float om1 = __shfl_xor(m1, 32, 64);
     const float om2 = __shfl_xor(m2, 32, 64);
@@ -381,9 +411,45 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
     const float band = 24.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {
-      const int slot = atomicAdd(nflag, 1);
-      flagged[slot] = (int32_t)n;
+      const int sl = atomicAdd(nflag, 1);
+      flagged[sl] = (int32_t)n;
+      fminb[2 * sl] = m1; fminb[2 * sl + 1] = band;
     }
+  }
+}
+
+// Exact re-check proportional to the ambiguity: one thread per flagged row evaluates, in the reference's
+// operation order (sequential over c; sub, mul, add individually rounded), only the codes the candidate
+// sweep listed, and keeps the smallest distance -- ties to the lowest index, whatever order the list is in.
+// Rows with more than VQ_CAP candidates (ties among many codes: a collapsed codebook, duplicate codes) go to
+// `overflow` for the all-codes re-check.
+__global__ __launch_bounds__(256) void vq_exact_cand_kernel(
+    const float* __restrict__ z, const float* __restrict__ W, int d, int T,
+    const int32_t* __restrict__ flagged, const int32_t* __restrict__ nflag, const int32_t* __restrict__ cand,
+    const int32_t* __restrict__ ccount, int32_t* __restrict__ idx, int32_t* __restrict__ overflow,
+    int32_t* __restrict__ noverflow) {
+  const long count = (long)(*nflag);
+  for (long sl = (long)blockIdx.x * blockDim.x + threadIdx.x; sl < count; sl += (long)gridDim.x * blockDim.x) {
+    const long n = flagged[sl];
+    const int nc = ccount[sl];
+    if (nc > VQ_CAP || nc <= 0) {        // (0 cannot happen: the row's own minimum is within its band)
+      overflow[atomicAdd(noverflow, 1)] = (int32_t)n;
+      continue;
+    }
+    const float* zp = z + ((n / T) * d) * (long)T + n % T;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = 0; q < nc; ++q) {
+      const int j = cand[sl * VQ_CAP + q];
+      const float* wr = W + (long)j * d;
+      float acc = 0.f;
+      for (int c = 0; c < d; ++c) {
+        const float df = __fsub_rn(zp[(long)c * T], wr[c]);
+        acc = __fadd_rn(acc, __fmul_rn(df, df));
+      }
+      if (acc < best || (acc == best && j < bi) || bi == 0x7fffffff) { best = acc; bi = j; }
+    }
+    idx[n] = bi;
   }
 }
 
@@ -772,7 +838,9 @@ using namespace vq;
 extern "C" size_t vqvae_vq_workspace_bytes(int B, int d, int T, int k) {
   const size_t N = (size_t)B * T;
   size_t fwd = align_up((size_t)k * 4, 256) + 256 /*wmax+nflag*/ + align_up(N * 4, 256) +
-               align_up((size_t)k * d * 6, 256) /*split codebook (matmul mode 2)*/;
+               align_up((size_t)k * d * 6, 256) /*split codebook (matmul mode 2)*/ +
+               // candidate re-check: (min, band) and count per flagged row, VQ_CAP candidates each, overflow list
+               align_up(N * 8, 256) + align_up(N * 4, 256) + align_up(N * 4 * VQ_CAP, 256) + align_up(N * 4, 256);
   // large-N codebook gradient: part64[k][SPLIT][d] | base[k+1] | cursor[nchunk][k] | sorted[N]
   const size_t nchunk = (N + VQ_GW_CHUNK - 1) / VQ_GW_CHUNK;
   size_t bwd = align_up((size_t)k * VQ_GW_SPLIT * d * 8, 256) + align_up(((size_t)k + 1) * 4, 256) +
@@ -793,7 +861,13 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
   int* wmax_bits = (int*)wp;
   int32_t* nflag = (int32_t*)(wp + 64); wp += 256;
   int32_t* flagged = (int32_t*)wp; wp += align_up((size_t)N * 4, 256);
-  unsigned* wsplit = (unsigned*)wp;
+  unsigned* wsplit = (unsigned*)wp; wp += align_up((size_t)k * d * 6, 256);
+  float* fminb = (float*)wp; wp += align_up((size_t)N * 8, 256);
+  int32_t* ccount = (int32_t*)wp; wp += align_up((size_t)N * 4, 256);
+  int32_t* cand = (int32_t*)wp; wp += align_up((size_t)N * 4 * VQ_CAP, 256);
+  int32_t* overflow = (int32_t*)wp;
+  int32_t* noverflow = nflag + 1;
+  bool cand_path = false;
   ProfScope ps(VQVAE_PROF_VQ_NEAREST, st);
   if (mode == 0) {
     const int dpad = (d + 1) / 2 * 2;
@@ -809,13 +883,23 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
       VQ_LAUNCH_CHECK();
       const size_t lds = 2 * 3 * 64 * (size_t)(d / 8 + 1) * 16;
       const unsigned grid = (unsigned)((N + 255) / 256);
-      if (d == 64) {
-        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vq_mfma_x3_kernel<64>, dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag);
-      } else {
-        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vq_mfma_x3_kernel<128>, dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag);
+      // the candidate pass pays when re-checking a row against all k codes costs more than sweeping it again
+      static const int cand_on = getenv("VQVAE_VQ_CAND") ? atoi(getenv("VQVAE_VQ_CAND")) : 1;
+      cand_path = cand_on && k >= 1024 && N >= 4096;
+      // the candidate sweep covers at most N/8 flagged rows per launch geometry; rows beyond are re-checked in full
+      const unsigned cgrid = (unsigned)((N / 8 + 255) / 256);
+      if (cand_path) VQ_CHECK_HIP(hipMemsetAsync(ccount, 0, (size_t)N * 4, st));
+#define VQ_X3_LAUNCH(Dv)                                                                                        \
+      {                                                                                                         \
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, false>), dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
+        if (cand_path) {                                                                                        \
+          VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+          hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, true>), dim3(cgrid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
+        }                                                                                                       \
       }
+      if (d == 64) VQ_X3_LAUNCH(64) else VQ_X3_LAUNCH(128)
+#undef VQ_X3_LAUNCH
       VQ_LAUNCH_CHECK();
     } else if (d == 64 || d == 128) {
       const size_t lds = 2 * 64 * (size_t)(d + 1) * 4;
@@ -844,6 +928,15 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     }
     VQ_LAUNCH_CHECK();
     }
+    const int32_t* list = flagged;
+    const int32_t* nlist = nflag;
+    if (cand_path) {
+      // flagged rows: the listed candidates only; rows with too many candidates (or beyond the candidate
+      // sweep's reach, which left their count at 0) fall through to the all-codes re-check below
+      hipLaunchKernelGGL(vq_exact_cand_kernel, dim3(1024), dim3(256), 0, st, z, W, d, T, flagged, nflag, cand, ccount, idx, overflow, noverflow);
+      VQ_LAUNCH_CHECK();
+      list = overflow; nlist = noverflow;
+    }
     {
       // exact re-check of the queued rows, 8 rows per workgroup pass
       constexpr int R = 8;
@@ -851,7 +944,7 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
       VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_exact_batched_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       const long maxb = (N + R - 1) / R;
       unsigned g2 = (unsigned)(maxb < 2048 ? maxb : 2048);
-      hipLaunchKernelGGL(vq_exact_batched_kernel<R>, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, flagged, nflag, idx);
+      hipLaunchKernelGGL(vq_exact_batched_kernel<R>, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, list, nlist, idx);
       VQ_LAUNCH_CHECK();
     }
     if (n_rechecked) VQ_CHECK_HIP(hipMemcpyAsync(n_rechecked, nflag, 4, hipMemcpyDeviceToDevice, st));
