@@ -557,7 +557,9 @@ def main():
                 'note': 'all-reduce time = HIP events around ncclAllReduce on its stream (includes waiting for the '
                         'slowest rank to arrive); rank_ms = each rank\'s own wall time per step before the closing barrier',
                 'cpu_affinity_rank0': affinity},
-            'dtype': 'bf16 operands, f32 accumulate' if args.bf16 else 'f32',
+            'dtype': ('bf16 operands, f32 accumulate' if args.bf16 else
+                      ('f32 (fp32 tensors; each fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate)'
+                       if mode == 'float32x3' else 'f32')),
             'matmul': {'bfloat16': 'operands rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulate',
                        'float32': 'v_mfma_f32_32x32x2_f32',
                        'float32x3': 'fp32 operands, fp32 results: each operand split EXACTLY into three bf16 '

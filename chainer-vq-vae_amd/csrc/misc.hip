@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void embed_bincount_kernel(const int32_t* __re
         const float v = g[t];
         for (int tap = 0; tap < K; ++tap) {
           const int ti = t - (K - 1 - tap);
-          if (ti >= 0) atomicAdd(&mine[tap * q + ib[ti]], v);
+          if (ti >= 0) { const int c = ib[ti]; if ((unsigned)c < (unsigned)q) atomicAdd(&mine[tap * q + c], v); }   // a class outside [0, q) has no one-hot row: no contribution, no stray LDS write
         }
       }
     }
@@ -760,10 +760,17 @@ __global__ __launch_bounds__(64 * BC_WAVES) void embed_bincount2x4_kernel(const 
     const long b = row / Cout;
     const int32_t* ib = idx + b * T;
     const float* g = gy + row * T;
+    const unsigned uq = (unsigned)q;           // a class outside [0, q) has no one-hot row: it contributes nothing
     auto add = [&](const float4 v, const int4 c, int cm) {
-      atomicAdd(&b1[c.x], v.x); atomicAdd(&b1[c.y], v.y); atomicAdd(&b1[c.z], v.z); atomicAdd(&b1[c.w], v.w);
-      if (cm >= 0) atomicAdd(&b0[cm], v.x);
-      atomicAdd(&b0[c.x], v.y); atomicAdd(&b0[c.y], v.z); atomicAdd(&b0[c.z], v.w);
+      const bool ox = (unsigned)c.x < uq, oy = (unsigned)c.y < uq, oz = (unsigned)c.z < uq, ow = (unsigned)c.w < uq;
+      if (ox) atomicAdd(&b1[c.x], v.x);
+      if (oy) atomicAdd(&b1[c.y], v.y);
+      if (oz) atomicAdd(&b1[c.z], v.z);
+      if (ow) atomicAdd(&b1[c.w], v.w);
+      if ((unsigned)cm < uq) atomicAdd(&b0[cm], v.x);
+      if (ox) atomicAdd(&b0[c.x], v.y);
+      if (oy) atomicAdd(&b0[c.y], v.z);
+      if (oz) atomicAdd(&b0[c.z], v.w);
     };
     int t = 4 * lane;
     for (; t + 256 < T; t += 512) {               // two independent chunks per iteration
@@ -1051,7 +1058,7 @@ int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* 
   int nb = (int)((rows + 3) / 4);
   if (nb > 2048) nb = 2048;
   const size_t lds2 = (size_t)BC_WAVES * BC_NCOPY * 2 * q * sizeof(float);
-  if (K == 2 && T % 4 == 0 && (((uintptr_t)gy) % 16 == 0) && lds2 <= 64 * 1024) {
+  if (K == 2 && T % 4 == 0 && (((uintptr_t)gy) % 16 == 0) && (((uintptr_t)idx) % 16 == 0) && lds2 <= 64 * 1024) {   // int4 loads of idx, float4 loads of gy
     int nb2 = (int)((rows + BC_WAVES - 1) / BC_WAVES);
     if (nb2 > 4096) nb2 = 4096;
     hipLaunchKernelGGL(embed_bincount2x4_kernel, dim3(nb2), dim3(64 * BC_WAVES), lds2, st, idx, gy, B, Cout, q, T, part, flag);

@@ -35,7 +35,8 @@ def init(device=0):
     _lib.call('vqvae_stream_create', C.byref(s))
     _state['stream'] = s
     _state['device'] = device
-    set_matmul_dtype(default_matmul_dtype())
+    if not _state.get('matmul_explicit'):          # a mode chosen before init() stays
+        _set_matmul_code(_MATMUL_CODES[default_matmul_dtype()])
 
 
 def available():
@@ -117,18 +118,39 @@ def wait_event(s, event):
     _lib.call('vqvae_stream_wait_event', s, event.h)
 
 
+_MATMUL_CODES = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3': 2, 'fp32x3': 2}
+
+
 def default_matmul_dtype():
     """The matmul mode a process starts in: $VQVAE_MATMUL if set, else 'float32x3' (fp32 products
-    on the bf16 matrix pipe; as accurate as 'float32', the fp32 MFMA path, and 1.3x faster)."""
-    return os.environ.get('VQVAE_MATMUL', 'float32x3')
+    on the bf16 matrix pipe; as accurate as 'float32', the fp32 MFMA path, and 1.4x faster)."""
+    name = os.environ.get('VQVAE_MATMUL', 'float32x3')
+    if name not in _MATMUL_CODES:
+        raise ValueError('VQVAE_MATMUL=%r: expected one of %s' % (name, sorted(_MATMUL_CODES)))
+    return name
+
+
+def _set_matmul_code(code):
+    _lib.call('vqvae_set_matmul_dtype', code)
 
 
 def set_matmul_dtype(name):
     """'float32' (fp32 MFMA), 'bfloat16' (operands rounded to bf16, fp32 accumulate) or
     'float32x3' (fp32 products as six bf16 MFMA products of an exact three-way operand split:
-    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2")."""
-    code = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3': 2, 'fp32x3': 2}[name]
-    _lib.call('vqvae_set_matmul_dtype', code)
+    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2").
+    An explicit choice survives a later backend.init(); workspace sizes depend on the mode, so
+    choose it before building workspaces.
+
+    Non-finite operands.  'float32x3' splits x into bf16(x) + bf16(x - bf16(x)) + ...: an operand
+    that is +-Inf gives Inf - Inf = NaN in the remainder, and a finite |x| above ~3.39e38 rounds its
+    high piece to Inf, so both produce NaN where the fp32 MFMA path gives +-Inf or a finite value.
+    The path's tensors (audio in [-1, 1], LeCun-scaled weights, their gradients) stay far from that
+    range; a caller that needs IEEE Inf propagation through a conv should use 'float32'
+    (tests/test_gpu_kernels.py::test_float32x3_nonfinite_operands pins the behaviour)."""
+    if name not in _MATMUL_CODES:
+        raise ValueError('set_matmul_dtype(%r): expected one of %s' % (name, sorted(_MATMUL_CODES)))
+    _state['matmul_explicit'] = True
+    _set_matmul_code(_MATMUL_CODES[name])
 
 
 def synchronize():

@@ -122,11 +122,28 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         # parameters created during this forward (lazily shaped links, net.py:34-43) join the
         # flat arenas BEFORE the exchange, so their gradients are summed like everyone else's
         adopt = getattr(optimizer, 'adopt_new_params', None)
-        if adopt is not None:
-            adopt()
+        if adopt is not None and adopt() and n > 1:
+            self._check_replicas(optimizer)
         if exchange:
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place
         optimizer.update()
+
+    def _check_replicas(self, optimizer):
+        """Parameters adopted after setup (lazily shaped links) were initialised by each rank's own
+        initializer stream, and nothing broadcasts parameters here (the reference's copyparams,
+        updaters.py:76-77, is replaced by "identical update on identical replicas"): verify the
+        premise when it can break -- the sum of the parameter arena must be the same on every rank."""
+        from . import _lib
+        tot = backend.zeros((1,), np.float32)
+        ws = backend.workspace(4096 * 4)
+        _lib.call('vqvae_sum', optimizer.params.ptr, optimizer.n_train, 1.0, tot.ptr, ws.ptr, ws.nbytes,
+                  backend.stream())
+        v = float(tot.get()[0])
+        hi, lo = self.comm.max_scalar(v), -self.comm.max_scalar(-v)
+        if hi != lo:
+            raise RuntimeError('data-parallel replicas diverged: parameter checksum %r..%r across ranks after '
+                               'lazily shaped parameters were created -- seed the initializers identically on '
+                               'every rank (core.seed_initializers) or load the same snapshot' % (lo, hi))
 
     def _update_overlapped(self, optimizer, model):
         """three_loss_backward with the exchange of the early bucket on the side stream."""
@@ -135,8 +152,8 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         loss1.backward()
         model.vq.cleargrads()
         adopt = getattr(optimizer, 'adopt_new_params', None)
-        if adopt is not None:
-            adopt()
+        if adopt is not None and adopt() and self.comm.size > 1:
+            self._check_replicas(optimizer)
         early, late = self._grad_buckets(optimizer)
         main, side = backend.stream(), backend.side_stream()
         backend.wait_event(side, backend.Event().record(main))      # loss1's gradients are complete

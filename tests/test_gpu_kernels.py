@@ -184,6 +184,32 @@ def test_vq_golden(gpu, matmul_mode, name, mode):
         assert nre > 0                                    # ties must take the exact path
 
 
+def test_float32x3_nonfinite_operands(gpu):
+    """Documented corner of matmul mode 'float32x3' (backend.set_matmul_dtype): the three-way split
+    computes x - bf16(x), so an Inf operand becomes NaN (Inf - Inf) where the fp32 MFMA mode
+    propagates +-Inf; values up to 1e37 are exact in both.  Pinned so that a change of behaviour is a
+    decision, not an accident."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    W = np.zeros((16, 16, 1), np.float32)
+    W[np.arange(16), np.arange(16), 0] = 1.0                      # identity 1x1 conv
+    x = np.zeros((1, 16, 64), np.float32)
+    x[0, 3, 5] = 1e37
+    x[0, 4, 6] = np.inf
+
+    def run(mode):
+        gpu.set_matmul_dtype(mode)
+        try:
+            return F.convolution_1d(Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), None).data.get()[0, :, :, 0]
+        finally:
+            gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+    y32, y3 = run('float32'), run('float32x3')
+    assert y32[3, 5] == np.float32(1e37) and y3[3, 5] == np.float32(1e37)
+    assert np.isposinf(y32[4, 6])
+    assert np.isnan(y3[4, 6])                                     # Inf - Inf in the remainder pieces
+    assert np.isfinite(y3[:, :6]).all() and np.isfinite(y3[:, 7:]).all()     # the other columns never see the Inf
+
+
 def test_vq_near_ties_around_the_certainty_band(gpu, matmul_mode):
     """Adversarial rows for the MFMA search's CERTAIN / re-check decision (vq.hip): every latent row
     has its own pair of codes whose reference-order distances differ by a chosen multiple of the
