@@ -740,6 +740,9 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 // fetch of a group's rows then follows the first by one step and is served by L1 / L2 instead of HBM /
 // MALL (round 1's gate kernel read x 2.09 times from the fabric); for any pair, both segments advance
 // by the same scalar offsets and the loop never re-runs the per-segment setup.
+#ifndef X3_FAKE_HALF
+#define X3_FAKE_HALF 0        // timing experiment only (wrong results): odd K steps stage without the bf16 split
+#endif
 template <int EPI, int WM, int NB, int NP, bool TAP2 = false>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
     unsigned pc[3][CPT / 2];                                   /* [piece][channel pair] */   \
     _Pragma("unroll") for (int e = 0; e < CPT; e += 2) {                                     \
       const float v0 = BV[e], v1 = BV[e + 1];          /* out-of-range elements arrived as 0 */ \
-      if constexpr (NP == 3) split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);       \
+      if constexpr (NP == 3) { if (X3_FAKE_HALF && (BUF) == 1) { pc[0][e / 2] = __builtin_bit_cast(unsigned, v0); pc[1][e / 2] = __builtin_bit_cast(unsigned, v1); pc[2][e / 2] = 0u; } else split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); } \
       else pc[0][e / 2] = pack_bf16x2(v0, v1);                                               \
     }                                                                                        \
     _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                         \

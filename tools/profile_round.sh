@@ -3,7 +3,7 @@
 #   kernel-trace stats of bench.py for c2 (default), c4, c5 --bf16, and separate --pmc passes
 #   (FETCH_SIZE / WRITE_SIZE / MFMA busy / instruction mix) for the dominant kernel of each.
 # usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
@@ -37,5 +37,5 @@ run_pmc c4_pmc_MFMA "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload c4 --s
 run_pmc c5_bf16_pmc_FETCH_SIZE FETCH_SIZE --workload c5 --bf16 --steps 2 --warmup 1
 run_pmc c5_bf16_pmc_WRITE_SIZE WRITE_SIZE --workload c5 --bf16 --steps 2 --warmup 1
 run_pmc c5_bf16_pmc_MFMA "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload c5 --bf16 --steps 2 --warmup 1
-ls -la $OUT | head -40
+ls $OUT | head -60
 for n in c2 c4 c5_bf16; do echo "== $n"; head -6 $OUT/${n}_kernel_stats.csv | cut -c1-150; done
