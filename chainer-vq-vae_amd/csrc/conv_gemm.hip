@@ -743,6 +743,9 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 #ifndef X3_FAKE_HALF
 #define X3_FAKE_HALF 0        // timing experiment only (wrong results): odd K steps stage without the bf16 split
 #endif
+#ifndef X3_ABL
+#define X3_ABL 0              // timing experiments only (wrong results): 1 no activation loads, 2 no weight loads, 3 no fragment reads, 4 no LDS writes, 5 no barrier-separated staging at all (1+2+4)
+#endif
 template <int EPI, int WM, int NB, int NP, bool TAP2 = false>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
@@ -865,19 +868,26 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   float pb[CPT], qb[CPT];
   unsigned pmask = 0, qmask = 0;           // (unused since the buffer loads: kept so that the staging macro's signature is unchanged)
 #define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw, vb, rx, !TAP2)
-#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, vb1, rx1, false)
+#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, (X3_ABL == 9 ? 0x80000000u : vb1), rx1, false)   /* ABL 9 (timing only): the second tap's activations are not fetched (every load out of range) */
 #define X3_FETCH_(A0, A1, A2, BV, SW, VB, RX, ADV)                                           \
   {                                                                                          \
+    if (X3_ABL == 2 || X3_ABL == 5) { A0 = make_uint4(va, 1u, 2u, 3u); A1 = A0; A2 = A0; } else {  \
     A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));  \
     if constexpr (NP == 3) {                                                                 \
       A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
       A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
-    }                                                                                        \
-    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = buf_ld(RX, (VB), sx + (unsigned)e * xcsb); \
+    } }                                                                                      \
+    if (X3_ABL == 8 && CPT == 8) {  /* timing only: the same bytes as two 16-byte loads per thread (no transpose: wrong results) */ \
+      const unsigned vq_ = ((VB) & 0x80000000u) ? (VB) : ((VB) - 4u * (unsigned)(tid & 3)) + (unsigned)(2 * (tid & 3)) * xcsb; \
+      const float4 l0_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(RX, vq_, sx, 0)); \
+      const float4 l1_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(RX, vq_, sx + xcsb, 0)); \
+      BV[0] = l0_.x; BV[1] = l0_.y; BV[2] = l0_.z; BV[3] = l0_.w; BV[4] = l1_.x; BV[5] = l1_.y; BV[6] = l1_.z; BV[7] = l1_.w; \
+    } else                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = (X3_ABL == 1 || X3_ABL == 5) ? __builtin_bit_cast(float, (VB) + (unsigned)e) : (X3_ABL == 6 ? buf_ld(RX, 0u, 0u) : (X3_ABL == 7 ? buf_ld(RX, ((VB) & 0x7fffffffu) % 4096u, 0u) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb))); \
     if (!SCHED && (ADV)) advance();                                                          \
   }
 #define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
-  {                                                                                          \
+  if (!((X3_ABL == 4 || X3_ABL == 5) && left < nsteps - 2)) {        /* ablation: only the first steps stage */ \
     uint4* ad = &As[BUF][0][0][0];                                                           \
     ad[tid] = A0;                                                                            \
     if constexpr (NP == 3) { ad[NT + tid] = A1; ad[2 * NT + tid] = A2; }                     \
@@ -903,8 +913,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if (X3_ABL == 3) {
+          af[i][p] = __builtin_bit_cast(bf16x8, make_uint4(tid + i, p, acc[0][0][0] > 1e30f ? 1u : 0u, 3u));
+          bf[i][p] = af[i][p];
+        } else {
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+        }
       }
     auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) bg[i][p] = X3_ABL == 3 ? bf[i][p] : __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
       block(acc2, bg);
     }
     if (SCHED) {
@@ -978,6 +993,181 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   if constexpr (NB == 2) {
     if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
+}
+
+// ---------------------------------------------------------------------------
+// conv_win_x3_kernel -- the two taps of a dilated conv from ONE staged activation window
+// (WaveNet/modules.py:13-16, 40-41: forward, and its backward-data).
+//
+// conv_gemm_x3_kernel<.., TAP2> alternates the taps channel group by channel group, but still fetches,
+// splits and stages the activations of a 16-channel group twice -- once per tap, shifted by the dilation.
+// For dilation < tile width the two 256-column windows overlap in 256 - dil columns.  The ablation of the
+// K loop (tools/abl.sh: parts of the loop compiled out, full chip) puts the activation fetch at ~20 % of
+// the kernel at full load -- the bytes delivered through the vector memory path, not the instruction count
+// (one broadcast address: free; the same loads at distinct L1-resident addresses: nearly the full cost) and
+// not the split (-1.3 % with it compiled out) -- so here every activation element crosses that path ONCE
+// per tile: per 16-channel group the workgroup stages a window of W = 256 + dil columns ([piece][k-half][w]
+// 16-byte words, thread = window column, all threads stage k-half (step & 1)), and the MFMA B fragments of
+// tap j are read from it at column offset o_j (0 or dil) -- the dilation gather is an LDS offset.
+//
+// Schedule (one barrier per K step, as before).  Step s = 2g + tap: A(s) from As[s & 1], window g from
+// Bw[g & 1].  Staged during step s: A(s + 1) and the k-half (s & 1) of window g + 1, i.e. the 8-channel
+// half-group c8 = s + 2; fetched at the top of step s (one step before it is staged): A(s + 2) and
+// half-group c8 = s + 3.  Threads beyond the window (tid >= W) fetch with an out-of-range offset and
+// stage nothing.  256 x 256 tiles, 8 waves; LDS 48 KB (A, two steps) + 2 x 36 KB (two windows of up to
+// 384 columns).  The K order (tap-interleaved) and the products are those of the TAP2 kernel: the results
+// are identical to the last bit.
+// ---------------------------------------------------------------------------
+constexpr int WIN_MAX_DIL = 128, WIN_W = 256 + WIN_MAX_DIL;
+template <int EPI, int NP>
+__global__ __launch_bounds__(512, 2) void conv_win_x3_kernel(const GemmArgs a) {
+  constexpr int BM = 256, NT = 512;
+  __shared__ uint4 As[2][NP][2][BM];
+  __shared__ uint4 Bw[2][NP][2][WIN_W];
+  const int nblk = gridDim.x;
+  int logical;
+  {
+    const int id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int mt = logical % a.ntile_m;
+  const int rest = logical / a.ntile_m;
+  const int nt = rest % a.ntile_n;
+  const int b = rest / a.ntile_n;
+  const int m0 = mt * BM, t0 = nt * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2], acc2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+
+  const Seg& s0 = a.seg[0];
+  const Seg& s1 = a.seg[1];
+  const int nsteps = 2 * (s0.cin / BK);                      // host: cin % 16 == 0, both segments alike
+  const int lo = min(s0.toff, s1.toff);
+  const int W = 256 + (max(s0.toff, s1.toff) - lo);          // window columns: [t0 + lo, t0 + lo + W)
+  const unsigned o0 = (unsigned)(s0.toff - lo), o1 = (unsigned)(s1.toff - lo);   // fragment column offsets of the taps
+  // ---- fetch state: buffer descriptors + per-thread offsets (fixed) + scalar offsets (walk the K steps)
+  constexpr unsigned OOB = 0x80000000u;
+  const rsrc_t rw = make_rsrc(s0.w);
+  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s0.x + (long)b * s0.x_bstride), 0,
+                                                      (int)(4u * (unsigned)s0.cin * (unsigned)s0.x_cstride), 0x00020000);
+  const int a_hi = tid / BM, a_m = tid % BM;
+  const unsigned va = 16u * (unsigned)(a_hi * s0.ldw + m0 + a_m);
+  const unsigned wl2b = 32u * (unsigned)s0.ldw, wadvb = 32u * NP * (unsigned)s0.ldw;
+  const unsigned xcsb = 4u * (unsigned)s0.x_cstride;
+  const unsigned sw1 = (unsigned)(reinterpret_cast<const char*>(s1.w) - reinterpret_cast<const char*>(s0.w));
+  const int tin = t0 + lo + tid;                             // this thread's window column in the input row
+  const bool stager = tid < W;
+  const unsigned vb = (stager && tin >= 0 && tin < s0.Tin) ? 4u * (unsigned)tin : OOB;
+  unsigned sw = 0;                                           // weight slab offset of the next channel group
+  unsigned sx = 0;                                           // byte offset of the next 8-channel half-group
+  int c8 = 0;                                                // ... and its index (clamped at the last one)
+  const int c8_last = nsteps - 1;                            // half-groups 0 .. 2 G - 1
+  uint4 pa0, pa1, pa2, qa0, qa1, qa2;
+  float pb[8], qb[8];
+#define WIN_FETCH_B(BV)                                                                        \
+  {                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) BV[e] = buf_ld(rx, vb, sx + (unsigned)e * xcsb); \
+    const bool more_ = c8 < c8_last;          /* past the end: re-read the last half-group (staged into a window nobody reads) */ \
+    c8 += more_ ? 1 : 0; sx += more_ ? 8u * xcsb : 0u;                                         \
+  }
+#define WIN_FETCH_A(A0, A1, A2, SW)                                                            \
+  {                                                                                            \
+    A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));    \
+    if constexpr (NP == 3) {                                                                   \
+      A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
+      A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
+    }                                                                                          \
+  }
+#define WIN_STAGE_A(A0, A1, A2, ABUF)                                                          \
+  {                                                                                            \
+    uint4* ad = &As[ABUF][0][0][0];                                                            \
+    ad[tid] = A0;                                                                              \
+    if constexpr (NP == 3) { ad[NT + tid] = A1; ad[2 * NT + tid] = A2; }                       \
+  }
+#define WIN_STAGE_B(BV, WBUF, KH)                                                              \
+  if (stager) {                                                                                \
+    unsigned pc[3][4];                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; e += 2) {                                         \
+      if constexpr (NP == 3) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
+      else pc[0][e / 2] = pack_bf16x2(BV[e], BV[e + 1]);                                       \
+    }                                                                                          \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) Bw[WBUF][p][KH][tid] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]); \
+  }
+  // one K step: fragments of A from As[ABUF], of the window WBUF at the tap's column offset OFS
+#define WIN_MMA(ABUF, WBUF, OFS)                                                               \
+  {                                                                                            \
+    bf16x8 af[2][NP], bf[2][NP], bg[2][NP];                                                    \
+    const uint4* bb = &Bw[WBUF][0][lk][(OFS) + wn * 64 + li];                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+      _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                         \
+        af[i][p] = __builtin_bit_cast(bf16x8, As[ABUF][p][lk][wm * 64 + i * 32 + li]);         \
+        bf[i][p] = __builtin_bit_cast(bf16x8, bb[p * 2 * WIN_W + i * 32]);                     \
+        bg[i][p] = __builtin_bit_cast(bf16x8, bb[p * 2 * WIN_W + 128 + i * 32]);               \
+      }                                                                                        \
+    WIN_CHAIN(acc, bf);                                                                        \
+    WIN_CHAIN(acc2, bg);                                                                       \
+  }
+#define WIN_CHAIN(ACC, FB)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+        f32x16 c = ACC[i][j];                                                                  \
+        if constexpr (NP == 3) {                               /* small products first */      \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], FB[j][0], c, 0, 0, 0);         \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][2], c, 0, 0, 0);         \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], FB[j][1], c, 0, 0, 0);         \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], FB[j][0], c, 0, 0, 0);         \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][1], c, 0, 0, 0);         \
+        }                                                                                      \
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][0], c, 0, 0, 0);           \
+        ACC[i][j] = c;                                                                         \
+      }
+
+  // ---- prologue: window 0 (half-groups 0, 1) and A(0) staged; {A(1), half-group 2} in flight in set Q
+  WIN_FETCH_B(pb);                                            // c8 = 0
+  WIN_FETCH_B(qb);                                            // c8 = 1
+  WIN_FETCH_A(pa0, pa1, pa2, sw);                             // A(0): tap 0, group 0
+  WIN_STAGE_A(pa0, pa1, pa2, 0);
+  WIN_STAGE_B(pb, 0, 0);
+  WIN_STAGE_B(qb, 0, 1);
+  WIN_FETCH_A(qa0, qa1, qa2, sw + sw1);                       // A(1): tap 1, group 0
+  WIN_FETCH_B(qb);                                            // c8 = 2
+  sw += (nsteps > 2) ? wadvb : 0u;
+  __syncthreads();
+  // top of a pair (s even = 2 g): As[0] holds A(s), Bw[g & 1] window g; set Q holds {A(s + 1), half-group s + 2}
+  int wcur = 0;                                               // g & 1
+  for (int s = 0; s < nsteps; s += 2) {
+    const int wnxt = wcur ^ 1;
+    WIN_FETCH_A(pa0, pa1, pa2, sw);                           // A(s + 2): tap 0 of group g + 1
+    WIN_FETCH_B(pb);                                          // half-group s + 3
+    WIN_MMA(0, wcur, o0);                                     // step s: tap 0
+    WIN_STAGE_A(qa0, qa1, qa2, 1);                            // A(s + 1)
+    WIN_STAGE_B(qb, wnxt, 0);                                 // half-group s + 2 = k-half 0 of window g + 1
+    __syncthreads();
+    WIN_FETCH_A(qa0, qa1, qa2, sw + sw1);                     // A(s + 3): tap 1 of group g + 1
+    WIN_FETCH_B(qb);                                          // half-group s + 4
+    sw += (s + 4 < nsteps) ? wadvb : 0u;                      // the group after the next (never beyond the last)
+    WIN_MMA(1, wcur, o1);                                     // step s + 1: tap 1
+    WIN_STAGE_A(pa0, pa1, pa2, 0);                            // A(s + 2)
+    WIN_STAGE_B(pb, wnxt, 1);                                 // half-group s + 3 = k-half 1 of window g + 1
+    __syncthreads();
+    wcur = wnxt;
+  }
+#undef WIN_FETCH_B
+#undef WIN_FETCH_A
+#undef WIN_STAGE_A
+#undef WIN_STAGE_B
+#undef WIN_MMA
+#undef WIN_CHAIN
+  gemm_epilogue<EPI, 4, false, true>(a, acc, m0, t0, b, wm, wn, li, lk, 0, logical, 0);
+  if (t0 + BN < a.Tout) gemm_epilogue<EPI, 4, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, logical, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1857,8 +2047,13 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if (X3_ABL == 3) {
+          af[i][p] = __builtin_bit_cast(bf16x8, make_uint4(tid + i, p, acc[0][0][0] > 1e30f ? 1u : 0u, 3u));
+          bf[i][p] = af[i][p];
+        } else {
         af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
         bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
+        }
       }
     auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
@@ -1883,7 +2078,7 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bg[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) bg[i][p] = X3_ABL == 3 ? bf[i][p] : __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
       block(acc2, bg);
     }
   };
@@ -2160,6 +2355,20 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   } while (0)
   // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
   // not instantiated
+  // both taps of ONE tensor, dilation <= WIN_MAX_DIL, 256 x 256 tiles: one staged window per channel group.
+  // (Depends on the contraction and on `wide`, which depends on the launch size -- but the window kernel's K
+  // order and products are the TAP2 kernel's, so the choice never changes a result.)
+  static const int x3_win = getenv("VQVAE_X3_WIN") ? atoi(getenv("VQVAE_X3_WIN")) : 1;
+  if constexpr (EPI != EPI_GATE_BWD) {
+    const int ddil = g.nseg == 2 ? abs(g.seg[0].toff - g.seg[1].toff) : 0;
+    if (x3_win && tap2 && wide && g.seg[0].x == g.seg[1].x && g.seg[0].tmul == 1 && g.seg[0].tdiv == 1 &&
+        ddil >= 1 && ddil <= WIN_MAX_DIL && g.skip_flag == nullptr) {
+      if (g_matmul_dtype == 2) hipLaunchKernelGGL((conv_win_x3_kernel<EPI, 3>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((conv_win_x3_kernel<EPI, 1>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+      VQ_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if constexpr (EPI != EPI_GATE_BWD) {
     if (big && g_matmul_dtype == 2) {
       if (wide) X3_LAUNCH(4, 2, 3, nblk2, 512);

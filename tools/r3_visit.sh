@@ -38,6 +38,8 @@ for step in "$@"; do
     convtests) timeout 1200 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -5 ;;
     w3nc) kstats w3nc2 VQVAE_W3_NC=2 ;;
     modeltests) timeout 1500 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_model.py tests/test_gpu_configs.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -5 ;;
+    wintests) timeout 1500 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_fullsize.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -5 ;;
+    winab) kstats win1 VQVAE_X3_WIN=1; kstats win0 VQVAE_X3_WIN=0; kstats win1b VQVAE_X3_WIN=1; kstats win0b VQVAE_X3_WIN=0 ;;
     occ) VQVAE_X3_NB=3 python tools/occ_scaling.py 2>&1 | grep '^B' ;;
     pp) timeout 900 python -m pytest tests/test_gpu_bench_shapes.py::test_resblock_b16_vs_oracle tests/test_gpu_kernels.py::test_conv1d_fwd_bwd tests/test_gpu_kernels.py::test_resblock_fwd_bwd -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -5; VQVAE_X3_NB=3 python tools/occ_scaling.py 2>&1 | grep '^B'; kstats pp1 VQVAE_X3_PP=1; kstats pp0 VQVAE_X3_PP=0 ;;
     kstats) kstats default A=1 ;;
