@@ -173,7 +173,9 @@ size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d);
 /* res may be NULL (last block: residual unused, modules.py:89-96).  skip is
  * overwritten, or accumulated into when skip_accumulate != 0 (modules.py:92-95);
  * skip may be NULL too (ResidualNet computes the skip sum with vqvae_resstack_skip_fwd).
- * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd.
+ * gates (B,Cd,T) = [tanh(h_a) | sigmoid(h_b)] and z (B,Cd/2,T) are saved for bwd.  z is OPAQUE to
+ * the caller: it is only ever handed back to this library (skip sum, weight gradients), and in matmul
+ * mode 1 (bf16 operands) the configs-sized blocks keep it as bf16 inside the same buffer.
  * With cproj != NULL, cond / Wc / bc are ignored (may be NULL).                       */
 int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                        const float* x, const float* cond, const vqvae_resblock_cproj* cproj,
