@@ -18,11 +18,20 @@ sys.path.insert(0, ROOT)
 
 
 def mean_of(path, pat, col):
+    """Dispatch-weighted mean of `col` over the kernels matching any of the '|'-separated patterns (the
+    gate launches of a step are served by two kernels: the single-window one for dilations <= 128 and the
+    tap-interleaved one for the rest)."""
+    pats = pat.split('|')
+    tot, n = 0.0, 0
     with open(path) as f:
         for row in csv.DictReader(f):
-            if pat in row['kernel']:
-                return float(row[col]), int(row['dispatches'])
-    raise SystemExit('%s: no kernel matching %r' % (path, pat))
+            if any(p in row['kernel'] for p in pats):
+                d = int(row['dispatches'])
+                tot += float(row[col]) * d
+                n += d
+    if n == 0:
+        raise SystemExit('%s: no kernel matching %r' % (path, pat))
+    return tot / n, n
 
 
 def main():
