@@ -162,3 +162,45 @@ def test_config1_whole_step_matches_oracle(gpu):
     for name, arr in O.flatten_params(P):
         dn = H._dev_name(name, True)
         assert_close(named[dn].data.get().reshape(arr.shape), arr, 1e-4, 'configs[1] param ' + dn)
+
+
+def test_pack_once_equals_pack_per_call(gpu):
+    """ResidualNet packs the weight slabs of all its blocks once per step (vqvae_resstack_pack + the _packed entry
+    points); the stand-alone entry points pack inside every call.  Same slabs, same kernels: the skip output and every
+    gradient must agree bit for bit."""
+    from vqvae_amd import functions as F, wavenet
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualStackFunction
+    dils, Bq, Tq, Cl, G, nspk = [1, 2, 4], 2, 512, 16, 16, 3
+    rs = np.random.RandomState(11)
+    blocks = [_rb_params(rs, 64, 64, 64, Cl + G, 2) for _ in dils]
+    x = rs.standard_normal((Bq, 64, Tq)).astype(np.float32)
+    local = rs.standard_normal((Bq, Cl, Tq // 64)).astype(np.float32)
+    E = rs.standard_normal((nspk, G)).astype(np.float32)
+    ids = rs.randint(0, nspk, Bq).astype(np.int32)
+    gy = rs.standard_normal((Bq, 64, Tq)).astype(np.float32)
+    order = ['conv', 'condition_proj', 'res', 'skip']
+
+    def run(pack_once):
+        old = wavenet.PACK_ONCE
+        wavenet.PACK_ONCE = pack_once
+        try:
+            vx = Variable(_dev(gpu, to4(x)))
+            vcond = F.condition_assemble(Variable(_dev(gpu, to4(local))), Variable(_dev(gpu, E)), _dev(gpu, ids), 64)
+            pv = []
+            for blk in blocks:
+                for n in order:
+                    pv += [Variable(_dev(gpu, to4(blk[n][0]))), Variable(_dev(gpu, blk[n][1]))]
+            skip = ResidualStackFunction(dils).apply([vx, vcond] + pv)[0]
+            out = [skip.data.get()]
+            skip.grad = _dev(gpu, to4(gy))
+            skip.backward()
+            out.append(vx.grad.get())
+            out += [v.grad.get() for v in pv if v.grad is not None]
+            return out
+        finally:
+            wavenet.PACK_ONCE = old
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and len(a) > 20
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
