@@ -1,5 +1,7 @@
-"""Slot timing of the ping-pong conv kernel (library built with `make EXTRA=-DX3_PROF`): shader-clock stamps of
-workgroup 0, waves 0 and 4, K steps 8..15 of one dilated-conv launch.
+"""Slot timing of the PING-PONG EXPERIMENT's conv kernel (not the product): apply
+tools/experiments/conv_gemm_pingpong.patch to conv_gemm.hip of commit b3f89f9, build with `make EXTRA=-DX3_PROF`,
+then run this: it prints the shader-clock stamps that workgroup 0 recorded at the barriers of K steps 8..15 of one
+dilated-conv launch (fetch / fragment reads / stage / barrier / MFMA issue / barrier, all eight waves).
 usage: VQVAE_X3_NB=3 python tools/pp_prof.py [B]"""
 import ctypes as C
 import os
