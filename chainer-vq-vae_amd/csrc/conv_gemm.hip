@@ -2797,7 +2797,8 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
 // identical results, 31.5 MB less per launch that touches it at configs[4].  VQVAE_Z16=0 keeps it fp32.
 static bool z_bf16(const vqvae_resblock_desc* d) {
   static const int on = getenv("VQVAE_Z16") ? atoi(getenv("VQVAE_Z16")) : 1;
-  return on && g_matmul_dtype == 1 && d->Cd / 2 == 128 && d->Cr == 256 && d->Cs % 256 == 0 && d->T % 64 == 0;
+  return on && g_matmul_dtype == 1 && d->Cd / 2 == 128 && d->Cr == 256 && d->Cs % 256 == 0 && d->T % 64 == 0 &&
+         (long)d->B * (d->Cr > d->Cs ? d->Cr : d->Cs) * d->T * 4 < (1L << 31);     // the bf16-reading kernels address with 32-bit offsets
 }
 
 static int check_rb(const vqvae_resblock_desc* d) {
