@@ -2331,6 +2331,9 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     fprintf(stderr, "[gemm] epi %d M %d Tout %d B %d nseg %d K %d blocks %ld tag %d tmul %d tdiv %d\n", EPI, g.M, g.Tout, g.B, g.nseg, ktot, nblk, tag, g.seg[0].tmul, g.seg[0].tdiv);
   }
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
+  if (g_matmul_dtype != 0)          // modes 1 / 2 address a batch item's activations with 32-bit buffer offsets
+    for (int i = 0; i < g.nseg; ++i)
+      VQ_REQUIRE((long)g.seg[i].cin * g.seg[i].x_cstride * 4 < (1L << 31), "conv_gemm: one batch item of segment %d exceeds 2 GB (Cin * T * 4 bytes)", i);
   // split-K when the caller provided a partial-tile buffer and the shape calls for it
   int nk = 0;
   for (int i = 0; i < g.nseg; ++i) nk += cdiv(g.seg[i].cin, BK);
