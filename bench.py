@@ -91,12 +91,11 @@ class ResidentIterator(object):
     """Yields this rank's shard as device-resident arrays (already concatenated):
     the timed region starts with inputs in HBM."""
 
+    yields_rank_shard = True      # VQVAE_ParallelUpdater takes next() as this rank's shard, no batch[rank::n] on a global batch
+
     class _Shard(object):
         def __init__(self, arrays):
             self.arrays = arrays
-
-        def __getitem__(self, sl):       # batch[rank::n] -- this IS the rank's shard
-            return self
 
     def __init__(self, shards):
         self.shards = [self._Shard(s) for s in shards]

@@ -109,7 +109,11 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         optimizer = self.get_optimizer('main')
         model = optimizer.target
         n = self.comm.size
-        shard = strided_shard(self.get_iterator('main').next(), self.comm.rank, n)   # batch[rank::n]
+        it = self.get_iterator('main')
+        if getattr(it, 'yields_rank_shard', False):
+            shard = it.next()        # the iterator already produces batch[rank::n] only (no rank builds the global batch)
+        else:
+            shard = strided_shard(it.next(), self.comm.rank, n)   # batch[rank::n], as the reference (updaters.py:37-38)
         in_arrays = self.converter(shard, self.device)
 
         with core.force_backprop_mode():
