@@ -204,3 +204,80 @@ def test_pack_once_equals_pack_per_call(gpu):
     assert len(a) == len(b) and len(a) > 20
     for u, v in zip(a, b):
         np.testing.assert_array_equal(u, v)
+
+
+_WIN_WORKER = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(sys.argv[1], 'chainer-vq-vae_amd')]
+from vqvae_amd import backend as gpu, functions as F
+from vqvae_amd.core import Variable
+gpu.init(0)
+rs = np.random.RandomState(5)
+B, C, T, dil = 9, 256, 7680, int(sys.argv[2])
+x = Variable(gpu.to_device(rs.standard_normal((B, C, T, 1)).astype(np.float32)))
+W = Variable(gpu.to_device((rs.standard_normal((C, C, 2, 1)) / 22).astype(np.float32)))
+b = Variable(gpu.to_device(rs.standard_normal(C).astype(np.float32)))
+y = F.convolution_1d(x, W, b, pad=dil, dilate=dil, out_len=T)
+y.grad = gpu.to_device(rs.standard_normal((B, C, T, 1)).astype(np.float32))
+y.backward()
+h = hashlib.sha256()
+h.update(y.data.get().tobytes()); h.update(x.grad.get().tobytes())
+print('HASH', h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize('dil', [1, 64])
+def test_window_kernel_equals_tap_interleaved_kernel_bitwise(gpu, tmp_path, dil):
+    """conv_win_x3_kernel (one staged window for both taps) keeps the K order and the products of the tap-interleaved
+    conv_gemm_x3_kernel: forward and backward-data of the dilated conv at B = 9, T = 7680 must not differ in a single bit
+    whichever kernel the launch picks (VQVAE_X3_WIN is read once per process: two subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'win_worker.py'
+    script.write_text(_WIN_WORKER)
+    out = []
+    for win in ('1', '0'):
+        env = dict(os.environ, VQVAE_X3_WIN=win)
+        r = subprocess.run([sys.executable, str(script), root, str(dil)], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out.append([l for l in r.stdout.decode().splitlines() if l.startswith('HASH')][0])
+    assert out[0] == out[1]
+
+
+_LIN_WORKER = r"""
+import hashlib, os, sys
+import numpy as np
+sys.path[:0] = [os.path.join(sys.argv[1], 'chainer-vq-vae_amd')]
+from vqvae_amd import backend as gpu, functions as F
+from vqvae_amd.core import Variable, no_backprop_mode
+gpu.init(0)
+rs = np.random.RandomState(6)
+x = Variable(gpu.to_device(rs.standard_normal((3, 128, 7680, 1)).astype(np.float32)))
+W = Variable(gpu.to_device((rs.standard_normal((256, 128, 1, 1)) / 11).astype(np.float32)))
+b = Variable(gpu.to_device(rs.standard_normal(256).astype(np.float32)))
+with no_backprop_mode():
+    y = F.convolution_1d(x, W, b)
+print('HASH', hashlib.sha256(y.data.get().tobytes()).hexdigest())
+"""
+
+
+def test_streaming_1x1_equals_tiled_kernel_bitwise(gpu, tmp_path):
+    """lin128_stream_kernel (weights in registers, persistent) multiplies the same bf16 pieces in the same K order and
+    adds the bias in the same place as conv_gemm_x3_kernel: identical bits (VQVAE_LIN128=0 selects the tiled kernel)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'lin_worker.py'
+    script.write_text(_LIN_WORKER)
+    out = []
+    for v in ('32', '0'):
+        env = dict(os.environ, VQVAE_LIN128=v)
+        r = subprocess.run([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        out.append([l for l in r.stdout.decode().splitlines() if l.startswith('HASH')][0])
+    assert out[0] == out[1]
