@@ -135,6 +135,9 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 // (rows m0 + wm*64 + mi*32, columns t0 + wn*64 + ni*32) of batch item b.  SPLITK: this instantiation
 // may have been launched with ksplit > 1 (raw partial tiles out, gemm_splitk_reduce_kernel finishes).
 // DEEP: the linear epilogue requests a whole block's operands up front (needs 64 more registers).
+#ifndef X3_ABL
+#define X3_ABL 0              // timing experiments only (wrong results), see conv_gemm_x3_kernel; 10: the gate epilogue issues no stores, 11: no gate epilogue at all
+#endif
 template <int EPI, int WM, bool SPLITK, bool DEEP = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
                                               const int b, const int wm, const int wn, const int li, const int lk,
@@ -332,6 +335,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
     const int Ch = a.M >> 1;
     const int g = (m0 + wm * 64) >> 6;
     const OutR& og = a.out[0];   // gates (B, 2Ch, T)
+    if (X3_ABL == 11) {          // timing only: the accumulators are consumed by one never-taken store
+      float s = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
+      if (s == 123456.789f) og.y[(long)b * og.y_bstride + li] = s;
+      return;
+    }
     const OutR& oz = a.out[1];   // z (B, Ch, T)
     // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
     // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
@@ -392,6 +406,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         if (tt[ni] >= T) continue;
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
+        if (X3_ABL == 10 && ta != 123456.789f) continue;     // timing only: the math without the stores
         buf_st(ta, rG, vT[ni], sT);
         buf_st(sb, rG, vT[ni], sT + sGq);
         if (a.z16) __builtin_amdgcn_raw_buffer_store_b16((short)(pack_bf16x2(ta * sb, 0.f) & 0xffffu), rZ, vT[ni] >> 1, sT >> 1, 0);
@@ -750,10 +765,16 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 #ifndef X3_ABL
 #define X3_ABL 0              // timing experiments only (wrong results): 1 no activation loads, 2 no weight loads, 3 no fragment reads, 4 no LDS writes, 5 no barrier-separated staging at all (1+2+4)
 #endif
+#ifndef X3_LEAN_SCHED
+#define X3_LEAN_SCHED 0       // experiment: MFMA : VALU interleave of the lean loop (sched_group_barrier), 0 = the compiler's order
+#endif
+#ifndef X3_LEAN
+#define X3_LEAN 1             // 256 x 128 tiles, two taps, six products: the 128-VGPR loop below (two 8-wave workgroups per CU)
+#endif
 // X16 (matmul mode 1, linear GEMMs over the z tensors): the activations of every segment are stored as bf16
 // (GemmArgs::z16): fetched with 2-byte loads and staged without a conversion.
 template <int EPI, int WM, int NB, int NP, bool TAP2 = false, bool X16 = false>
-__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) void conv_gemm_x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(!X16 || (NP == 1 && !TAP2 && EPI == EPI_LINEAR), "bf16-stored activations: mode 1 linear GEMMs only");
   constexpr unsigned ESZ = X16 ? 2u : 4u;               // bytes per activation element
@@ -874,7 +895,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   // unconditional (a branch around them makes hipcc drain to vmcnt(0)).
   uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
   float pb[CPT], qb[CPT];
-  unsigned pmask = 0, qmask = 0;           // (unused since the buffer loads: kept so that the staging macro's signature is unchanged)
+  [[maybe_unused]] unsigned pmask = 0, qmask = 0;           // (unused since the buffer loads: kept so that the staging macro's signature is unchanged)
 #define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw, vb, rx, !TAP2)
 #define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, (X3_ABL == 9 ? 0x80000000u : vb1), rx1, false)   /* ABL 9 (timing only): the second tap's activations are not fetched (every load out of range) */
 #define X3_FETCH_(A0, A1, A2, BV, SW, VB, RX, ADV)                                           \
@@ -974,6 +995,98 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
+  // LEAN (256 x 128 tiles, two taps, six products): the loop in 128 VGPRs, so that TWO 8-wave workgroups share a
+  // CU (2 x 72 KB of LDS) and one tile's epilogue -- 13 % of the gate kernel's time with nothing beside it
+  // (tools/abl_gate.sh) -- runs beside the other's K loop.  What it gives up against the loop below: the
+  // weights (L2-resident) are fetched ONE step ahead into a single register set, only the activations two;
+  // the A fragments of one 32-row block at a time.
+  constexpr bool LEAN = (WM == 4 && NB == 1 && NP == 3 && TAP2 && X3_LEAN);
+  if constexpr (LEAN) {
+    unsigned swA = 0, sxB = 0;                 // the two cursors: weights of the next A fetch, activations of the next B fetch
+    int leftA = nsteps, leftB = nsteps;
+    uint4 la0, la1, la2;
+    float pb[CPT], qb[CPT];
+#define LN_FETCH_A(TAP1)                                                                      \
+    {                                                                                         \
+      const unsigned so_ = swA + ((TAP1) ? sw1 : 0u);                                         \
+      la0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
+      la1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
+      la2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
+      if (TAP1) { leftA -= 2; swA += leftA > 0 ? wadvb : 0u; }                                \
+    }
+#define LN_FETCH_B(BV, TAP1)                                                                  \
+    {                                                                                         \
+      _Pragma("unroll") for (int e = 0; e < CPT; ++e)                                         \
+        BV[e] = (TAP1) ? buf_ld(rx1, vb1, sxB + (unsigned)e * xcsb) : buf_ld(rx, vb, sxB + (unsigned)e * xcsb); \
+      if (TAP1) { leftB -= 2; sxB += leftB > 0 ? xadvb : 0u; }                                \
+    }
+#define LN_STAGE(BV, BUF)                                                                     \
+    {                                                                                         \
+      uint4* ad = &As[BUF][0][0][0];                                                          \
+      ad[tid] = la0; ad[NT + tid] = la1; ad[2 * NT + tid] = la2;                              \
+      unsigned pc[3][CPT / 2];                                                                \
+      _Pragma("unroll") for (int e = 0; e < CPT; e += 2) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                         \
+        uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
+        *bd = make_uint2(pc[p][0], pc[p][1]);                                                 \
+      }                                                                                       \
+    }
+    static_assert(!LEAN || CPT == 4, "lean loop: 512 threads stage 128 columns x 16 channels");
+    auto lmma = [&](auto curc) {
+      constexpr int cur = decltype(curc)::value;
+      bf16x8 bf[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + j * 32 + li]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];                                  // same product order as the loop below
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+#if X3_LEAN_SCHED
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, X3_LEAN_SCHED, 0);
+      }
+#endif
+    };
+    if (nsteps > 0) {
+      LN_FETCH_B(pb, false);                   // step 0
+      LN_FETCH_A(false);                       // step 0
+      LN_FETCH_B(qb, true);                    // step 1
+      LN_STAGE(pb, 0);
+      __syncthreads();
+      for (int i = 0; i < nsteps; i += 2) {    // nsteps is even: two taps per channel group
+        LN_FETCH_A(true);                      // weights of step i + 1
+        LN_FETCH_B(pb, false);                 // activations of step i + 2
+        lmma(std::integral_constant<int, 0>{});
+        LN_STAGE(qb, 1);                       // step i + 1
+        __syncthreads();
+        LN_FETCH_A(false);                     // weights of step i + 2
+        LN_FETCH_B(qb, true);                  // activations of step i + 3
+        lmma(std::integral_constant<int, 1>{});
+        LN_STAGE(pb, 0);                       // step i + 2
+        __syncthreads();
+      }
+    }
+#undef LN_FETCH_A
+#undef LN_FETCH_B
+#undef LN_STAGE
+  } else
   if (nsteps > 0) {
     X3_FETCH(pa0, pa1, pa2, pb, pmask);
     if (SCHED && !TAP2) advance();
@@ -1002,7 +1115,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : 2) v
 #undef X3_FETCH1
 #undef X3_FETCH_
 #undef X3_STAGE
-  gemm_epilogue<EPI, WM, SPLITK, WM == 4>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);
+  gemm_epilogue<EPI, WM, SPLITK, (WM == 4 && !(NB == 1 && TAP2 && X3_LEAN))>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
   if constexpr (NB == 2) {
     if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
@@ -2387,8 +2500,6 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
   static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
   const long nblk2 = (long)g.ntile_m * cdiv(g.Tout, 2 * BN) * g.B;
-  const bool wide = g_matmul_dtype != 0 && big && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
-  if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
   // two taps of one tensor: interleave them channel group by channel group (TAP2).  The choice depends
   // on the contraction only, never on the tile shape, so that a result does not change with the batch size.
   static const int x3_tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
@@ -2398,6 +2509,14 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
                     g.seg[0].Tin == g.seg[1].Tin && g.seg[0].tmul == g.seg[1].tmul && g.seg[0].tdiv == g.seg[1].tdiv &&
                     g.seg[0].ldw == g.seg[1].ldw && g.seg[1].w >= g.seg[0].w &&          // second slab addressed off the first's descriptor
                     (reinterpret_cast<const char*>(g.seg[1].w) - reinterpret_cast<const char*>(g.seg[0].w)) < (1L << 30);
+  // Two taps in the six-product mode: 256 x 128 tiles whose loop fits 128 VGPRs (LEAN in conv_gemm_x3_kernel), TWO
+  // workgroups per CU -- one tile's epilogue beside the other's K loop: gate kernel 211 -> 197 us, backward-data
+  // 217 -> 198 us at configs[1] against the 256 x 256 tiles, which stay for every other contraction.  Same K
+  // order and products as the other two-tap kernels: the choice never changes a result.
+  static const int x3_lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
+  const bool lean = x3_lean && X3_LEAN && tap2 && big && g_matmul_dtype != 0 && EPI != EPI_GATE_BWD && x3_nb != 3;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
+  const bool wide = g_matmul_dtype != 0 && big && !lean && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
+  if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
 #define X3_LAUNCH(WMv, NBv, NPv, blocks, threads)                                                                    \
   do {                                                                                                                \
     if (tap2) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, true>), dim3((unsigned)(blocks)), dim3(threads), 0, st, g);  \

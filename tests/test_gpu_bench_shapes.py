@@ -228,10 +228,12 @@ print('HASH', h.hexdigest())
 
 
 @pytest.mark.parametrize('dil', [1, 64])
-def test_window_kernel_equals_tap_interleaved_kernel_bitwise(gpu, tmp_path, dil):
-    """conv_win_x3_kernel (one staged window for both taps) keeps the K order and the products of the tap-interleaved
-    conv_gemm_x3_kernel: forward and backward-data of the dilated conv at B = 9, T = 7680 must not differ in a single bit
-    whichever kernel the launch picks (VQVAE_X3_WIN is read once per process: two subprocesses)."""
+def test_two_tap_kernels_agree_bitwise(gpu, tmp_path, dil):
+    """The three kernels a two-tap contraction can run on -- the 256 x 128-tile loop with two workgroups per CU (the
+    default in the six-product mode), conv_win_x3_kernel (one staged window for both taps) and the tap-interleaved
+    256 x 256-tile conv_gemm_x3_kernel -- keep one K order and one product order: forward and backward-data of the
+    dilated conv at B = 9, T = 7680 must not differ in a single bit whichever the launch picks (the selecting
+    switches are read once per process: one subprocess each)."""
     import os
     import subprocess
     import sys
@@ -239,13 +241,13 @@ def test_window_kernel_equals_tap_interleaved_kernel_bitwise(gpu, tmp_path, dil)
     script = tmp_path / 'win_worker.py'
     script.write_text(_WIN_WORKER)
     out = []
-    for win in ('1', '0'):
-        env = dict(os.environ, VQVAE_X3_WIN=win)
+    for lean, win in (('1', '1'), ('0', '1'), ('0', '0')):
+        env = dict(os.environ, VQVAE_X3_LEAN=lean, VQVAE_X3_WIN=win)
         r = subprocess.run([sys.executable, str(script), root, str(dil)], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         out.append([l for l in r.stdout.decode().splitlines() if l.startswith('HASH')][0])
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]
 
 
 _LIN_WORKER = r"""
