@@ -2034,8 +2034,11 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // NP = bf16 pieces per operand: 3 (mode 2) or 1 (mode 1: operands rounded to bf16, one product).
 // X16 (matmul mode 1): the x operand (the z tensors: unshifted, T a multiple of 16) is stored as bf16 -- 8-byte loads
 // of 4 t, staged as they are.
+#ifndef W3_LEAN
+#define W3_LEAN 1             // 256 x 128 tiles, six products: compiled for 128 VGPRs (two 8-wave workgroups per CU)
+#endif
 template <int WM, int NC, int NP, bool X16 = false>
-__global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3) ? 4 : 2) void wgrad3_kernel(const WgradArgs a) {
   static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(!X16 || NP == 1, "bf16-stored x: mode 1 only");
   constexpr unsigned XSZ = X16 ? 2u : 4u;
@@ -2196,8 +2199,34 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
       else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v);                         \
     }                                                                                          \
   }
+  constexpr bool LEANW = W3_LEAN && WM == 4 && NC == 1 && NP == 3;
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
+    if constexpr (LEANW) {                 // 128-VGPR form: the A fragments of one 32-row block at a time (same products, same order)
+      bf16x8 bq[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[j][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + j * 32 + li]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 ap[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bq[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+      return;
+    }
     bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -2241,6 +2270,28 @@ __global__ __launch_bounds__(128 * WM, 2) void wgrad3_kernel(const WgradArgs a) 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   const int nsteps = g1 - g0;
+  if constexpr (LEANW) {
+    // one register set, fetched ONE step ahead: with two workgroups on the CU the other one's MFMAs cover the
+    // wait a late load costs this one, and the second set's 15 registers are what kept the loop above 128
+    if (nsteps > 0) {
+      W3_FETCH(pra, prb, pvm, pbs, pbt);
+      W3_STAGE(pra, prb, pvm, pbs, pbt, 0, true);
+      __syncthreads();
+      for (int i = 0; i < nsteps; i += 2) {
+        if (i + 1 < nsteps) advance();
+        W3_FETCH(pra, prb, pvm, pbs, pbt);                  // step i + 1 (past the end: re-reads the last step, unused)
+        mma(I0{});
+        W3_STAGE(pra, prb, pvm, pbs, pbt, 1, i + 1 < nsteps);
+        __syncthreads();
+        if (i + 1 >= nsteps) break;
+        if (i + 2 < nsteps) advance();
+        W3_FETCH(pra, prb, pvm, pbs, pbt);                  // step i + 2
+        mma(I1{});
+        W3_STAGE(pra, prb, pvm, pbs, pbt, 0, i + 2 < nsteps);
+        __syncthreads();
+      }
+    }
+  } else
   if (nsteps > 0) {
     W3_FETCH(pra, prb, pvm, pbs, pbt);
     if (nsteps > 1) advance();
