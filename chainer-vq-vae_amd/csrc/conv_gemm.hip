@@ -768,13 +768,16 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 #ifndef X3_LEAN_SCHED
 #define X3_LEAN_SCHED 0       // experiment: MFMA : VALU interleave of the lean loop (sched_group_barrier), 0 = the compiler's order
 #endif
+#ifndef X3_LEAN_GBWD
+#define X3_LEAN_GBWD 0        // experiment: the gate-derivative GEMM on the lean loop (136 VGPRs, THREE workgroups per CU): 175 us against 161 -- that kernel wants bytes in flight per workgroup, not workgroups
+#endif
 #ifndef X3_LEAN
 #define X3_LEAN 1             // 256 x 128 tiles, two taps, six products: the 128-VGPR loop below (two 8-wave workgroups per CU)
 #endif
 // X16 (matmul mode 1, linear GEMMs over the z tensors): the activations of every segment are stored as bf16
 // (GemmArgs::z16): fetched with 2-byte loads and staged without a conversion.
 template <int EPI, int WM, int NB, int NP, bool TAP2 = false, bool X16 = false>
-__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : ((WM == 2 && NP == 3 && TAP2 && EPI == EPI_GATE_BWD && X3_LEAN_GBWD) ? 3 : 2))) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(!X16 || (NP == 1 && !TAP2 && EPI == EPI_LINEAR), "bf16-stored activations: mode 1 linear GEMMs only");
   constexpr unsigned ESZ = X16 ? 2u : 4u;               // bytes per activation element
@@ -1000,7 +1003,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // (tools/abl_gate.sh) -- runs beside the other's K loop.  What it gives up against the loop below: the
   // weights (L2-resident) are fetched ONE step ahead into a single register set, only the activations two;
   // the A fragments of one 32-row block at a time.
-  constexpr bool LEAN = (WM == 4 && NB == 1 && NP == 3 && TAP2 && X3_LEAN);
+  constexpr bool LEAN = (NB == 1 && NP == 3 && TAP2 && ((WM == 4 && X3_LEAN) || (WM == 2 && EPI == EPI_GATE_BWD && X3_LEAN_GBWD)));   // gate-derivative GEMM (128 x 128 tiles, 256 threads): 168 VGPRs, three workgroups per CU
   if constexpr (LEAN) {
     unsigned swA = 0, sxB = 0;                 // the two cursors: weights of the next A fetch, activations of the next B fetch
     int leftA = nsteps, leftB = nsteps;
@@ -1027,11 +1030,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       unsigned pc[3][CPT / 2];                                                                \
       _Pragma("unroll") for (int e = 0; e < CPT; e += 2) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                         \
-        uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
-        *bd = make_uint2(pc[p][0], pc[p][1]);                                                 \
+        if constexpr (CPT == 8) {                                                             \
+          Bs[BUF][p][tid / BNW][s_n] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);    \
+        } else {                                                                              \
+          uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
+          *bd = make_uint2(pc[p][0], pc[p][1]);                                               \
+        }                                                                                     \
       }                                                                                       \
     }
-    static_assert(!LEAN || CPT == 4, "lean loop: 512 threads stage 128 columns x 16 channels");
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
       bf16x8 bf[2][3];
