@@ -419,35 +419,79 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
     const rsrc_t rGt = make_rsrc(od.add + (long)b * od.add_bstride);
     const rsrc_t rGh = make_rsrc(od.y + (long)b * od.y_bstride);
     const unsigned sQ = 4u * (unsigned)(Ch * T);
+    if constexpr (DEEP) {       // (the x3 kernels: 256 VGPRs allowed)
+      // ALL gate values of the wave's four 32 x 32 sub-tiles are requested before the first store: loads and
+      // stores retire through one in-order counter, so a sub-tile's loads issued behind the previous sub-tile's
+      // stores waited for those stores' acknowledgements -- four load + store round trips per tile, now one.
+      float ta[2][2][16], sb[2][2][16];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int t = t0 + wn * 64 + ni * 32 + li;
-        const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
-        const bool tok = t < T;
-        const unsigned voff = 4u * (unsigned)(mb * T + t);
-        // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
-        float ta[16], sb[16];
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+          const bool tok = t < T;
+          const unsigned voff = 4u * (unsigned)(mb * T + t);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          const bool ok = tok && mb + dr < Ch;
-          const unsigned so = 4u * (unsigned)(dr * T);
-          ta[r] = ok ? buf_ld(rGt, voff, so) : 0.f;
-          sb[r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          if (tok && mb + dr < Ch) {
-            const float gz = acc[mi][ni][r];
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const bool ok = tok && mb + dr < Ch;
             const unsigned so = 4u * (unsigned)(dr * T);
-            buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
-            buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
+            ta[mi][ni][r] = ok ? buf_ld(rGt, voff, so) : 0.f;
+            sb[mi][ni][r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
           }
         }
-      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+          const bool tok = t < T;
+          const unsigned voff = 4u * (unsigned)(mb * T + t);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (tok && mb + dr < Ch) {
+              const float gz = acc[mi][ni][r];
+              const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
+              const unsigned so = 4u * (unsigned)(dr * T);
+              buf_st(gz * sv * (1.f - tv * tv), rGh, voff, so);
+              buf_st(gz * tv * sv * (1.f - sv), rGh, voff, so + sQ);
+            }
+          }
+        }
+    } else {                    // the fp32 MFMA kernel runs four waves per SIMD (128 VGPRs): one sub-tile's gate values at a time
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int t = t0 + wn * 64 + ni * 32 + li;
+          const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+          const bool tok = t < T;
+          const unsigned voff = 4u * (unsigned)(mb * T + t);
+          // all gate loads of the 32x32 sub-tile first, then the stores (may-alias ordering)
+          float ta[16], sb[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const bool ok = tok && mb + dr < Ch;
+            const unsigned so = 4u * (unsigned)(dr * T);
+            ta[r] = ok ? buf_ld(rGt, voff, so) : 0.f;
+            sb[r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (tok && mb + dr < Ch) {
+              const float gz = acc[mi][ni][r];
+              const unsigned so = 4u * (unsigned)(dr * T);
+              buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
+              buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
+            }
+          }
+        }
+    }
   }
 }
 
@@ -1009,12 +1053,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     int leftA = nsteps, leftB = nsteps;
     uint4 la0, la1, la2;
     float pb[CPT], qb[CPT];
-#define LN_FETCH_A(TAP1)                                                                      \
+#define LN_FETCH_A(TAP1) LN_FETCH_A_(la0, la1, la2, TAP1)
+#define LN_FETCH_A_(L0, L1, L2, TAP1)                                                         \
     {                                                                                         \
       const unsigned so_ = swA + ((TAP1) ? sw1 : 0u);                                         \
-      la0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
-      la1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
-      la2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
+      L0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
+      L1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
+      L2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
       if (TAP1) { leftA -= 2; swA += leftA > 0 ? wadvb : 0u; }                                \
     }
 #define LN_FETCH_B(BV, TAP1)                                                                  \
@@ -1023,10 +1068,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         BV[e] = (TAP1) ? buf_ld(rx1, vb1, sxB + (unsigned)e * xcsb) : buf_ld(rx, vb, sxB + (unsigned)e * xcsb); \
       if (TAP1) { leftB -= 2; sxB += leftB > 0 ? xadvb : 0u; }                                \
     }
-#define LN_STAGE(BV, BUF)                                                                     \
+#define LN_STAGE(BV, BUF) LN_STAGE_(la0, la1, la2, BV, BUF)
+#define LN_STAGE_(L0, L1, L2, BV, BUF)                                                        \
     {                                                                                         \
       uint4* ad = &As[BUF][0][0][0];                                                          \
-      ad[tid] = la0; ad[NT + tid] = la1; ad[2 * NT + tid] = la2;                              \
+      ad[tid] = L0; ad[NT + tid] = L1; ad[2 * NT + tid] = L2;                                 \
       unsigned pc[3][CPT / 2];                                                                \
       _Pragma("unroll") for (int e = 0; e < CPT; e += 2) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                         \
@@ -1070,6 +1116,29 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       }
 #endif
     };
+    if constexpr (WM == 2) {                   // gate-derivative GEMM: the weights two steps ahead as well (second set)
+      uint4 ma0, ma1, ma2;
+      if (nsteps > 0) {
+        LN_FETCH_B(pb, false);                 // step 0
+        LN_FETCH_A_(la0, la1, la2, false);
+        LN_FETCH_B(qb, true);                  // step 1
+        LN_FETCH_A_(ma0, ma1, ma2, true);
+        LN_STAGE_(la0, la1, la2, pb, 0);
+        __syncthreads();
+        for (int i = 0; i < nsteps; i += 2) {
+          LN_FETCH_A_(la0, la1, la2, false);   // step i + 2
+          LN_FETCH_B(pb, false);
+          lmma(std::integral_constant<int, 0>{});
+          LN_STAGE_(ma0, ma1, ma2, qb, 1);     // step i + 1
+          __syncthreads();
+          LN_FETCH_A_(ma0, ma1, ma2, true);    // step i + 3
+          LN_FETCH_B(qb, true);
+          lmma(std::integral_constant<int, 1>{});
+          LN_STAGE_(la0, la1, la2, pb, 0);     // step i + 2
+          __syncthreads();
+        }
+      }
+    } else
     if (nsteps > 0) {
       LN_FETCH_B(pb, false);                   // step 0
       LN_FETCH_A(false);                       // step 0
@@ -1090,6 +1159,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       }
     }
 #undef LN_FETCH_A
+#undef LN_FETCH_A_
+#undef LN_STAGE_
 #undef LN_FETCH_B
 #undef LN_STAGE
   } else
@@ -1121,7 +1192,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
 #undef X3_FETCH1
 #undef X3_FETCH_
 #undef X3_STAGE
-  gemm_epilogue<EPI, WM, SPLITK, (WM == 4 && !(NB == 1 && TAP2 && X3_LEAN))>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
+  gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD)>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
   if constexpr (NB == 2) {
     if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
