@@ -2208,10 +2208,10 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
     const unsigned sob = XSZ * (unsigned)((long)b * sg.x_bstride + (interior ? tb + sg.toff : 0)); \
     VM = (!ragged || tb + 4 * s_chunk < Tout) ? 1u : 0u;                                       \
     unsigned vo_[NB];                                                                          \
-    if (interior) {                                                                            \
-      BS = 0; BT = 0;                                                                          \
-      _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = vobk[i];                         \
-    } else {                                                                                   \
+    BS = 0; BT = 0;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = vobk[i];                           \
+    if (!interior) {                                   /* wave-uniform, two steps per row and tap: a real branch (the empty asm keeps hipcc from turning the ~25 VALU of the edge path into selects that every step pays) */ \
+      asm volatile("");                                                           \
       const int tin = tb + 4 * s_chunk + sg.toff;                                              \
       const bool any = VM != 0u && tin + 3 >= 0 && tin < sg.Tin;                               \
       const int tc = min(max(tin, 0), sg.Tin - 4);                                             \
@@ -2261,7 +2261,8 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       float4 v = RB[i];                               /* invalid rows / groups arrived as 0 */ \
-      if (!X16 && BS != 0) {        /* the group crosses a row end: element e is loaded[e - BS] */ \
+      if (!X16 && __builtin_amdgcn_ballot_w64(BS != 0) != 0ull) {   /* some group of this wave crosses a row end (edge steps only: wave-uniform branch): element e is loaded[e - BS] */ \
+        asm volatile("");                                                         \
         const float l[4] = {v.x, v.y, v.z, v.w};                                               \
         float o[4];                                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
