@@ -784,8 +784,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? (EPI == EPI_LINEAR ? 3 : 4) : 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   h = pack_bf16x2(x0, x1);
+  asm("" : "+v"(h));        // opaque (not volatile: free to move): hipcc otherwise re-derives `h << 16` as a second conversion of x0 alone
   float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
   m = pack_bf16x2(r0, r1);
+  asm("" : "+v"(m));
   r0 -= __builtin_bit_cast(float, m << 16); r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
   l = pack_bf16x2(r0, r1);
 }
