@@ -798,6 +798,108 @@ __global__ __launch_bounds__(64 * BC_WAVES) void embed_bincount2x4_kernel(const 
   }
 }
 
+
+// ---- K == 2 bincount as a gather over class-sorted positions ----------------------------------------------
+// The LDS-atomic form above costs ~3 clocks per lane-add (345 us at configs[1]: 63 M adds).  The positions of
+// one batch item are the same for all Cout rows of that item, so they are sorted by class ONCE per item
+// (embed_sort_kernel: stable counting sort -> perm[b][.], off[b][c]) and every row then sums, per class, the
+// gradient values at that class's positions (tap 1) and at the positions after them (tap 0: the class of the
+// PREVIOUS sample) -- plain LDS reads, no atomics.  ES_LPC lanes share a class (position j of the class's list
+// goes to lane j % ES_LPC), their partial sums are combined in lane order: a fixed summation order.
+constexpr int ES_NT = 1024, ES_NW = ES_NT / 64;
+// Stable counting sort of one batch item's positions by class.  Every wave owns a contiguous chunk of the time
+// axis and a private counter row: the returning ds_add gives a position its rank among the SAME-class positions
+// of its chunk (lanes of one instruction are applied in lane order, instructions in program order), a scan over
+// (class, wave) turns the counters into start offsets.  Deterministic, and position-ordered within a class.
+__global__ __launch_bounds__(ES_NT) void embed_sort_kernel(const int32_t* __restrict__ idx, int q, int T,
+                                                           unsigned short* __restrict__ perm, int32_t* __restrict__ off,
+                                                           const int32_t* __restrict__ run_flag) {
+  extern __shared__ unsigned char es_smem[];
+  if (run_flag != nullptr && *run_flag == 0) return;
+  int* wcnt = reinterpret_cast<int*>(es_smem);                                  // [ES_NW][q]
+  int* sc = wcnt + ES_NW * q;                                                   // [ES_NT] block scan
+  unsigned short* rank = reinterpret_cast<unsigned short*>(sc + ES_NT);         // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* ib = idx + (long)b * T;
+  for (int i = tid; i < ES_NW * q; i += ES_NT) wcnt[i] = 0;
+  __syncthreads();
+  const int ch = ((T + ES_NW - 1) / ES_NW + 63) & ~63;                          // chunk length, a multiple of 64
+  const int t_lo = wave * ch, t_hi = min(T, t_lo + ch);
+  int* mine = wcnt + wave * q;
+  for (int t = t_lo + lane; t < t_hi; t += 64) {
+    const int c = ib[t];
+    if ((unsigned)c < (unsigned)q) rank[t] = (unsigned short)atomicAdd(&mine[c], 1);
+  }
+  __syncthreads();
+  int tot = 0;
+  if (tid < q) for (int w = 0; w < ES_NW; ++w) { const int v = wcnt[w * q + tid]; wcnt[w * q + tid] = tot; tot += v; }
+  sc[tid] = tid < q ? tot : 0;
+  __syncthreads();
+  for (int d = 1; d < ES_NT; d <<= 1) {                                         // inclusive block scan over the classes
+    const int v = tid >= d ? sc[tid - d] : 0;
+    __syncthreads();
+    sc[tid] += v;
+    __syncthreads();
+  }
+  if (tid < q) off[(long)b * (q + 1) + tid] = sc[tid] - tot;
+  if (tid == q - 1) off[(long)b * (q + 1) + q] = sc[tid];
+  unsigned short* pb = perm + (long)b * T;
+  for (int t = t_lo + lane; t < t_hi; t += 64) {
+    const int c = ib[t];
+    if ((unsigned)c < (unsigned)q) pb[(c ? sc[c - 1] : 0) + mine[c] + rank[t]] = (unsigned short)t;    // class start + this wave's start within the class + rank within the wave's chunk
+  }
+}
+
+constexpr int EG_ROWS = 8;                                 // rows (output channels) of one batch item per workgroup
+__global__ __launch_bounds__(ES_NT) void embed_gathersum_kernel(const float* __restrict__ gy, int B, int Cout, int q, int T,
+                                                                int lpc, const unsigned short* __restrict__ perm,
+                                                                const int32_t* __restrict__ off, float* __restrict__ part,
+                                                                const int32_t* __restrict__ run_flag) {
+  extern __shared__ unsigned char eg_smem[];
+  if (run_flag != nullptr && *run_flag == 0) return;
+  float* g0 = reinterpret_cast<float*>(eg_smem);                               // [2][T + 4] gradient rows (double buffer)
+  const int pitch = T + 4;
+  unsigned short* pl = reinterpret_cast<unsigned short*>(g0 + 2 * pitch);      // [T] this item's sorted positions
+  int* ol = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(pl) + (((size_t)T * 2 + 15) & ~(size_t)15));   // [q + 1]
+  const int tid = threadIdx.x;
+  const int groups = (Cout + EG_ROWS - 1) / EG_ROWS;
+  const int b = blockIdx.x / groups, r0 = (blockIdx.x % groups) * EG_ROWS;
+  const int nr = min(EG_ROWS, Cout - r0);
+  for (int t = tid; t < T; t += ES_NT) pl[t] = perm[(long)b * T + t];
+  for (int i = tid; i <= q; i += ES_NT) ol[i] = off[(long)b * (q + 1) + i];
+  const float* gb = gy + ((long)b * Cout + r0) * T;
+  const int T4 = T >> 2;                                   // host: T % 4 == 0, rows 16-byte aligned
+  for (int i = tid; i < T4; i += ES_NT) *reinterpret_cast<float4*>(g0 + 4 * i) = *reinterpret_cast<const float4*>(gb + 4 * i);
+  if (tid < 4) g0[T + tid] = 0.f, g0[pitch + T + tid] = 0.f;                   // g[T] = 0: the position after the last one
+  __syncthreads();
+  const int c = tid / lpc, k = tid % lpc;
+  const int j0 = c < q ? ol[c] : 0, j1 = c < q ? ol[c + 1] : 0;
+  for (int r = 0; r < nr; ++r) {
+    float* g = g0 + (r & 1) * pitch;
+    if (r + 1 < nr) {                                      // next row into the other buffer while this one is summed
+      float* gn = g0 + ((r + 1) & 1) * pitch;
+      const float* src = gb + (long)(r + 1) * T;
+      for (int i = tid; i < T4; i += ES_NT) *reinterpret_cast<float4*>(gn + 4 * i) = *reinterpret_cast<const float4*>(src + 4 * i);
+    }
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = j0 + k; j < j1; j += lpc) {
+      const int t = pl[j];
+      s1 += g[t];                                          // tap 1: the class of the position itself
+      s0 += g[t + 1];                                      // tap 0: this position is the PREVIOUS sample of t + 1 (g[T] = 0)
+    }
+    for (int d = 1; d < lpc; d <<= 1) {                    // lanes of a class are adjacent: fixed-order tree
+      s0 += __shfl_xor(s0, d, 64);
+      s1 += __shfl_xor(s1, d, 64);
+    }
+    if (c < q && k == 0) {
+      float* out = part + ((long)b * Cout + r0 + r) * 2 * q;
+      out[c] = s0;
+      out[q + c] = s1;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- concat / split of equally sized parameter arrays ---------------------------
 struct PtrList32 { float* p[32]; };
 __global__ void concat_kernel(const PtrList32 src, int n, long count, float* __restrict__ dst) {
@@ -1011,9 +1113,14 @@ int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, c
   return 0;
 }
 
+// workspace: [per-row partial histograms | class-sorted positions + class offsets (K == 2 gather form) | dense-conv fallback]
+static size_t embed_ws_sort_off(int B, int Cout, int q, int K) { return align_up((size_t)B * Cout * K * q * sizeof(float), 256); }
+static size_t embed_ws_conv_off(int B, int Cout, int q, int K, int T) {
+  return embed_ws_sort_off(B, Cout, q, K) + align_up((size_t)B * T * sizeof(unsigned short), 256) + align_up((size_t)B * (q + 1) * sizeof(int32_t), 256);
+}
 size_t vqvae_embed_onehot_workspace_bytes(int B, int Cout, int q, int K, int T) {
   vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
-  return align_up((size_t)B * Cout * K * q * sizeof(float), 256) + vqvae_conv1d_workspace_bytes(&d) + 256;
+  return embed_ws_conv_off(B, Cout, q, K, T) + vqvae_conv1d_workspace_bytes(&d) + 256;
 }
 
 int vqvae_embed_onehot_fwd(const float* x, const float* W, const float* b, int B, int Cout, int q,
@@ -1040,7 +1147,7 @@ int vqvae_embed_onehot_fwd(const float* x, const float* W, const float* b, int B
   VQ_LAUNCH_CHECK();
   // ... anything else: the dense causal conv (pad K-1, cropped to T), skipped on the device when flag != 0
   vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
-  char* cw = (char*)ws + align_up((size_t)B * Cout * K * q * sizeof(float), 256);
+  char* cw = (char*)ws + embed_ws_conv_off(B, Cout, q, K, T);
   return vqvae_conv1d_fwd_cond(&d, x, W, b, y, cw, ws_bytes - (size_t)(cw - (char*)ws), flag, s);
 }
 
@@ -1058,6 +1165,26 @@ int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* 
   int nb = (int)((rows + 3) / 4);
   if (nb > 2048) nb = 2048;
   const size_t lds2 = (size_t)BC_WAVES * BC_NCOPY * 2 * q * sizeof(float);
+  static const int use_sort = getenv("VQVAE_EMBED_SORT") ? atoi(getenv("VQVAE_EMBED_SORT")) : 1;
+  int lpc = 1;
+  while (lpc * 2 * q <= ES_NT && lpc < 64) lpc *= 2;       // lanes per class: 4 at q = 256
+  const size_t lds_sort = (size_t)(ES_NW * q + ES_NT) * sizeof(int) + (size_t)T * 2;
+  const size_t lds_gath = (size_t)2 * (T + 4) * sizeof(float) + (((size_t)T * 2 + 15) & ~(size_t)15) + (size_t)(q + 1) * sizeof(int);
+  if (use_sort && K == 2 && T % 4 == 0 && T <= 65535 && q <= ES_NT && (((uintptr_t)gy) % 16 == 0) &&
+      lds_sort <= 64 * 1024 && lds_gath <= 150 * 1024) {
+    unsigned short* perm = reinterpret_cast<unsigned short*>((char*)ws + embed_ws_sort_off(B, Cout, q, K));
+    int32_t* off = reinterpret_cast<int32_t*>((char*)perm + align_up((size_t)B * T * sizeof(unsigned short), 256));
+    hipLaunchKernelGGL(embed_sort_kernel, dim3(B), dim3(ES_NT), lds_sort, st, idx, q, T, perm, off, flag);
+    VQ_LAUNCH_CHECK();
+    const int groups = (Cout + EG_ROWS - 1) / EG_ROWS;
+    static size_t lds_allowed = 64 * 1024;                 // dynamic LDS beyond 64 KB has to be asked for
+    if (lds_gath > lds_allowed) {
+      VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(embed_gathersum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gath));
+      lds_allowed = lds_gath;
+    }
+    hipLaunchKernelGGL(embed_gathersum_kernel, dim3(B * groups), dim3(ES_NT), lds_gath, st, gy, B, Cout, q, T, lpc,
+                       (const unsigned short*)perm, (const int32_t*)off, part, flag);
+  } else
   if (K == 2 && T % 4 == 0 && (((uintptr_t)gy) % 16 == 0) && (((uintptr_t)idx) % 16 == 0) && lds2 <= 64 * 1024) {   // int4 loads of idx, float4 loads of gy
     int nb2 = (int)((rows + BC_WAVES - 1) / BC_WAVES);
     if (nb2 > 4096) nb2 = 4096;
@@ -1075,7 +1202,7 @@ int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* 
   }
   if (flag == nullptr) return 0;                          // index-fed input: there is no dense form to fall back to
   vqvae_conv1d_desc d = {B, q, T, Cout, T, K, 1, K - 1, 1, 0};
-  char* cw = (char*)ws + align_up((size_t)B * Cout * K * q * sizeof(float), 256);
+  char* cw = (char*)ws + embed_ws_conv_off(B, Cout, q, K, T);
   return vqvae_conv1d_bwd_weight_cond(&d, x, gy, gW, gb, accumulate, cw, ws_bytes - (size_t)(cw - (char*)ws), flag, s);
 }
 
