@@ -47,8 +47,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chi
 # residual 1x1 conv is a separate launch the extra term is 0.
 ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
                    '+ latent-rate condition lerp + tanh*sigmoid gate)')
-ROOFLINE_KERNEL_X3 = ('conv_win_x3_kernel<EPI_GATE> (dilation <= 128: both taps from one staged window) / '
-                      'conv_gemm_x3_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
+ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU> '
+                      '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
                       'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
                       '+ latent-rate condition lerp + tanh*sigmoid gate)')
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense
