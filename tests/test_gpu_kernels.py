@@ -720,3 +720,51 @@ def test_embed_conv_onehot_auto_paths(gpu, matmul_mode, shape):
     for o in outs[1:]:
         np.testing.assert_array_equal(o[0], outs[0][0])
         np.testing.assert_array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize('case', ['skewed', 'one_class', 'out_of_range', 'q50'])
+def test_embed_index_wgrad_sorted_gather_edge_cases(gpu, case):
+    """vqvae_embed_onehot_wgrad's K = 2 form (positions sorted by class once per batch item, per-row gather sums):
+    class distributions a uniform draw never produces -- 60 % of the positions in one class, every position in one
+    class (one lane group sums the whole row), classes outside [0, q) (no one-hot row: they contribute nothing, to
+    either tap), and a class count that is not a power of two -- against a float64 scatter-add; three runs, same bits
+    (modules.py:127-128 with utils.py:85-87's one-hot input, whose weight gradient this is)."""
+    from vqvae_amd import _lib, backend
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    rs = np.random.RandomState(len(case))
+    B, Cout, T = 3, 24, 512
+    q = 50 if case == 'q50' else 256
+    idx = rs.randint(0, q, size=(B, T)).astype(np.int32)
+    if case == 'skewed':
+        idx[rs.uniform(size=(B, T)) < 0.6] = 131
+    elif case == 'one_class':
+        idx[:] = 7
+    elif case == 'out_of_range':
+        idx[0, ::5] = -1
+        idx[1, ::7] = q
+        idx[2, 3::11] = 1 << 20
+    gy = rs.standard_normal((B, Cout, T)).astype(np.float32)
+    want = np.zeros((Cout, q, 2), np.float64)
+    for b in range(B):
+        for t in range(T):
+            c1 = idx[b, t]
+            if 0 <= c1 < q:
+                want[:, c1, 1] += gy[b, :, t]
+            if t > 0:
+                c0 = idx[b, t - 1]
+                if 0 <= c0 < q:
+                    want[:, c0, 0] += gy[b, :, t]
+    d_idx, d_gy = gpu.to_device(idx), gpu.to_device(gy)
+    ws = backend.workspace(lib.vqvae_embed_onehot_workspace_bytes(B, Cout, q, 2, T))
+    outs = []
+    for _ in range(3):
+        gW = DeviceArray((Cout, q, 2), np.float32)
+        gb = DeviceArray((Cout,), np.float32)
+        _lib.call('vqvae_embed_onehot_wgrad', None, d_idx.ptr, None, d_gy.ptr, B, Cout, q, 2, T, gW.ptr, gb.ptr, 0,
+                  ws.ptr, ws.nbytes, gpu.stream())
+        outs.append((gW.get().copy(), gb.get().copy()))
+    assert_close_scaled(outs[0][0], want, 1e-5, 'embed gW from indices (%s)' % case)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[0], outs[0][0])
+        np.testing.assert_array_equal(o[1], outs[0][1])
