@@ -3,7 +3,7 @@ against the reference Chainer CPU path on identical inputs").
 
   configs[0]  batch 1, length 7680, d=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256,
               EMA on: one whole VQVAE_StandardUpdater.update() against oracle.train_step --
-              indices bit-exact, three losses 1e-4, every gradient 2e-4 of its scale, every
+              indices bit-exact, three losses 1e-4, every gradient 1e-4 of its scale, every
               parameter after Adam 1e-4, EMA copy 1e-5  (updaters.py:6-19, net.py:79-96).
   configs[4]  use_logistic=True, input_dim=1, n_mixture=30 (10 logistics), n_loop=4 n_layer=10
               (40 blocks), full channel widths, bf16 MFMA operands: a whole step against the
@@ -68,10 +68,15 @@ def test_config0_whole_step_matches_oracle(gpu, matmul_mode):
         assert_close(a, float(b), 1e-4, 'configs[0] loss%d' % (i + 1))
     g_dev = _grads_by_name(model, opt, True)
     assert len(G) > 150
-    for name, arr in G.items():
+    worst = ('', 0.0)                            # north_star's bar: 1e-4 of the tensor's scale (round 2 held 2e-4; with the
+    for name, arr in G.items():                  # oracle's backward taking the device's side at ReLU kinks every tensor is inside 1e-4)
         dn = H._dev_name(name, True)
         assert dn in g_dev, 'missing grad for ' + dn
-        assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 2e-4, 'configs[0] grad ' + dn)
+        assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 1e-4, 'configs[0] grad ' + dn)
+        err = np.abs(g_dev[dn].reshape(arr.shape).astype(np.float64) - arr).max() / max(np.abs(arr).max(), 1e-30)
+        if err > worst[1]:
+            worst = (dn, float(err))
+    print('configs[0] (%s): worst of %d gradient tensors: %s %.2e of its scale' % ((matmul_mode, len(G)) + worst))
     named = dict(model.namedparams())
     for name, arr in O.flatten_params(P):
         dn = H._dev_name(name, True)
