@@ -52,6 +52,10 @@ ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave
                       'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
                       '+ latent-rate condition lerp + tanh*sigmoid gate)')
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense
+# what the whole chip's matrix pipe sustains on the six-product stream with REAL operands (N(0,1) values split into
+# three bf16 pieces; registers only, no LDS / memory): tools/ubench/mfma_power.hip, profiles/r3/ubench_mfma_power.txt
+# (zeros: 2 130-2 180; the power limit).  Reported beside the nominal peak, never instead of it.
+SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA = 1670.0
 X3_PRODUCTS = 6                     # bf16 MFMA products per fp32 product in matmul mode 'float32x3'
 
 
@@ -586,6 +590,11 @@ def main():
                                       'algorithmic fp32 FLOPs' % X3_PRODUCTS if x3 else 'fp32 MFMA peak')),
                          'frac': (ach / peak) if ach else None,
                          'achieved_vs_fp32_mfma_peak': (ach / PEAK_FP32_MFMA_TFLOPS) if (ach and not args.bf16) else None,
+                         'achieved_vs_measured_sustained_mfma': ((ach * X3_PRODUCTS / SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA)
+                                                                 if (ach and x3) else None),
+                         'sustained_is': ('%.0f TFLOP/s bf16: the six-product MFMA stream alone on real operands, whole chip '
+                                          '(tools/ubench/mfma_power.hip; %.0f nominal)'
+                                          % (SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA, PEAK_BF16_MFMA_TFLOPS)) if x3 else None,
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
