@@ -434,3 +434,11 @@ def test_hot_kernels_keep_their_staging_in_registers(tmp_path):
             assert vgpr <= 256
             if lds is not None:
                 assert got_lds == lds, '%s: %d B of LDS (private arrays promoted?), expected %d' % (name, got_lds, lds)
+    # the instantiations that run TWO 8-wave workgroups per CU must fit four waves per SIMD: 128 VGPRs
+    for key in ('conv_gemm_x3_kernelILi0ELi4ELi1ELi3ELb1', 'conv_gemm_x3_kernelILi1ELi4ELi1ELi3ELb1',
+                'conv_gemm_x3_kernelILi0ELi4ELi1ELi1ELb1', 'conv_gemm_x3_kernelILi1ELi4ELi1ELi1ELb1',
+                'wgrad3_kernelILi4ELi1ELi3E'):
+        hits = [(n, v) for n, v in meta.items() if key in n]
+        assert hits, 'no kernel matching %s in the compiled module' % key
+        for name, (got_lds, scratch, vgpr, spills) in hits:
+            assert vgpr <= 128 and 2 * got_lds <= 160 * 1024, '%s: %d VGPRs, %d B of LDS: not two workgroups per CU' % (name, vgpr, got_lds)
