@@ -2752,6 +2752,9 @@ struct WgradPlan { int ntile_m, ntile_n, steps_per_b, steps_per_split, nsplit, n
 // the flattened (batch, time) axis cut into WBK-wide steps; choose the number of K splits so that
 // tiles x splits is just under a whole number of residency rounds, with as few splits as that
 // allows (every split costs one 64 KB partial slab per tile, written and re-read by the reduce).
+#ifndef W3_SLOTS_256
+#define W3_SLOTS_256 512
+#endif
 static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   WgradPlan p;
   p.nseg = nseg;
@@ -2764,7 +2767,12 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   long maxs = total_steps / 4;                 // at least 4 K steps (128 positions) per split
   if (maxs < 1) maxs = 1;
   if (maxs > 256) maxs = 256;
-  const long slots = 512;
+  // 128-row tile units per residency round: 512 = one 256-row workgroup (two units) per CU.  The 256-row
+  // six-product kernel would admit two per CU since round 3 (128 VGPRs), i.e. 1024 units: twice the splits
+  // (and slab traffic) for half the K range each measured 22.02 against 21.97 ms per step, 768 units 22.24:
+  // the plan stays (VQVAE_W3_SLOTS overrides it for such A/B runs).
+  static const long slots_env = getenv("VQVAE_W3_SLOTS") ? atol(getenv("VQVAE_W3_SLOTS")) : 0;
+  const long slots = slots_env > 0 ? slots_env : ((M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512);
   long want = 1;
   double best = -1.0;
   for (long w = 1; w <= maxs; ++w) {
