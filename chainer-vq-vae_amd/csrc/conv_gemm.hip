@@ -2196,7 +2196,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
     vobk[i] = b_ok[i] ? vrow[i] + 4u * XSZ * (unsigned)s_chunk : OOB;      // interior steps: the tap shift rides in the scalar offset
   }
   const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
-  const bool ragged = (Tout % W2K) != 0;                 // the last step of a row holds groups beyond Tout
+  const bool ragged = (Tout % WBK) != 0;                 // the last step(s) of a row hold groups beyond Tout (the plan counts WBK = 2 x W2K positions per step: with Tout % 32 == 16 the row's last 16-t step lies wholly beyond it)
 
   float4 pra[NA], prb[NB], qra[NA], qrb[NB];
   unsigned pvm = 0, qvm = 0;     // 1: this thread's 4-t group lies inside [0, Tout)
@@ -2894,12 +2894,37 @@ static size_t conv_pack_floats(const vqvae_conv1d_desc* d) {
   return f > b ? f : b;
 }
 
+// Stride-2 convs (the encoder, net.py:14-28): their weight gradient contracts gy[t] with x[2 t + e].  The fast
+// weight-gradient kernels read 16-byte runs of consecutive t, so x is first split into its even and odd phases
+// (one pass over x, into the workspace); tap e then is a STRIDE-1 segment of one phase: x[2 t + e] = xe[t + e / 2]
+// for even e, xo[t + (e - 1) / 2] for odd e.  (Until round 3 these layers ran the generic fp32-MFMA kernel.)
+static int phase_pitch(const vqvae_conv1d_desc* d) { return ((d->Tin + 1) / 2 + 3) & ~3; }
+static bool phase_split_ok(const vqvae_conv1d_desc* d) {
+  static const int on = getenv("VQVAE_WGRAD_PHASES") ? atoi(getenv("VQVAE_WGRAD_PHASES")) : 1;
+  return on && d->stride == 2 && d->dil == 1 && d->K <= MAXSEG && d->Tout % 4 == 0 && d->Tin >= 8;
+}
+static size_t phase_split_floats(const vqvae_conv1d_desc* d) {
+  return phase_split_ok(d) ? (size_t)2 * d->B * d->Cin * phase_pitch(d) + 64 : 0;
+}
+__global__ void phase_split_kernel(const float* __restrict__ x, long rows, int Tin, int Tp, float* __restrict__ xe,
+                                   float* __restrict__ xo, const int32_t* __restrict__ skip_flag) {
+  if (skip_flag != nullptr && *skip_flag != 0) return;
+  const long total = rows * Tp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Tp;
+    const int tp = (int)(i - r * Tp);
+    const float* xr = x + r * Tin;
+    xe[i] = 2 * tp < Tin ? xr[2 * tp] : 0.f;
+    xo[i] = 2 * tp + 1 < Tin ? xr[2 * tp + 1] : 0.f;
+  }
+}
+
 extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
   if (!d) return 0;
   int cins[MAXTAPS];
   for (int i = 0; i < d->K && i < MAXTAPS; ++i) cins[i] = d->Cin;
   WgradPlan p = plan_wgrad(d->Cout, d->B, d->Tout, cins, d->K < MAXTAPS ? d->K : MAXTAPS);
-  size_t wg = (p.slab_floats + p.bslab_floats) * sizeof(float);
+  size_t wg = (p.slab_floats + p.bslab_floats) * sizeof(float) + phase_split_floats(d) * sizeof(float);
   size_t pk = conv_pack_floats(d) * sizeof(float);
   // forward / backward-data may split K: packed weights first, then the partial tiles
   size_t pf = ksplit_partial_floats(d->Cout, d->Tout, d->B, d->K * cdiv(d->Cin, BK));
@@ -2998,10 +3023,31 @@ extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const fl
   WgradArgs w; memset(&w, 0, sizeof(w));
   w.gy = gy; w.gy_bstride = (long)d->Cout * d->Tout; w.M = d->Cout; w.Tout = d->Tout; w.B = d->B;
   w.nseg = d->K;
+  const bool phases = phase_split_ok(d) && (p.slab_floats + p.bslab_floats + phase_split_floats(d)) * sizeof(float) <= ws_bytes;
+  float* xe = nullptr;
+  float* xo = nullptr;
+  const int Tp = phase_pitch(d);
+  if (phases) {
+    xe = (float*)ws + ((p.slab_floats + p.bslab_floats + 63) / 64) * 64;
+    xo = xe + (size_t)d->B * d->Cin * Tp;
+    const long rows = (long)d->B * d->Cin;
+    long nb = (rows * Tp + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(phase_split_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, rows, d->Tin, Tp, xe, xo, skip_flag);
+    VQ_LAUNCH_CHECK();
+  }
   for (int j = 0; j < d->K; ++j) {
     WSeg& sg = w.seg[j];
-    sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
-    sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
+    const int e = j * d->dil - d->pad;
+    if (phases) {
+      const bool odd = (e & 1) != 0;
+      sg.x = odd ? xo : xe; sg.x_bstride = (long)d->Cin * Tp; sg.x_cstride = Tp; sg.cin = d->Cin;
+      sg.Tin = odd ? d->Tin / 2 : (d->Tin + 1) / 2;
+      sg.tmul = 1; sg.toff = odd ? (e - 1) >> 1 : e >> 1; sg.tdiv = 1;       // (arithmetic shifts: floor for negative e)
+    } else {
+      sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
+      sg.tmul = d->stride; sg.toff = e; sg.tdiv = 1;
+    }
     sg.gw = gW + j; sg.gw_co_stride = (long)d->Cin * d->K; sg.gw_ci_stride = d->K;
   }
   w.seg[0].gb = gb; w.accumulate = accumulate;

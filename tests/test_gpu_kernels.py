@@ -768,3 +768,34 @@ def test_embed_index_wgrad_sorted_gather_edge_cases(gpu, case):
     for o in outs[1:]:
         np.testing.assert_array_equal(o[0], outs[0][0])
         np.testing.assert_array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize('stride,Tin', [(2, 8), (2, 32), (2, 96), (2, 160), (2, 250), (2, 480), (1, 48), (1, 16), (1, 80)])
+def test_conv_weight_gradient_row_lengths(gpu, matmul_mode, stride, Tin):
+    """vqvae_conv1d_bwd_weight over row lengths around the kernels' step sizes (16 positions per K step, 32 per step of
+    the split plan): output rows of 16, 24, 40, 48, 80 ... positions -- a row whose length is 16 mod 32 ends in a
+    16-position step that lies wholly beyond it (found in round 3: such a row read the next one) -- and the stride-2
+    form (net.py:14-28: the encoder), which runs as stride-1 segments over the even / odd phases of x."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(Tin * 7 + stride)
+    B, Cin, Cout, K = 3, 64, 256, 4
+    pad = 1 if stride == 2 else 3
+    Tout = (Tin + 2 * pad - K) // stride + 1 if stride == 2 else Tin
+    x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / 16).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    gy = rs.standard_normal((B, Cout, Tout)).astype(np.float32)
+    vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+    if stride == 2:
+        y = F.convolution_1d(vx, vW, vb, stride=2, pad=pad)
+    else:
+        y = F.convolution_1d(vx, vW, vb, pad=pad, out_len=Tin)           # causal: pad K-1, cropped to the input length
+    assert y.shape[2] == Tout
+    y.grad = _dev(gpu, to4(gy))
+    y.backward()
+    xp = np.zeros((B, Cin, Tin + 2 * pad + K), np.float64)
+    xp[:, :, pad:pad + Tin] = x
+    want = np.stack([np.einsum('bot,bit->oi', gy.astype(np.float64), xp[:, :, j:j + stride * Tout:stride]) for j in range(K)], axis=2)
+    assert_close_scaled(vW.grad.get()[..., 0], want, 1e-4, 'gW stride %d Tin %d' % (stride, Tin))
+    assert_close_scaled(vb.grad.get(), gy.sum(axis=(0, 2), dtype=np.float64), 1e-4, 'gb')
