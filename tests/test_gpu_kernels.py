@@ -106,6 +106,10 @@ RB_CASES = [
     (1, 300, 96, 128, 80, 40, 2, 8),        # ragged T, mixed channels
     (2, 384, 256, 256, 256, 192, 2, 512),   # real channel counts, dilation > T
     (1, 200, 64, 64, 64, 16, 3, 4),         # filter_size 3
+    (2, 48, 256, 256, 256, 192, 2, 4),      # rows of 16 mod 32 positions (the weight gradients' last K step lies beyond the row)
+    (3, 80, 64, 64, 64, 48, 2, 1),
+    (1, 112, 256, 256, 256, 192, 2, 16),
+    (2, 16, 64, 64, 64, 48, 2, 2),
 ]
 
 
@@ -799,3 +803,48 @@ def test_conv_weight_gradient_row_lengths(gpu, matmul_mode, stride, Tin):
     want = np.stack([np.einsum('bot,bit->oi', gy.astype(np.float64), xp[:, :, j:j + stride * Tout:stride]) for j in range(K)], axis=2)
     assert_close_scaled(vW.grad.get()[..., 0], want, 1e-4, 'gW stride %d Tin %d' % (stride, Tin))
     assert_close_scaled(vb.grad.get(), gy.sum(axis=(0, 2), dtype=np.float64), 1e-4, 'gb')
+
+
+def _fuzz_conv_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        B = int(rs.randint(1, 4))
+        Cin = int(rs.choice([1, 3, 16, 48, 64, 128, 256]))
+        Cout = int(rs.choice([8, 32, 64, 128, 256]))
+        K = int(rs.randint(1, 5))
+        stride = int(rs.choice([1, 1, 2]))
+        dil = 1 if stride == 2 else int(rs.choice([1, 1, 2, 4]))
+        T = int(rs.choice([4, 7, 16, 31, 32, 33, 48, 64, 80, 100, 127, 128, 144, 200, 256, 272, 300]))
+        pad = int(rs.randint(0, (K - 1) * dil + 1))
+        if (T + 2 * pad - (K - 1) * dil - 1) // stride + 1 < 1:
+            continue
+        cases.append((B, Cin, Cout, K, stride, dil, pad, T))
+    return cases
+
+
+@pytest.mark.parametrize('case', _fuzz_conv_cases(48, 20260928), ids=lambda c: 'B%d_Ci%d_Co%d_K%d_s%d_d%d_p%d_T%d' % c)
+def test_conv1d_random_shapes_vs_oracle(gpu, matmul_mode, case):
+    """Forward, backward-data and backward-weight of F.convolution_1d on 48 seeded random shapes (channel counts off the
+    tile sizes, row lengths around the kernels' step sizes, strides, dilations, paddings) against the oracle's conv
+    (net.py:14-28, WaveNet/modules.py:13-16 use it with these parameters): the fixed shapes of the other tests are the
+    configured ones; this one looks for the shape nobody configured."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Cout, K, stride, dil, pad, T = case
+    rs = np.random.RandomState(zlib.crc32(repr(case).encode()) & 0x7fffffff)
+    x = rs.standard_normal((B, Cin, T)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    y_ref = O.conv1d_fwd(x, W, b, stride, pad, dil)
+    gy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    gx_ref, gW_ref, gb_ref = O.conv1d_bwd(x, W, gy, stride, pad, dil)
+    vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+    y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil)
+    assert y.shape[:3] == y_ref.shape
+    assert_close(y.data.get()[..., 0], y_ref, 1e-4, 'fwd')
+    y.grad = _dev(gpu, to4(gy))
+    y.backward()
+    assert_close_scaled(vx.grad.get()[..., 0], gx_ref, 1e-4, 'gx')
+    assert_close_scaled(vW.grad.get()[..., 0], gW_ref, 1e-4, 'gW')
+    assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'gb')
