@@ -128,6 +128,12 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) 
 __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
+#ifndef X3_GATE_ST_AUX
+#define X3_GATE_ST_AUX 2      // cache policy of the gate epilogue's three stores: non-temporal (tanh / sigmoid are next read in the backward pass; z by the next launch, which measured no slower for it).  Gate kernel 199.5 -> 195.5-196 us, step -0.1 ms
+#endif
+__device__ __forceinline__ void buf_st_gate(float v, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, X3_GATE_ST_AUX);
+}
 
 // WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
 // halves the activation-tile loads per FLOP and is used whenever M >= 256.
@@ -407,10 +413,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
         if (X3_ABL == 10 && ta != 123456.789f) continue;     // timing only: the math without the stores
-        buf_st(ta, rG, vT[ni], sT);
-        buf_st(sb, rG, vT[ni], sT + sGq);
+        buf_st_gate(ta, rG, vT[ni], sT);
+        buf_st_gate(sb, rG, vT[ni], sT + sGq);
         if (a.z16) __builtin_amdgcn_raw_buffer_store_b16((short)(pack_bf16x2(ta * sb, 0.f) & 0xffffu), rZ, vT[ni] >> 1, sT >> 1, 0);
-        else buf_st(ta * sb, rZ, vT[ni], sT);
+        else buf_st_gate(ta * sb, rZ, vT[ni], sT);
       }
     }
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
