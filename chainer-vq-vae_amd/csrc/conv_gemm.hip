@@ -128,6 +128,9 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) 
 __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
+#ifndef X3_GBWD_LD_AUX
+#define X3_GBWD_LD_AUX 2      // cache policy of the gate-derivative epilogue's loads of tanh / sigmoid (their last use): non-temporal, step -0.08 ms
+#endif
 #ifndef X3_GATE_ST_AUX
 #define X3_GATE_ST_AUX 2      // cache policy of the gate epilogue's three stores: non-temporal (tanh / sigmoid are next read in the backward pass; z by the next launch, which measured no slower for it).  Gate kernel 199.5 -> 195.5-196 us, step -0.1 ms
 #endif
@@ -443,8 +446,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             const int dr = (r & 3) + 8 * (r >> 2);
             const bool ok = tok && mb + dr < Ch;
             const unsigned so = 4u * (unsigned)(dr * T);
-            ta[mi][ni][r] = ok ? buf_ld(rGt, voff, so) : 0.f;
-            sb[mi][ni][r] = ok ? buf_ld(rGt, voff, so + sQ) : 0.f;
+            ta[mi][ni][r] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGt, voff, so, X3_GBWD_LD_AUX)) : 0.f;
+            sb[mi][ni][r] = ok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGt, voff, so + sQ, X3_GBWD_LD_AUX)) : 0.f;
           }
         }
 #pragma unroll
@@ -2119,6 +2122,9 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // NP = bf16 pieces per operand: 3 (mode 2) or 1 (mode 1: operands rounded to bf16, one product).
 // X16 (matmul mode 1): the x operand (the z tensors: unshifted, T a multiple of 16) is stored as bf16 -- 8-byte loads
 // of 4 t, staged as they are.
+#ifndef W3_LD_AUX
+#define W3_LD_AUX 0           // cache policy of the weight-gradient kernels' operand loads (experiment: non-temporal = 2 costs 1.5 ms per step, the column tiles of a launch share their output-gradient rows through L2)
+#endif
 #ifndef W3_LEAN
 #define W3_LEAN 1             // 256 x 128 tiles, six products: compiled for 128 VGPRs (two 8-wave workgroups per CU)
 #endif
@@ -2227,12 +2233,12 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
       _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = (any && b_ok[i]) ? vrow[i] + XSZ * (unsigned)tc : OOB; \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
-      RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, 0)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
+      RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       if constexpr (X16) {                       /* 4 bf16 = 8 bytes, raw, in .x / .y (host: toff == 0, Tout % 16 == 0) */ \
-        const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rbx, vo_[i], sob, 0)); \
+        const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rbx, vo_[i], sob, W3_LD_AUX)); \
         RB[i] = make_float4(__builtin_bit_cast(float, h_.x), __builtin_bit_cast(float, h_.y), 0.f, 0.f); \
-      } else RB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbx, vo_[i], sob, 0)); \
+      } else RB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbx, vo_[i], sob, W3_LD_AUX)); \
     }                                                                                          \
   }
   auto advance = [&]() {
