@@ -128,6 +128,16 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) 
 __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
+// Cache policy of the epilogues' stores (2 = non-temporal), A/B'd per epilogue at configs[1] on one box:
+#ifndef X3_LIN_ST_AUX
+#define X3_LIN_ST_AUX 2       // linear epilogue (interior tiles): -0.1 ms per step
+#endif
+#ifndef X3_GBWD_ST_AUX
+#define X3_GBWD_ST_AUX 0      // gate-derivative epilogue (gh, read by the next three launches): non-temporal +0.07 ms
+#endif
+#ifndef L128_ST_AUX
+#define L128_ST_AUX 0         // streaming residual 1x1 (the next block's input): non-temporal +0.12 ms
+#endif
 #ifndef X3_GBWD_LD_AUX
 #define X3_GBWD_LD_AUX 2      // cache policy of the gate-derivative epilogue's loads of tanh / sigmoid (their last use): non-temporal, step -0.08 ms
 #endif
@@ -238,7 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           for (int r = 0; r < 16; ++r) {
             float v = acc[mi][ni][r] + pv[p][r];
             if (od.relu) v = fmaxf(v, 0.f);
-            buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
           }
         }
       } else {
@@ -275,7 +285,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             for (int r = 0; r < 16; ++r) {
               float v = acc[mi][ni][r] + pv[p & 1][r];
               if (od.relu) v = fmaxf(v, 0.f);
-              buf_st(v, ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
             }
           }
         }
@@ -465,8 +475,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
               const float gz = acc[mi][ni][r];
               const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
               const unsigned so = 4u * (unsigned)(dr * T);
-              buf_st(gz * sv * (1.f - tv * tv), rGh, voff, so);
-              buf_st(gz * tv * sv * (1.f - sv), rGh, voff, so + sQ);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(gz * sv * (1.f - tv * tv))), rGh, voff, so, X3_GBWD_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(gz * tv * sv * (1.f - sv))), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
             }
           }
         }
@@ -1536,7 +1546,7 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
             const int r = 4 * q + j;                                                           \
             float v = acc[cb][r] + bv[j];                                                      \
             if constexpr (HAS_ADD) v += XCUR[cb][r];                                           \
-            buf_st(v, ry, voff, sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T));           \
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T), L128_ST_AUX);           \
           }                                                                                    \
       }                                                                                        \
     }                                                                                          \
