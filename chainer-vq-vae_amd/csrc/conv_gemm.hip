@@ -135,6 +135,14 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 #ifndef X3_GBWD_ST_AUX
 #define X3_GBWD_ST_AUX 0      // gate-derivative epilogue (gh, read by the next three launches): non-temporal +0.07 ms
 #endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifndef L128_Z_NT
+#define L128_Z_NT 1           // z is streamed non-temporally (it was stored that way by the gate kernel; next reads: the skip sum after the stack, the backward): step -0.09 ms, and the gate kernel beside it -1.4 %
+#endif
+#ifndef L128_X_AUX
+#define L128_X_AUX 2           // the residual operand x_l is read non-temporally (after this launch nobody needs it before the backward): the NEXT gate launch then finds its own operand still cached -- gate kernel 193 -> 181 us, step -0.1 ms
+#endif
 #ifndef L128_ST_AUX
 #define L128_ST_AUX 0         // streaming residual 1x1 (the next block's input): non-temporal +0.12 ms
 #endif
@@ -1468,10 +1476,10 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
         }                                                                                      \
       } else                                                                                   \
       if constexpr (CPC == 4) {                                                                \
-        const float4 v_ = *reinterpret_cast<const float4*>(p_ + (long)j * T);                  \
+        const float4 v_ = L128_Z_NT ? __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p_ + (long)j * T))) : *reinterpret_cast<const float4*>(p_ + (long)j * T); \
         zr[j][0] = v_.x; zr[j][1] = v_.y; zr[j][2] = v_.z; zr[j][3] = v_.w;                    \
       } else {                                                                                 \
-        const float2 v_ = *reinterpret_cast<const float2*>(p_ + (long)j * T);                  \
+        const float2 v_ = L128_Z_NT ? __builtin_bit_cast(float2, __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p_ + (long)j * T))) : *reinterpret_cast<const float2*>(p_ + (long)j * T); \
         zr[j][0] = v_.x; zr[j][1] = v_.y;                                                      \
       }                                                                                        \
     }                                                                                          \
@@ -1506,7 +1514,7 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     const unsigned sb_ = 4u * (unsigned)(32 * wave * T + t_);                                  \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                         \
       _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
-        XV[cb][r] = buf_ld(rx_, voff, sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T)); \
+        XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff, sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T), L128_X_AUX)); \
   }
   // one tile: MFMAs on LDS buffer CUR, next tile's z -> the other buffer, epilogue with XCUR while
   // XNXT (the next tile's residual) and the z tile after the next travel
