@@ -92,6 +92,7 @@ struct GemmArgs {
   // once (the one-hot embed conv launches its gather form and this dense form; a flag computed on
   // the device picks one of them without a host round trip)
   const int32_t* skip_flag;
+  int x_nt;      // the activations of every segment are read once by this launch and by nothing soon after (the skip sum over all blocks' z): non-temporal loads
   int z16;       // matmul mode 1 only: EPI_GATE writes z (out[1]) as bf16; a linear GEMM reads the activations of EVERY segment as bf16 (the z tensors)
 };
 
@@ -131,6 +132,15 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 // Cache policy of the epilogues' stores (2 = non-temporal), A/B'd per epilogue at configs[1] on one box:
 #ifndef X3_LIN_ST_AUX
 #define X3_LIN_ST_AUX 2       // linear epilogue (interior tiles): -0.1 ms per step
+#endif
+#ifndef X3_LIN_ADD_AUX
+#define X3_LIN_ADD_AUX 2       // linear epilogue: the added operand (g_res in the backward-data launches: its last use before the res weight gradients) is read non-temporally: step -0.1 ms
+#endif
+#ifndef X3_SKIP_X_NT
+#define X3_SKIP_X_NT 0         // skip sum: every z read non-temporally -- neutral (21.24 vs 21.26 ms)
+#endif
+#ifndef X3_GBWD_B0_AUX
+#define X3_GBWD_B0_AUX 0       // gate-derivative GEMM: g_res fetched non-temporally -- +0.1 ms
 #endif
 #ifndef X3_GBWD_ST_AUX
 #define X3_GBWD_ST_AUX 0      // gate-derivative epilogue (gh, read by the next three launches): non-temporal +0.07 ms
@@ -237,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           if (src) {
             const rsrc_t rs = make_rsrc(src);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pv[q][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+            for (int r = 0; r < 16; ++r) pv[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ADD_AUX));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv[q][r] = 0.f;
@@ -275,7 +285,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             if (src) {
               const rsrc_t rs = make_rsrc(src);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) pv[q & 1][r] = buf_ld(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T));
+              for (int r = 0; r < 16; ++r) pv[q & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ADD_AUX));
             } else {
 #pragma unroll
               for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
@@ -972,9 +982,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
   float pb[CPT], qb[CPT];
   [[maybe_unused]] unsigned pmask = 0, qmask = 0;           // (unused since the buffer loads: kept so that the staging macro's signature is unchanged)
-#define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw, vb, rx, !TAP2)
-#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, (X3_ABL == 9 ? 0x80000000u : vb1), rx1, false)   /* ABL 9 (timing only): the second tap's activations are not fetched (every load out of range) */
-#define X3_FETCH_(A0, A1, A2, BV, SW, VB, RX, ADV)                                           \
+#define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw, vb, rx, !TAP2, ((EPI == EPI_GATE_BWD && TAP2) ? X3_GBWD_B0_AUX : (a.x_nt ? 2 : 0)))
+#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, (X3_ABL == 9 ? 0x80000000u : vb1), rx1, false, 0)   /* ABL 9 (timing only): the second tap's activations are not fetched (every load out of range) */
+#define X3_FETCH_(A0, A1, A2, BV, SW, VB, RX, ADV, BAUX)                                     \
   {                                                                                          \
     if (X3_ABL == 2 || X3_ABL == 5) { A0 = make_uint4(va, 1u, 2u, 3u); A1 = A0; A2 = A0; } else {  \
     A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));  \
@@ -992,7 +1002,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       const float4 l1_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(RX, vq_, sx + xcsb, 0)); \
       BV[0] = l0_.x; BV[1] = l0_.y; BV[2] = l0_.z; BV[3] = l0_.w; BV[4] = l1_.x; BV[5] = l1_.y; BV[6] = l1_.z; BV[7] = l1_.w; \
     } else                                                                                     \
-    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = (X3_ABL == 1 || X3_ABL == 5) ? __builtin_bit_cast(float, (VB) + (unsigned)e) : (X3_ABL == 6 ? buf_ld(RX, 0u, 0u) : (X3_ABL == 7 ? buf_ld(RX, ((VB) & 0x7fffffffu) % 4096u, 0u) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb))); \
+    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = (X3_ABL == 1 || X3_ABL == 5) ? __builtin_bit_cast(float, (VB) + (unsigned)e) : (X3_ABL == 6 ? buf_ld(RX, 0u, 0u) : (X3_ABL == 7 ? buf_ld(RX, ((VB) & 0x7fffffffu) % 4096u, 0u) : ((BAUX) == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RX, (VB), sx + (unsigned)e * xcsb, 2)) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb)))); \
     if (!SCHED && (ADV)) advance();                                                          \
   }
 #define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
@@ -3512,6 +3522,7 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   g.out[0].bias = bsum;
   g.out[0].accumulate = accumulate;
   g.z16 = z_bf16(d) ? 1 : 0;
+  g.x_nt = X3_SKIP_X_NT;
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st);
 }
 
