@@ -147,6 +147,7 @@ __device__ __forceinline__ void buf_st(float v, rsrc_t r, unsigned voff, unsigne
 #endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 #ifndef L128_Z_NT
 #define L128_Z_NT 1           // z is streamed non-temporally (it was stored that way by the gate kernel; next reads: the skip sum after the stack, the backward): step -0.09 ms, and the gate kernel beside it -1.4 %
 #endif
@@ -1477,11 +1478,11 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
       if constexpr (Z16) {                        /* raw bf16 bits in the low half of a register */ \
         if constexpr (CPC == 4) {                                                              \
-          const uint2 v_ = *reinterpret_cast<const uint2*>(h_ + (long)j * T);                  \
+          const uint2 v_ = L128_Z_NT ? __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(h_ + (long)j * T))) : *reinterpret_cast<const uint2*>(h_ + (long)j * T); \
           zr[j][0] = __builtin_bit_cast(float, v_.x & 0xffffu); zr[j][1] = __builtin_bit_cast(float, v_.x >> 16); \
           zr[j][2] = __builtin_bit_cast(float, v_.y & 0xffffu); zr[j][3] = __builtin_bit_cast(float, v_.y >> 16); \
         } else {                                                                               \
-          const unsigned v_ = *reinterpret_cast<const unsigned*>(h_ + (long)j * T);            \
+          const unsigned v_ = L128_Z_NT ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(h_ + (long)j * T)) : *reinterpret_cast<const unsigned*>(h_ + (long)j * T); \
           zr[j][0] = __builtin_bit_cast(float, v_ & 0xffffu); zr[j][1] = __builtin_bit_cast(float, v_ >> 16); \
         }                                                                                      \
       } else                                                                                   \
