@@ -51,4 +51,9 @@ struct ProfScope {
   ~ProfScope() { if (tag) prof_end(tag, s); }
 };
 
+// A launch timed by the events of its OWN dispatch packet (hipExtLaunchKernelGGL(start, stop)): no event packets
+// before and after the kernel on the stream -- those cost ~5.6 us of idle queue each, 0.22 ms per step when the 20 gate
+// launches of the bench are timed (tools/phase_trace.py).  prof_attach returns false when the tag is not enabled.
+bool prof_attach(int tag, hipEvent_t* start, hipEvent_t* stop);
+
 }  // namespace vq

@@ -25,6 +25,7 @@
 //   pack_kernel             re-lays Chainer (Cout,Cin,K,1) weights as the A slabs the GEMMs want
 //                           (mode 0: [k][m] fp32; modes 1, 2: pre-split 16-byte fragment words).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -2628,7 +2629,15 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     if (sp > 1) { g.ksplit = sp; g.ksteps_per_split = cdiv(nk, sp); }
   }
   const long grid = nblk * g.ksplit;
-  ProfScope ps(tag, st);
+  // timing (vqvae_prof_*): the GEMM kernel of this call is timed by its own dispatch's events (a split-K reduce behind it is not)
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  const bool attach = prof_attach(tag, &pe0, &pe1);
+  ProfScope ps(attach ? 0 : tag, st);
+#define LG_LAUNCH(KERNEL, GRID, BLOCK, ARG)                                                                    \
+  do {                                                                                                          \
+    if (attach) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, pe0, pe1, 0, ARG);                            \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, ARG);                                                   \
+  } while (0)
   // the K = 128 -> 256-row projection with residual add (the ResidualBlock `res` conv): streaming kernel
   if constexpr (EPI == EPI_LINEAR) {
     static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;   // 0: off; 32 / 64: column tile
@@ -2654,13 +2663,13 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       const unsigned nwg = (unsigned)(la.ntiles < n_cu ? la.ntiles : n_cu);
 #define L128_LAUNCH(NPv, NCv)                                                                                        \
       do {                                                                                                           \
-        if (la.add) hipLaunchKernelGGL((lin128_stream_kernel<NPv, NCv, true>), dim3(nwg), dim3(512), 0, st, la);     \
-        else hipLaunchKernelGGL((lin128_stream_kernel<NPv, NCv, false>), dim3(nwg), dim3(512), 0, st, la);           \
+        if (la.add) LG_LAUNCH((lin128_stream_kernel<NPv, NCv, true>), dim3(nwg), dim3(512), la);     \
+        else LG_LAUNCH((lin128_stream_kernel<NPv, NCv, false>), dim3(nwg), dim3(512), la);           \
       } while (0)
       if (g_matmul_dtype == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
       else if (g.z16) {
-        if (la.add) hipLaunchKernelGGL((lin128_stream_kernel<1, 32, true, true>), dim3(nwg), dim3(512), 0, st, la);
-        else hipLaunchKernelGGL((lin128_stream_kernel<1, 32, false, true>), dim3(nwg), dim3(512), 0, st, la);
+        if (la.add) LG_LAUNCH((lin128_stream_kernel<1, 32, true, true>), dim3(nwg), dim3(512), la);
+        else LG_LAUNCH((lin128_stream_kernel<1, 32, false, true>), dim3(nwg), dim3(512), la);
       }
       else { if (nc == 32) L128_LAUNCH(1, 32); else L128_LAUNCH(1, 64); }
 #undef L128_LAUNCH
@@ -2691,8 +2700,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
 #define X3_LAUNCH(WMv, NBv, NPv, blocks, threads)                                                                    \
   do {                                                                                                                \
-    if (tap2) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, true>), dim3((unsigned)(blocks)), dim3(threads), 0, st, g);  \
-    else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, false>), dim3((unsigned)(blocks)), dim3(threads), 0, st, g);      \
+    if (tap2) LG_LAUNCH((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, true>), dim3((unsigned)(blocks)), dim3(threads), g);  \
+    else LG_LAUNCH((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, false>), dim3((unsigned)(blocks)), dim3(threads), g);      \
   } while (0)
   // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
   // not instantiated
@@ -2704,8 +2713,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     const int ddil = g.nseg == 2 ? abs(g.seg[0].toff - g.seg[1].toff) : 0;
     if (x3_win && tap2 && wide && g.seg[0].x == g.seg[1].x && g.seg[0].tmul == 1 && g.seg[0].tdiv == 1 &&
         ddil >= 1 && ddil <= WIN_MAX_DIL && g.skip_flag == nullptr) {
-      if (g_matmul_dtype == 2) hipLaunchKernelGGL((conv_win_x3_kernel<EPI, 3>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((conv_win_x3_kernel<EPI, 1>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
+      if (g_matmul_dtype == 2) LG_LAUNCH((conv_win_x3_kernel<EPI, 3>), dim3((unsigned)nblk2), dim3(512), g);
+      else LG_LAUNCH((conv_win_x3_kernel<EPI, 1>), dim3((unsigned)nblk2), dim3(512), g);
       VQ_LAUNCH_CHECK();
       return 0;
     }
@@ -2714,8 +2723,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     if (g.z16) {
       VQ_REQUIRE(g_matmul_dtype == 1 && big && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1 and 256-row tiles");
       for (int i = 0; i < g.nseg; ++i) VQ_REQUIRE(g.seg[i].tmul == 1 && g.seg[i].tdiv == 1, "conv_gemm: bf16-stored activations: stride-1 segments only");
-      if (wide) hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, true>), dim3((unsigned)nblk2), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, true>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+      if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, true>), dim3((unsigned)nblk2), dim3(512), g);
+      else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, true>), dim3((unsigned)nblk), dim3(512), g);
       VQ_LAUNCH_CHECK();
       return 0;
     }
@@ -2728,19 +2737,20 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       if (wide) X3_LAUNCH(4, 2, 1, nblk2, 512);
       else X3_LAUNCH(4, 1, 1, nblk, 512);
     } else if (big) {
-      hipLaunchKernelGGL((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), 0, st, g);
+      LG_LAUNCH((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), g);
     }
     if (!big) {
       if (g_matmul_dtype == 2) X3_LAUNCH(2, 1, 3, grid, 256);
       else if (g_matmul_dtype == 1) X3_LAUNCH(2, 1, 1, grid, 256);
-      else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
+      else LG_LAUNCH((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), g);
     }
   } else {
     if (g_matmul_dtype == 2) X3_LAUNCH(2, 1, 3, grid, 256);
     else if (g_matmul_dtype == 1) X3_LAUNCH(2, 1, 1, grid, 256);
-    else hipLaunchKernelGGL((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else LG_LAUNCH((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), g);
   }
 #undef X3_LAUNCH
+#undef LG_LAUNCH
   VQ_LAUNCH_CHECK();
   if (g.ksplit > 1) {
     const long total = nblk * 128 * 128;

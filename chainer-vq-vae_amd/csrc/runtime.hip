@@ -43,6 +43,15 @@ void prof_begin(int tag, hipStream_t s) {
   g_prof_open[tag] = e;
 }
 
+bool prof_attach(int tag, hipEvent_t* start, hipEvent_t* stop) {
+  if (tag <= 0 || tag >= VQVAE_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEvent_t a = prof_get_event(), b = prof_get_event();
+  if (!a || !b) return false;
+  *start = a; *stop = b;
+  g_prof_pairs.push_back({a, b, tag});
+  return true;
+}
 void prof_end(int tag, hipStream_t s) {
   if (tag <= 0 || tag >= VQVAE_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -34,3 +34,7 @@ for s, e, name in step[i_gbwd_last + 1:len(step) - 1]:
 print('rest of backward, by kernel:')
 for k, v in c.most_common(14):
     print('  %-72s x%3d  %7.3f ms' % (k, n[k], v / 1e6))
+print('gaps > 4 us in the step:')
+for (s0, e0, n0), (s1, e1, n1) in zip(step[:-1], step[1:]):
+    if s1 - e0 > 4000:
+        print('  %6.1f us  after %-50s before %s' % ((s1 - e0) / 1e3, n0.split('(')[0][-50:], n1.split('(')[0][-50:]))
