@@ -395,7 +395,7 @@ def main():
                          'shape, latency-bound) and ~1 M (default 8738 x 120 = 1 048 560)')
     ap.add_argument('--bf16', action='store_true',
                     help='bf16 MFMA operands with fp32 accumulation (configs[4] precision)')
-    ap.add_argument('--matmul', choices=['float32x3', 'float32'], default=None,
+    ap.add_argument('--matmul', choices=['float32x2', 'float32x3', 'float32'], default=None,
                     help="fp32 matmul mode: 'float32x3' (default; fp32 products as six bf16 MFMA products of an "
                          "exact three-way operand split) or 'float32' (v_mfma_f32_32x32x2_f32)")
     ap.add_argument('--index-input', action='store_true',
@@ -570,7 +570,10 @@ def main():
                                     '(h + m + l), six of the nine products on v_mfma_f32_32x32x16_bf16 with fp32 '
                                     'accumulate (the dropped three are < 2^-25 relative); error against float64 is at '
                                     'or below the fp32 MFMA path\'s (tests/test_gpu_kernels.py::'
-                                    'test_float32x3_is_as_accurate_as_fp32_mfma)'}[mode],
+                                    'test_float32x3_is_as_accurate_as_fp32_mfma)',
+                       'float32x2': 'fp32 operands, fp32 results: each operand scaled by a power of two per tensor and split '
+                                    'into two fp16 (hi + lo), three products on v_mfma_f32_32x32x16_f16 with fp32 accumulate; '
+                                    'error against float64 at or below the fp32 MFMA path\'s (same test)'}[mode],
             'data': 'synthetic' + (' (x_dec as device-computed bin indices)' if args.index_input else ''),
             'samples_per_sec_per_gpu': value / n,
             'config': {'workload': ('BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '

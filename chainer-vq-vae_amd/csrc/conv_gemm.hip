@@ -27,6 +27,8 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 namespace vq {
@@ -35,10 +37,15 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 
 // 0: fp32 operands on v_mfma_f32_32x32x2_f32; 1: operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32),
 // v_mfma_f32_32x32x16_bf16, fp32 accumulate; 2 (default): fp32 products as six bf16 MFMA products of an
 // exact three-way split of both operands (conv_gemm_x3_kernel / wgrad3_kernel below).
+// 3: fp32 products as THREE fp16 MFMA products of a two-way split of both operands scaled by a power of two
+// per tensor (`float32x2`, section "matmul mode 3" below) wherever the caller provides the operands' absolute
+// maxima (the ResidualNet chain, the large generic convs); mode 2's kernels everywhere else.
 // HBM tensors, epilogues and accumulators stay fp32 in every mode.
 static int g_matmul_dtype = 2;
 static int g_wgrad_impl = 0;      // 0: auto; 1: force the generic wgrad_kernel (tests / A-B timing)
@@ -57,6 +64,11 @@ struct Seg {
   int vec;             // host says: strides/pointer allow aligned float4 rows
   const float* w;      // packed A^T slab [cin_pad16][ldw]
   int ldw;
+  // float32x2 (NP = 2) only: where the absolute maximum of the activation tensor is (device, float bits; any
+  // upper bound will do) or, with amax == nullptr, a host-known bound; and the absolute maximum pack_kernel
+  // scaled this slab's weights by
+  const unsigned* amax; float amax_static;
+  const unsigned* wamax;
 };
 
 struct OutR {          // one row range of M
@@ -64,6 +76,7 @@ struct OutR {          // one row range of M
   const float* add; long add_bstride;   // residual add / gates input
   const float* bias; const float* bias2;
   int rows; int accumulate; int relu;
+  unsigned* amax_out;  // range 0 only, nullable: atomicMax of |y| over everything this launch stores (float bits)
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_GATE_BWD = 2 };
@@ -94,6 +107,7 @@ struct GemmArgs {
   // the device picks one of them without a host round trip)
   const int32_t* skip_flag;
   int x_nt;      // the activations of every segment are read once by this launch and by nothing soon after (the skip sum over all blocks' z): non-temporal loads
+  int f16x2;     // matmul mode 3: every segment carries its maxima and a format-3 slab -> the float32x2 kernels (NP = 2); otherwise mode 3 runs mode 2's
   int z16;       // matmul mode 1 only: EPI_GATE writes z (out[1]) as bf16; a linear GEMM reads the activations of EVERY segment as bf16 (the z tensors)
 };
 
@@ -115,6 +129,41 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // RN
   bf16x2 v;
   v[0] = (__bf16)lo; v[1] = (__bf16)hi;
   return __builtin_bit_cast(unsigned, v);
+}
+
+// float32x2 scale bookkeeping.  A tensor's absolute maximum travels as the bit pattern of a non-negative float
+// (unsigned compare == float compare), spread over AMAX_SLOTS words: a producer raises ONE of them per workgroup
+// (atomicMax on slot blockIdx & 15 -- thousands of same-address atomics per launch cost 50 us, measured), a consumer
+// takes the maximum of all.  Scales are powers of two taken from its exponent: 2^(14 - e) puts a tensor with amax in
+// [2^e, 2^(e+1)) into [2^14, 2^15) < 65504.
+constexpr int AMAX_SLOTS = 16;
+__device__ __forceinline__ int amax_expo(unsigned bits) {        // unbiased exponent; zero / denormal amax -> -126
+  const int e = (int)((bits >> 23) & 0xffu);
+  return (e < 1 ? 1 : e) - 127;
+}
+__device__ __forceinline__ unsigned amax_load(const unsigned* p) {      // max over the slots, wave-uniform
+  unsigned v = p[threadIdx.x & (AMAX_SLOTS - 1)];
+#pragma unroll
+  for (int o = AMAX_SLOTS / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+// m >= 0: this thread's max |value stored|.  EVERY thread of the workgroup must call (two barriers).
+__device__ __forceinline__ void amax_commit(float m, unsigned* dst) {
+  __shared__ float red[16];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)(blockDim.x >> 6);
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+    atomicMax(dst + (blockIdx.x & (AMAX_SLOTS - 1)), __builtin_bit_cast(unsigned, m));
+  }
+  __syncthreads();
 }
 
 // Buffer-resource addressing for the epilogues: base in four SGPRs, one 32-bit VGPR byte offset per
@@ -174,9 +223,6 @@ __device__ __forceinline__ void buf_st_gate(float v, rsrc_t r, unsigned voff, un
 // (rows m0 + wm*64 + mi*32, columns t0 + wn*64 + ni*32) of batch item b.  SPLITK: this instantiation
 // may have been launched with ksplit > 1 (raw partial tiles out, gemm_splitk_reduce_kernel finishes).
 // DEEP: the linear epilogue requests a whole block's operands up front (needs 64 more registers).
-#ifndef X3_ABL
-#define X3_ABL 0              // timing experiments only (wrong results), see conv_gemm_x3_kernel; 10: the gate epilogue issues no stores, 11: no gate epilogue at all
-#endif
 template <int EPI, int WM, bool SPLITK, bool DEEP = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
                                               const int b, const int wm, const int wn, const int li, const int lk,
@@ -184,6 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
   // ---- epilogue ----------------------------------------------------------
   // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int T = a.Tout;
+  float am = 0.f;                 // max |value stored| (published through out[0].amax_out when the caller asked for it)
   if (SPLITK && a.ksplit > 1) {
     float* pt = a.partial + ((long)ksp * ntiles_all + tile_id) * (128 * 128);
 #pragma unroll
@@ -268,6 +315,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           for (int r = 0; r < 16; ++r) {
             float v = acc[mi][ni][r] + pv[p][r];
             if (od.relu) v = fmaxf(v, 0.f);
+            am = fmaxf(am, fabsf(v));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
           }
         }
@@ -305,6 +353,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             for (int r = 0; r < 16; ++r) {
               float v = acc[mi][ni][r] + pv[p & 1][r];
               if (od.relu) v = fmaxf(v, 0.f);
+              am = fmaxf(am, fabsf(v));
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
             }
           }
@@ -362,29 +411,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             if (tok && mrb + dr < rows_left) {
               float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
               if (od.relu) v = fmaxf(v, 0.f);
+              am = fmaxf(am, fabsf(v));
               yp[(long)dr * T] = v;
             }
           }
         }
       }
     }
+    if (a.out[0].amax_out != nullptr) amax_commit(am, a.out[0].amax_out);
   } else if (EPI == EPI_GATE) {
     // packed rows: each 64-row wave tile = 32 tanh rows (mi=0) + the matching 32
     // sigmoid rows (mi=1) of channel group g.
     const int Ch = a.M >> 1;
     const int g = (m0 + wm * 64) >> 6;
     const OutR& og = a.out[0];   // gates (B, 2Ch, T)
-    if (X3_ABL == 11) {          // timing only: the accumulators are consumed by one never-taken store
-      float s = 0.f;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s += acc[mi][ni][r];
-      if (s == 123456.789f) og.y[(long)b * og.y_bstride + li] = s;
-      return;
-    }
     const OutR& oz = a.out[1];   // z (B, Ch, T)
     // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
     // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
@@ -445,7 +485,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         if (tt[ni] >= T) continue;
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
-        if (X3_ABL == 10 && ta != 123456.789f) continue;     // timing only: the math without the stores
         buf_st_gate(ta, rG, vT[ni], sT);
         buf_st_gate(sb, rG, vT[ni], sT + sGq);
         if (a.z16) __builtin_amdgcn_raw_buffer_store_b16((short)(pack_bf16x2(ta * sb, 0.f) & 0xffffu), rZ, vT[ni] >> 1, sT >> 1, 0);
@@ -495,8 +534,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
               const float gz = acc[mi][ni][r];
               const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
               const unsigned so = 4u * (unsigned)(dr * T);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(gz * sv * (1.f - tv * tv))), rGh, voff, so, X3_GBWD_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(gz * tv * sv * (1.f - sv))), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
+              const float ga = gz * sv * (1.f - tv * tv), gb = gz * tv * sv * (1.f - sv);
+              am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ga), rGh, voff, so, X3_GBWD_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gb), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
             }
           }
         }
@@ -525,12 +566,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             if (tok && mb + dr < Ch) {
               const float gz = acc[mi][ni][r];
               const unsigned so = 4u * (unsigned)(dr * T);
-              buf_st(gz * sb[r] * (1.f - ta[r] * ta[r]), rGh, voff, so);
-              buf_st(gz * ta[r] * sb[r] * (1.f - sb[r]), rGh, voff, so + sQ);
+              const float ga = gz * sb[r] * (1.f - ta[r] * ta[r]), gb = gz * ta[r] * sb[r] * (1.f - sb[r]);
+              am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
+              buf_st(ga, rGh, voff, so);
+              buf_st(gb, rGh, voff, so + sQ);
             }
           }
         }
     }
+    if (od.amax_out != nullptr) amax_commit(am, od.amax_out);
   }
 }
 
@@ -831,6 +875,58 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
   l = pack_bf16x2(r0, r1);
 }
 
+// ---------------------------------------------------------------------------
+// matmul mode 3 (`float32x2`): fp32 products on the fp16 matrix pipe, THREE MFMAs per product.
+//
+//     x * 2^k = hi + lo          hi = fp16(x 2^k) (RNE), lo = fp16(x 2^k - hi)           (k: one power of two per tensor)
+//     a*b ~= (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi) * 2^-(ka+kb)                            (fp32 accumulate in the MFMA)
+//
+// 2 x 11 significand bits plus the sign of the remainder: hi + lo is x to within 2^-24 |x| -- the size of one fp32
+// rounding -- for every element within 2^-15 of the tensor's absolute maximum, and to within 2^-39 of that maximum for
+// smaller ones (lo then lies in fp16's subnormal range, which v_mfma_f32_32x32x16_f16 honours: tools/ubench/
+// f16x2_probe.hip); a product of two fp16 is exact in fp32; the dropped a_lo*b_lo is below 2^-22 |a*b|.  Against
+// float64 the result is at or below the error of the fp32 MFMA path AND of mode 2's six bf16 products (same probe,
+// K = 128 ... 2560, also with 6 decades of dynamic range inside a tensor and with 1e-7-sized gradients), because a
+// K step of 16 products is rounded once where the fp32 MFMA rounds eight times.  The power of two needs the tensor's
+// absolute maximum BEFORE the kernel runs: producers on this path publish it from their epilogues (OutR::amax_out),
+// entry points whose operand comes from elsewhere run absmax_kernel first.  Several segments in one accumulator
+// (taps, the g_res | g_skip pair, the skip sum over all blocks) share ONE product scale 2^(28 - emax),
+// emax = max_j (e_w_j + e_x_j): segment j's activations are scaled by 2^(14 - emax + e_w_j) <= their own optimum, so
+// nothing overflows and every segment's error stays below 2^-39 of the largest product any segment can contribute.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split2(float x0, float x1, int k, unsigned& h, unsigned& l) {
+  const float y0 = __builtin_ldexpf(x0, k), y1 = __builtin_ldexpf(x1, k);
+  f16x2 hv;
+  hv[0] = (_Float16)y0; hv[1] = (_Float16)y1;
+  h = __builtin_bit_cast(unsigned, hv);
+  asm("" : "+v"(h));
+  const f16x2 hb = __builtin_bit_cast(f16x2, h);
+  f16x2 lv;
+  lv[0] = (_Float16)(y0 - (float)hb[0]); lv[1] = (_Float16)(y1 - (float)hb[1]);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+// one 32 x 32 x 16 MFMA on 16-byte fragment words: fp16 (NP == 2) or bf16 operands
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
+  if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the product chain of one accumulator tile and K step, small products first (NP pieces per operand: 3 -> six bf16
+// products, 2 -> three fp16 products, 1 -> one bf16 product)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_chain(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 c) {
+  if constexpr (NP == 3) {
+    c = mfma16<3>(a[2], b[0], c);
+    c = mfma16<3>(a[0], b[2], c);
+    c = mfma16<3>(a[1], b[1], c);
+  }
+  if constexpr (NP >= 2) {
+    c = mfma16<NP>(a[1], b[0], c);
+    c = mfma16<NP>(a[0], b[1], c);
+  }
+  return mfma16<NP>(a[0], b[0], c);
+}
+
 // NB = 128-column blocks per workgroup (a.ntile_n counts NB*128-column tiles).  NB = 2 (256 x 256
 // tiles, 256-row tiles only): every weight word staged serves twice the columns -- the weight
 // stream from L2 is the largest non-MFMA consumer of the power budget the chip runs into (DESIGN.md
@@ -844,29 +940,17 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 // fetch of a group's rows then follows the first by one step and is served by L1 / L2 instead of HBM /
 // MALL (round 1's gate kernel read x 2.09 times from the fabric); for any pair, both segments advance
 // by the same scalar offsets and the loop never re-runs the per-segment setup.
-#ifndef X3_FAKE_HALF
-#define X3_FAKE_HALF 0        // timing experiment only (wrong results): odd K steps stage without the bf16 split
-#endif
-#ifndef X3_ABL
-#define X3_ABL 0              // timing experiments only (wrong results): 1 no activation loads, 2 no weight loads, 3 no fragment reads, 4 no LDS writes, 5 no barrier-separated staging at all (1+2+4)
-#endif
-#ifndef X3_LEAN_SCHED
-#define X3_LEAN_SCHED 0       // experiment: MFMA : VALU interleave of the lean loop (sched_group_barrier), 0 = the compiler's order
-#endif
-#ifndef X3_LEAN_GBWD
-#define X3_LEAN_GBWD 0        // experiment: the gate-derivative GEMM on the lean loop (136 VGPRs, THREE workgroups per CU): 175 us against 161 -- that kernel wants bytes in flight per workgroup, not workgroups
-#endif
 #ifndef X3_LEAN
-#define X3_LEAN 1             // 256 x 128 tiles, two taps, six products: the 128-VGPR loop below (two 8-wave workgroups per CU)
+#define X3_LEAN 1             // 256 x 128 tiles, two taps, NP >= 2: the 128-VGPR loop below (two 8-wave workgroups per CU)
 #endif
 // X16 (matmul mode 1, linear GEMMs over the z tensors): the activations of every segment are stored as bf16
 // (GemmArgs::z16): fetched with 2-byte loads and staged without a conversion.
 template <int EPI, int WM, int NB, int NP, bool TAP2 = false, bool X16 = false>
-__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : ((WM == 2 && NP == 3 && TAP2 && EPI == EPI_GATE_BWD && X3_LEAN_GBWD) ? 3 : 2))) void conv_gemm_x3_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(!X16 || (NP == 1 && !TAP2 && EPI == EPI_LINEAR), "bf16-stored activations: mode 1 linear GEMMs only");
   constexpr unsigned ESZ = X16 ? 2u : 4u;               // bytes per activation element
-  static_assert(NP == 1 || NP == 3, "one piece (bf16 operands) or three (exact split)");
+  static_assert(NP >= 1 && NP <= 3, "one piece (bf16 operands), two (fp16 hi + lo, scaled) or three (exact bf16 split)");
   constexpr int SCHED = (WM == 4 && NB == 1 && NP == 3) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
   constexpr int BM = 64 * WM, NT = 128 * WM, BNW = BN * NB;
   constexpr int NQ = NT / BNW;            // staging threads per tile column
@@ -912,6 +996,23 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   }
   const int nsteps = it_end - it_beg;
 
+  // ---- float32x2 (NP == 2): the launch's common product scale 2^(28 - emax) and each segment's activation scale
+  // 2^(14 - emax + e_w) (see split2); all wave-uniform, read once per workgroup / per segment switch
+  [[maybe_unused]] int emax = 0;
+  [[maybe_unused]] auto seg_kx = [&](int s) -> int {
+    return 14 - emax + amax_expo(amax_load(a.seg[s].wamax));
+  };
+  if constexpr (NP == 2) {
+    int em = -100000;
+    for (int s = 0; s < a.nseg; ++s) {
+      const Seg& sg = a.seg[s];
+      const int eb = amax_expo(sg.amax ? amax_load(sg.amax) : __builtin_bit_cast(unsigned, sg.amax_static));
+      em = max(em, amax_expo(amax_load(sg.wamax)) + eb);
+    }
+    emax = em;
+  }
+  [[maybe_unused]] int kcur = 0, k1 = 0;    // scale exponent of the segment the fetch cursor is in (TAP2: of segment 0 / segment 1)
+
   // ---- staging state of the next step to fetch (advanced once per fetch) ----------------------
   // Every fetch is a buffer load: descriptor (base, extent) in SGPRs, a per-thread 32-bit offset that is
   // fixed for a whole segment, and a wave-uniform SGPR offset that walks the K steps -- the per-step
@@ -948,6 +1049,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     va = 16u * (unsigned)(a_hi * sg.ldw + m0 + a_m);
     vb = col_offset(sg);
     sw = (unsigned)skip * wadvb; sx = (unsigned)skip * xadvb;
+    if constexpr (NP == 2) kcur = seg_kx(s);
   };
   {
     int s = 0, skip = it_beg;
@@ -964,6 +1066,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       sw1 = (unsigned)(reinterpret_cast<const char*>(s1.w) - reinterpret_cast<const char*>(a.seg[0].w));
       rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1.x + (long)b * s1.x_bstride), 0,
                                               (int)(4u * (unsigned)s1.cin * (unsigned)s1.x_cstride), 0x00020000);
+      if constexpr (NP == 2) k1 = seg_kx(1);
     }
   }
   auto advance2 = [&]() {                    // TAP2: both taps of a channel group have been fetched
@@ -978,96 +1081,81 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     else { sw += wadvb; sx += xadvb; }
   };
 
+  // staging of one K step's activations: split (or round) this thread's CPT channels of its column, one 8- or 16-byte
+  // LDS write per piece.  KX: the segment's scale exponent (NP == 2)
+  auto stage_b = [&](const float (&bv)[CPT], const int kx, const int buf) {
+    unsigned pc[NP][CPT / 2];                                  // [piece][channel pair]
+#pragma unroll
+    for (int e = 0; e < CPT; e += 2) {
+      const float v0 = bv[e], v1 = bv[e + 1];                  // out-of-range elements arrived as 0
+      if constexpr (NP == 3) split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);
+      else if constexpr (NP == 2) split2(v0, v1, kx, pc[0][e / 2], pc[1][e / 2]);
+      else if constexpr (X16) pc[0][e / 2] = __builtin_bit_cast(unsigned, v0) | (__builtin_bit_cast(unsigned, v1) << 16);   // already bf16
+      else pc[0][e / 2] = pack_bf16x2(v0, v1);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if constexpr (CPT == 8) {
+        Bs[buf][p][tid / BNW][s_n] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);
+      } else {
+        uint2* bd = reinterpret_cast<uint2*>(&Bs[buf][p][tid >> 8][s_n]) + ((tid >> 7) & 1);
+        *bd = make_uint2(pc[p][0], pc[p][1]);
+      }
+    }
+  };
+
   // two register sets (P: even steps, Q: odd steps) so that the fetch of step i+2 is in flight while
   // step i+1 is split and stored: every wait in the loop is then a counted vmcnt.  The fetches are
   // unconditional (a branch around them makes hipcc drain to vmcnt(0)).
-  uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
-  float pb[CPT], qb[CPT];
-  [[maybe_unused]] unsigned pmask = 0, qmask = 0;           // (unused since the buffer loads: kept so that the staging macro's signature is unchanged)
-#define X3_FETCH(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw, vb, rx, !TAP2, ((EPI == EPI_GATE_BWD && TAP2) ? X3_GBWD_B0_AUX : (a.x_nt ? 2 : 0)))
-#define X3_FETCH1(A0, A1, A2, BV, MASK) X3_FETCH_(A0, A1, A2, BV, sw + sw1, (X3_ABL == 9 ? 0x80000000u : vb1), rx1, false, 0)   /* ABL 9 (timing only): the second tap's activations are not fetched (every load out of range) */
-#define X3_FETCH_(A0, A1, A2, BV, SW, VB, RX, ADV, BAUX)                                     \
+  [[maybe_unused]] uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
+  [[maybe_unused]] int pkx = 0, qkx = 0;                    // the scale exponent that goes with each set's activations
+#define X3_FETCH(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, kcur, sw, vb, rx, !TAP2, ((EPI == EPI_GATE_BWD && TAP2) ? X3_GBWD_B0_AUX : (a.x_nt ? 2 : 0)))
+#define X3_FETCH1(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, k1, sw + sw1, vb1, rx1, false, 0)
+#define X3_FETCH_(A0, A1, A2, BV, KX, KV, SW, VB, RX, ADV, BAUX)                             \
   {                                                                                          \
-    if (X3_ABL == 2 || X3_ABL == 5) { A0 = make_uint4(va, 1u, 2u, 3u); A1 = A0; A2 = A0; } else {  \
     A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));  \
-    if constexpr (NP == 3) {                                                                 \
-      A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
-      A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
-    } }                                                                                      \
+    if constexpr (NP >= 2) A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
+    if constexpr (NP == 3) A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
     if constexpr (X16) {                      /* raw bf16 bits, kept in the low half of a register */ \
       _Pragma("unroll") for (int e = 0; e < CPT; ++e)                                          \
         BV[e] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(RX, (VB), sx + (unsigned)e * xcsb, 0)); \
     } else                                                                                     \
-    if (X3_ABL == 8 && CPT == 8) {  /* timing only: the same bytes as two 16-byte loads per thread (no transpose: wrong results) */ \
-      const unsigned vq_ = ((VB) & 0x80000000u) ? (VB) : ((VB) - 4u * (unsigned)(tid & 3)) + (unsigned)(2 * (tid & 3)) * xcsb; \
-      const float4 l0_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(RX, vq_, sx, 0)); \
-      const float4 l1_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(RX, vq_, sx + xcsb, 0)); \
-      BV[0] = l0_.x; BV[1] = l0_.y; BV[2] = l0_.z; BV[3] = l0_.w; BV[4] = l1_.x; BV[5] = l1_.y; BV[6] = l1_.z; BV[7] = l1_.w; \
-    } else                                                                                     \
-    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = (X3_ABL == 1 || X3_ABL == 5) ? __builtin_bit_cast(float, (VB) + (unsigned)e) : (X3_ABL == 6 ? buf_ld(RX, 0u, 0u) : (X3_ABL == 7 ? buf_ld(RX, ((VB) & 0x7fffffffu) % 4096u, 0u) : ((BAUX) == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RX, (VB), sx + (unsigned)e * xcsb, 2)) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb)))); \
+    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = ((BAUX) == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RX, (VB), sx + (unsigned)e * xcsb, 2)) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb)); \
+    KX = (KV);                                                                               \
     if (!SCHED && (ADV)) advance();                                                          \
   }
-#define X3_STAGE(A0, A1, A2, BV, MASK, BUF)                                                 \
-  if (!((X3_ABL == 4 || X3_ABL == 5) && left < nsteps - 2)) {        /* ablation: only the first steps stage */ \
+#define X3_STAGE(A0, A1, A2, BV, KX, BUF)                                                    \
+  {                                                                                          \
     uint4* ad = &As[BUF][0][0][0];                                                           \
     ad[tid] = A0;                                                                            \
-    if constexpr (NP == 3) { ad[NT + tid] = A1; ad[2 * NT + tid] = A2; }                     \
-    unsigned pc[3][CPT / 2];                                   /* [piece][channel pair] */   \
-    _Pragma("unroll") for (int e = 0; e < CPT; e += 2) {                                     \
-      const float v0 = BV[e], v1 = BV[e + 1];          /* out-of-range elements arrived as 0 */ \
-      if constexpr (NP == 3) { if (X3_FAKE_HALF && (BUF) == 1) { pc[0][e / 2] = __builtin_bit_cast(unsigned, v0); pc[1][e / 2] = __builtin_bit_cast(unsigned, v1); pc[2][e / 2] = 0u; } else split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); } \
-      else if constexpr (X16) pc[0][e / 2] = __builtin_bit_cast(unsigned, v0) | (__builtin_bit_cast(unsigned, v1) << 16);   /* already bf16 */ \
-      else pc[0][e / 2] = pack_bf16x2(v0, v1);                                               \
-    }                                                                                        \
-    _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                         \
-      if constexpr (CPT == 8) {                                                              \
-        Bs[BUF][p][tid / BNW][s_n] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);     \
-      } else {                                                                               \
-        uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
-        *bd = make_uint2(pc[p][0], pc[p][1]);                                                \
-      }                                                                                      \
-    }                                                                                        \
+    if constexpr (NP >= 2) ad[NT + tid] = A1;                                                \
+    if constexpr (NP == 3) ad[2 * NT + tid] = A2;                                            \
+    stage_b(BV, KX, BUF);                                                                \
   }
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
-    bf16x8 af[2][NP], bf[2][NP];
+    uint4 af[2][NP], bf[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        if (X3_ABL == 3) {
-          af[i][p] = __builtin_bit_cast(bf16x8, make_uint4(tid + i, p, acc[0][0][0] > 1e30f ? 1u : 0u, 3u));
-          bf[i][p] = af[i][p];
-        } else {
-        af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
-        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
-        }
+        af[i][p] = As[cur][p][lk][wm * 64 + i * 32 + li];
+        bf[i][p] = Bs[cur][p][lk][wn * 64 + i * 32 + li];
       }
-    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = ac[i][j];
-          if constexpr (NP == 3) {                               // small products first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
-          }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
-          ac[i][j] = c;
-        }
-    };
-    block(acc, bf);
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(af[i], bf[j], acc[i][j]);
     if constexpr (NB == 2) {
-      bf16x8 bg[2][NP];
+      uint4 bg[2][NP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bg[i][p] = X3_ABL == 3 ? bf[i][p] : __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
-      block(acc2, bg);
+        for (int p = 0; p < NP; ++p) bg[i][p] = Bs[cur][p][lk][BN + wn * 64 + i * 32 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[i][j] = mfma_chain<NP>(af[i], bg[j], acc2[i][j]);
     }
     if (SCHED) {
       // one MFMA (32 pipe cycles), then a few of the step's other instructions (the split of the next
@@ -1083,24 +1171,23 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // LEAN (256 x 128 tiles, two taps, six products): the loop in 128 VGPRs, so that TWO 8-wave workgroups share a
-  // CU (2 x 72 KB of LDS) and one tile's epilogue -- 13 % of the gate kernel's time with nothing beside it
+  // LEAN (256 x 128 tiles, two taps, NP >= 2): the loop in 128 VGPRs, so that TWO 8-wave workgroups share a
+  // CU and one tile's epilogue -- 13 % of the gate kernel's time with nothing beside it
   // (tools/abl_gate.sh) -- runs beside the other's K loop.  What it gives up against the loop below: the
   // weights (L2-resident) are fetched ONE step ahead into a single register set, only the activations two;
   // the A fragments of one 32-row block at a time.
-  constexpr bool LEAN = (NB == 1 && NP == 3 && TAP2 && ((WM == 4 && X3_LEAN) || (WM == 2 && EPI == EPI_GATE_BWD && X3_LEAN_GBWD)));   // gate-derivative GEMM (128 x 128 tiles, 256 threads): 168 VGPRs, three workgroups per CU
+  constexpr bool LEAN = (NB == 1 && NP >= 2 && TAP2 && WM == 4 && X3_LEAN);
   if constexpr (LEAN) {
     unsigned swA = 0, sxB = 0;                 // the two cursors: weights of the next A fetch, activations of the next B fetch
     int leftA = nsteps, leftB = nsteps;
-    uint4 la0, la1, la2;
+    [[maybe_unused]] uint4 la0, la1, la2;
     float pb[CPT], qb[CPT];
-#define LN_FETCH_A(TAP1) LN_FETCH_A_(la0, la1, la2, TAP1)
-#define LN_FETCH_A_(L0, L1, L2, TAP1)                                                         \
+#define LN_FETCH_A(TAP1)                                                                      \
     {                                                                                         \
       const unsigned so_ = swA + ((TAP1) ? sw1 : 0u);                                         \
-      L0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
-      L1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
-      L2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
+      la0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
+      la1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
+      if constexpr (NP == 3) la2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
       if (TAP1) { leftA -= 2; swA += leftA > 0 ? wadvb : 0u; }                                \
     }
 #define LN_FETCH_B(BV, TAP1)                                                                  \
@@ -1109,309 +1196,98 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         BV[e] = (TAP1) ? buf_ld(rx1, vb1, sxB + (unsigned)e * xcsb) : buf_ld(rx, vb, sxB + (unsigned)e * xcsb); \
       if (TAP1) { leftB -= 2; sxB += leftB > 0 ? xadvb : 0u; }                                \
     }
-#define LN_STAGE(BV, BUF) LN_STAGE_(la0, la1, la2, BV, BUF)
-#define LN_STAGE_(L0, L1, L2, BV, BUF)                                                        \
+#define LN_STAGE(BV, KX, BUF)                                                                 \
     {                                                                                         \
       uint4* ad = &As[BUF][0][0][0];                                                          \
-      ad[tid] = L0; ad[NT + tid] = L1; ad[2 * NT + tid] = L2;                                 \
-      unsigned pc[3][CPT / 2];                                                                \
-      _Pragma("unroll") for (int e = 0; e < CPT; e += 2) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                         \
-        if constexpr (CPT == 8) {                                                             \
-          Bs[BUF][p][tid / BNW][s_n] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);    \
-        } else {                                                                              \
-          uint2* bd = reinterpret_cast<uint2*>(&Bs[BUF][p][tid >> 8][s_n]) + ((tid >> 7) & 1); \
-          *bd = make_uint2(pc[p][0], pc[p][1]);                                               \
-        }                                                                                     \
-      }                                                                                       \
+      ad[tid] = la0; ad[NT + tid] = la1;                                                      \
+      if constexpr (NP == 3) ad[2 * NT + tid] = la2;                                          \
+      stage_b(BV, KX, BUF);                                                               \
     }
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
-      bf16x8 bf[2][3];
+      uint4 bf[2][NP];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bf[j][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + j * 32 + li]);
+        for (int p = 0; p < NP; ++p) bf[j][p] = Bs[cur][p][lk][wn * 64 + j * 32 + li];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        bf16x8 af[3];
+        uint4 af[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) af[p] = As[cur][p][lk][wm * 64 + i * 32 + li];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];                                  // same product order as the loop below
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(af, bf[j], acc[i][j]);     // same product order as the loop below
       }
-#if X3_LEAN_SCHED
-#pragma unroll
-      for (int q = 0; q < 24; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, X3_LEAN_SCHED, 0);
-      }
-#endif
     };
-    if constexpr (WM == 2) {                   // gate-derivative GEMM: the weights two steps ahead as well (second set)
-      uint4 ma0, ma1, ma2;
-      if (nsteps > 0) {
-        LN_FETCH_B(pb, false);                 // step 0
-        LN_FETCH_A_(la0, la1, la2, false);
-        LN_FETCH_B(qb, true);                  // step 1
-        LN_FETCH_A_(ma0, ma1, ma2, true);
-        LN_STAGE_(la0, la1, la2, pb, 0);
-        __syncthreads();
-        for (int i = 0; i < nsteps; i += 2) {
-          LN_FETCH_A_(la0, la1, la2, false);   // step i + 2
-          LN_FETCH_B(pb, false);
-          lmma(std::integral_constant<int, 0>{});
-          LN_STAGE_(ma0, ma1, ma2, qb, 1);     // step i + 1
-          __syncthreads();
-          LN_FETCH_A_(ma0, ma1, ma2, true);    // step i + 3
-          LN_FETCH_B(qb, true);
-          lmma(std::integral_constant<int, 1>{});
-          LN_STAGE_(la0, la1, la2, pb, 0);     // step i + 2
-          __syncthreads();
-        }
-      }
-    } else
     if (nsteps > 0) {
       LN_FETCH_B(pb, false);                   // step 0
       LN_FETCH_A(false);                       // step 0
       LN_FETCH_B(qb, true);                    // step 1
-      LN_STAGE(pb, 0);
+      LN_STAGE(pb, kcur, 0);
       __syncthreads();
       for (int i = 0; i < nsteps; i += 2) {    // nsteps is even: two taps per channel group
         LN_FETCH_A(true);                      // weights of step i + 1
         LN_FETCH_B(pb, false);                 // activations of step i + 2
         lmma(std::integral_constant<int, 0>{});
-        LN_STAGE(qb, 1);                       // step i + 1
+        LN_STAGE(qb, k1, 1);                   // step i + 1
         __syncthreads();
         LN_FETCH_A(false);                     // weights of step i + 2
         LN_FETCH_B(qb, true);                  // activations of step i + 3
         lmma(std::integral_constant<int, 1>{});
-        LN_STAGE(pb, 0);                       // step i + 2
+        LN_STAGE(pb, kcur, 0);                 // step i + 2
         __syncthreads();
       }
     }
 #undef LN_FETCH_A
-#undef LN_FETCH_A_
-#undef LN_STAGE_
 #undef LN_FETCH_B
 #undef LN_STAGE
   } else
   if (nsteps > 0) {
-    X3_FETCH(pa0, pa1, pa2, pb, pmask);
+    float pb[CPT], qb[CPT];
+    X3_FETCH(pa0, pa1, pa2, pb, pkx);
     if (SCHED && !TAP2) advance();
-    if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qmask); advance2(); }
-    else X3_FETCH(qa0, qa1, qa2, qb, qmask);
+    if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
+    else X3_FETCH(qa0, qa1, qa2, qb, qkx);
     if (SCHED && !TAP2) advance();
-    X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);
+    X3_STAGE(pa0, pa1, pa2, pb, pkx, 0);
     __syncthreads();
-    // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1
-    for (int i = 0; i < nsteps; i += 2) {
-      X3_FETCH(pa0, pa1, pa2, pb, pmask);           // step i + 2
+    // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1.  (Whole pairs in the loop,
+    // an odd last step behind it: with a `break` between the halves hipcc copied the accumulators between register sets
+    // inside the loop and spilled 250 registers in the two-piece instantiations.)
+    for (int i = 0; i + 1 < nsteps; i += 2) {
+      X3_FETCH(pa0, pa1, pa2, pb, pkx);             // step i + 2 (past the end: re-reads the last step, never used)
       mma(I0{});
-      X3_STAGE(qa0, qa1, qa2, qb, qmask, 1);        // step i + 1
+      X3_STAGE(qa0, qa1, qa2, qb, qkx, 1);          // step i + 1
       if (SCHED && !TAP2) advance();
       __syncthreads();
-      if (i + 1 >= nsteps) break;
-      if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qmask); advance2(); }
-      else X3_FETCH(qa0, qa1, qa2, qb, qmask);      // step i + 3
+      if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
+      else X3_FETCH(qa0, qa1, qa2, qb, qkx);        // step i + 3
       mma(I1{});
-      X3_STAGE(pa0, pa1, pa2, pb, pmask, 0);        // step i + 2
+      X3_STAGE(pa0, pa1, pa2, pb, pkx, 0);          // step i + 2
       if (SCHED && !TAP2) advance();
       __syncthreads();
     }
+    if (nsteps & 1) mma(I0{});                      // the last step of an odd count: staged by the prologue / the last pair
   }
 #undef X3_FETCH
 #undef X3_FETCH1
 #undef X3_FETCH_
 #undef X3_STAGE
+  [[maybe_unused]] auto unscale = [&](f32x16 (&ac)[2][2]) {      // float32x2: back from the launch's product scale 2^(28 - emax)
+    const int ku = emax - 28;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[i][j][r] = __builtin_ldexpf(ac[i][j][r], ku);
+  };
+  if constexpr (NP == 2) unscale(acc);
   gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD)>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
   if constexpr (NB == 2) {
+    if constexpr (NP == 2) unscale(acc2);
     if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
-}
-
-// ---------------------------------------------------------------------------
-// conv_win_x3_kernel -- the two taps of a dilated conv from ONE staged activation window
-// (WaveNet/modules.py:13-16, 40-41: forward, and its backward-data).
-//
-// conv_gemm_x3_kernel<.., TAP2> alternates the taps channel group by channel group, but still fetches,
-// splits and stages the activations of a 16-channel group twice -- once per tap, shifted by the dilation.
-// For dilation < tile width the two 256-column windows overlap in 256 - dil columns.  The ablation of the
-// K loop (tools/abl.sh: parts of the loop compiled out, full chip) puts the activation fetch at ~20 % of
-// the kernel at full load -- the bytes delivered through the vector memory path, not the instruction count
-// (one broadcast address: free; the same loads at distinct L1-resident addresses: nearly the full cost) and
-// not the split (-1.3 % with it compiled out) -- so here every activation element crosses that path ONCE
-// per tile: per 16-channel group the workgroup stages a window of W = 256 + dil columns ([piece][k-half][w]
-// 16-byte words, thread = window column, all threads stage k-half (step & 1)), and the MFMA B fragments of
-// tap j are read from it at column offset o_j (0 or dil) -- the dilation gather is an LDS offset.
-//
-// Schedule (one barrier per K step, as before).  Step s = 2g + tap: A(s) from As[s & 1], window g from
-// Bw[g & 1].  Staged during step s: A(s + 1) and the k-half (s & 1) of window g + 1, i.e. the 8-channel
-// half-group c8 = s + 2; fetched at the top of step s (one step before it is staged): A(s + 2) and
-// half-group c8 = s + 3.  Threads beyond the window (tid >= W) fetch with an out-of-range offset and
-// stage nothing.  256 x 256 tiles, 8 waves; LDS 48 KB (A, two steps) + 2 x 36 KB (two windows of up to
-// 384 columns).  The K order (tap-interleaved) and the products are those of the TAP2 kernel: the results
-// are identical to the last bit.
-// ---------------------------------------------------------------------------
-constexpr int WIN_MAX_DIL = 128, WIN_W = 256 + WIN_MAX_DIL;
-template <int EPI, int NP>
-__global__ __launch_bounds__(512, 2) void conv_win_x3_kernel(const GemmArgs a) {
-  constexpr int BM = 256, NT = 512;
-  __shared__ uint4 As[2][NP][2][BM];
-  __shared__ uint4 Bw[2][NP][2][WIN_W];
-  const int nblk = gridDim.x;
-  int logical;
-  {
-    const int id = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  }
-  const int mt = logical % a.ntile_m;
-  const int rest = logical / a.ntile_m;
-  const int nt = rest % a.ntile_n;
-  const int b = rest / a.ntile_n;
-  const int m0 = mt * BM, t0 = nt * 256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
-
-  f32x16 acc[2][2], acc2[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
-
-  const Seg& s0 = a.seg[0];
-  const Seg& s1 = a.seg[1];
-  const int nsteps = 2 * (s0.cin / BK);                      // host: cin % 16 == 0, both segments alike
-  const int lo = min(s0.toff, s1.toff);
-  const int W = 256 + (max(s0.toff, s1.toff) - lo);          // window columns: [t0 + lo, t0 + lo + W)
-  const unsigned o0 = (unsigned)(s0.toff - lo), o1 = (unsigned)(s1.toff - lo);   // fragment column offsets of the taps
-  // ---- fetch state: buffer descriptors + per-thread offsets (fixed) + scalar offsets (walk the K steps)
-  constexpr unsigned OOB = 0x80000000u;
-  const rsrc_t rw = make_rsrc(s0.w);
-  const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s0.x + (long)b * s0.x_bstride), 0,
-                                                      (int)(4u * (unsigned)s0.cin * (unsigned)s0.x_cstride), 0x00020000);
-  const int a_hi = tid / BM, a_m = tid % BM;
-  const unsigned va = 16u * (unsigned)(a_hi * s0.ldw + m0 + a_m);
-  const unsigned wl2b = 32u * (unsigned)s0.ldw, wadvb = 32u * NP * (unsigned)s0.ldw;
-  const unsigned xcsb = 4u * (unsigned)s0.x_cstride;
-  const unsigned sw1 = (unsigned)(reinterpret_cast<const char*>(s1.w) - reinterpret_cast<const char*>(s0.w));
-  const int tin = t0 + lo + tid;                             // this thread's window column in the input row
-  const bool stager = tid < W;
-  const unsigned vb = (stager && tin >= 0 && tin < s0.Tin) ? 4u * (unsigned)tin : OOB;
-  unsigned sw = 0;                                           // weight slab offset of the next channel group
-  unsigned sx = 0;                                           // byte offset of the next 8-channel half-group
-  int c8 = 0;                                                // ... and its index (clamped at the last one)
-  const int c8_last = nsteps - 1;                            // half-groups 0 .. 2 G - 1
-  uint4 pa0, pa1, pa2, qa0, qa1, qa2;
-  float pb[8], qb[8];
-#define WIN_FETCH_B(BV)                                                                        \
-  {                                                                                            \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) BV[e] = buf_ld(rx, vb, sx + (unsigned)e * xcsb); \
-    const bool more_ = c8 < c8_last;          /* past the end: re-read the last half-group (staged into a window nobody reads) */ \
-    c8 += more_ ? 1 : 0; sx += more_ ? 8u * xcsb : 0u;                                         \
-  }
-#define WIN_FETCH_A(A0, A1, A2, SW)                                                            \
-  {                                                                                            \
-    A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));    \
-    if constexpr (NP == 3) {                                                                   \
-      A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
-      A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
-    }                                                                                          \
-  }
-#define WIN_STAGE_A(A0, A1, A2, ABUF)                                                          \
-  {                                                                                            \
-    uint4* ad = &As[ABUF][0][0][0];                                                            \
-    ad[tid] = A0;                                                                              \
-    if constexpr (NP == 3) { ad[NT + tid] = A1; ad[2 * NT + tid] = A2; }                       \
-  }
-#define WIN_STAGE_B(BV, WBUF, KH)                                                              \
-  if (stager) {                                                                                \
-    unsigned pc[3][4];                                                                         \
-    _Pragma("unroll") for (int e = 0; e < 8; e += 2) {                                         \
-      if constexpr (NP == 3) split3(BV[e], BV[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]); \
-      else pc[0][e / 2] = pack_bf16x2(BV[e], BV[e + 1]);                                       \
-    }                                                                                          \
-    _Pragma("unroll") for (int p = 0; p < NP; ++p) Bw[WBUF][p][KH][tid] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]); \
-  }
-  // one K step: fragments of A from As[ABUF], of the window WBUF at the tap's column offset OFS
-#define WIN_MMA(ABUF, WBUF, OFS)                                                               \
-  {                                                                                            \
-    bf16x8 af[2][NP], bf[2][NP], bg[2][NP];                                                    \
-    const uint4* bb = &Bw[WBUF][0][lk][(OFS) + wn * 64 + li];                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
-      _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                         \
-        af[i][p] = __builtin_bit_cast(bf16x8, As[ABUF][p][lk][wm * 64 + i * 32 + li]);         \
-        bf[i][p] = __builtin_bit_cast(bf16x8, bb[p * 2 * WIN_W + i * 32]);                     \
-        bg[i][p] = __builtin_bit_cast(bf16x8, bb[p * 2 * WIN_W + 128 + i * 32]);               \
-      }                                                                                        \
-    WIN_CHAIN(acc, bf);                                                                        \
-    WIN_CHAIN(acc2, bg);                                                                       \
-  }
-#define WIN_CHAIN(ACC, FB)                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
-        f32x16 c = ACC[i][j];                                                                  \
-        if constexpr (NP == 3) {                               /* small products first */      \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], FB[j][0], c, 0, 0, 0);         \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][2], c, 0, 0, 0);         \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], FB[j][1], c, 0, 0, 0);         \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], FB[j][0], c, 0, 0, 0);         \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][1], c, 0, 0, 0);         \
-        }                                                                                      \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], FB[j][0], c, 0, 0, 0);           \
-        ACC[i][j] = c;                                                                         \
-      }
-
-  // ---- prologue: window 0 (half-groups 0, 1) and A(0) staged; {A(1), half-group 2} in flight in set Q
-  WIN_FETCH_B(pb);                                            // c8 = 0
-  WIN_FETCH_B(qb);                                            // c8 = 1
-  WIN_FETCH_A(pa0, pa1, pa2, sw);                             // A(0): tap 0, group 0
-  WIN_STAGE_A(pa0, pa1, pa2, 0);
-  WIN_STAGE_B(pb, 0, 0);
-  WIN_STAGE_B(qb, 0, 1);
-  WIN_FETCH_A(qa0, qa1, qa2, sw + sw1);                       // A(1): tap 1, group 0
-  WIN_FETCH_B(qb);                                            // c8 = 2
-  sw += (nsteps > 2) ? wadvb : 0u;
-  __syncthreads();
-  // top of a pair (s even = 2 g): As[0] holds A(s), Bw[g & 1] window g; set Q holds {A(s + 1), half-group s + 2}
-  int wcur = 0;                                               // g & 1
-  for (int s = 0; s < nsteps; s += 2) {
-    const int wnxt = wcur ^ 1;
-    WIN_FETCH_A(pa0, pa1, pa2, sw);                           // A(s + 2): tap 0 of group g + 1
-    WIN_FETCH_B(pb);                                          // half-group s + 3
-    WIN_MMA(0, wcur, o0);                                     // step s: tap 0
-    WIN_STAGE_A(qa0, qa1, qa2, 1);                            // A(s + 1)
-    WIN_STAGE_B(qb, wnxt, 0);                                 // half-group s + 2 = k-half 0 of window g + 1
-    __syncthreads();
-    WIN_FETCH_A(qa0, qa1, qa2, sw + sw1);                     // A(s + 3): tap 1 of group g + 1
-    WIN_FETCH_B(qb);                                          // half-group s + 4
-    sw += (s + 4 < nsteps) ? wadvb : 0u;                      // the group after the next (never beyond the last)
-    WIN_MMA(1, wcur, o1);                                     // step s + 1: tap 1
-    WIN_STAGE_A(pa0, pa1, pa2, 0);                            // A(s + 2)
-    WIN_STAGE_B(pb, wnxt, 1);                                 // half-group s + 3 = k-half 1 of window g + 1
-    __syncthreads();
-    wcur = wnxt;
-  }
-#undef WIN_FETCH_B
-#undef WIN_FETCH_A
-#undef WIN_STAGE_A
-#undef WIN_STAGE_B
-#undef WIN_MMA
-#undef WIN_CHAIN
-  gemm_epilogue<EPI, 4, false, true>(a, acc, m0, t0, b, wm, wn, li, lk, 0, logical, 0);
-  if (t0 + BN < a.Tout) gemm_epilogue<EPI, 4, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, logical, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1440,6 +1316,9 @@ struct Lin128Args {
   float* y; long y_bstride;                // (B, 256, T)
   const float* bias;                       // 256 or null
   int T, tiles_per_b, ntiles;
+  // float32x2 (NP = 2): maxima of the weights (as packed) and of z (device pointer or host-known bound); amax_out
+  // (nullable, any mode): atomicMax of |y| over the launch
+  const unsigned* wamax; const unsigned* z_amax; float z_amax_static; unsigned* amax_out;
 };
 
 // Z16 (matmul mode 1): z is stored as bf16 (same element strides): fetched as 2 x CPC bytes per row and staged as is.
@@ -1461,6 +1340,12 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
 #pragma unroll
     for (int p = 0; p < NP; ++p) af[s][p] = a.w[((long)(s * NP + p) * 2 + lk) * a.ldw + 32 * wave + li];
   if (tid < 256) reinterpret_cast<float*>(bias_s)[tid] = a.bias ? a.bias[tid] : 0.f;
+  [[maybe_unused]] int kz = 0, ku = 0;             // float32x2: z is scaled by 2^kz, the accumulators come back by 2^ku
+  if constexpr (NP == 2) {
+    const int ew = amax_expo(amax_load(a.wamax)), ez = amax_expo(a.z_amax ? amax_load(a.z_amax) : __builtin_bit_cast(unsigned, a.z_amax_static));
+    kz = 14 - ez; ku = ew + ez - 28;
+  }
+  float am = 0.f;
 
   // ---- staging role: CPC consecutive columns x 4 consecutive channels per thread ----
   const int cg = tid & 15, kq = tid >> 4;
@@ -1501,7 +1386,13 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     uint4* base_ = &Bs[BUF][st_word];                                                          \
     _Pragma("unroll") for (int c = 0; c < CPC; ++c) {                                          \
       uint2* d_ = reinterpret_cast<uint2*>(base_ + c) + st_sub;                                \
-      if constexpr (NP == 3) {                                                                 \
+      if constexpr (NP == 2) {                                                                 \
+        unsigned h0, l0, h1, l1;                                                               \
+        split2(zr[0][c], zr[1][c], kz, h0, l0);                                                \
+        split2(zr[2][c], zr[3][c], kz, h1, l1);                                                \
+        d_[0] = make_uint2(h0, h1);                                                            \
+        d_[2 * (2 * NC)] = make_uint2(l0, l1);                                                 \
+      } else if constexpr (NP == 3) {                                                          \
         unsigned h0, m0, l0, h1, m1, l1;                                                       \
         split3(zr[0][c], zr[1][c], h0, m0, l0);                                                \
         split3(zr[2][c], zr[3][c], h1, m1, l1);                                                \
@@ -1540,18 +1431,9 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     const uint4* bb = &Bs[CUR][lk * NC + li];                                                  \
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                           \
       _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) {                                     \
-        bf16x8 bq[NP];                                                                         \
-        _Pragma("unroll") for (int p = 0; p < NP; ++p) bq[p] = __builtin_bit_cast(bf16x8, bb[s * STEPW + p * 2 * NC + cb * 32]); \
-        f32x16 c = acc[cb];                                                                    \
-        if constexpr (NP == 3) {                               /* small products first (as conv_gemm_x3_kernel) */ \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][2]), bq[0], c, 0, 0, 0); \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[2], c, 0, 0, 0); \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][1]), bq[1], c, 0, 0, 0); \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][1]), bq[0], c, 0, 0, 0); \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[1], c, 0, 0, 0); \
-        }                                                                                      \
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s][0]), bq[0], c, 0, 0, 0); \
-        acc[cb] = c;                                                                           \
+        uint4 bq[NP];                                                                          \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) bq[p] = bb[s * STEPW + p * 2 * NC + cb * 32]; \
+        acc[cb] = mfma_chain<NP>(af[s], bq, acc[cb]);             /* small products first (as conv_gemm_x3_kernel) */ \
       }                                                                                        \
     }                                                                                          \
     L128_STAGE(CUR ^ 1);                                                                       \
@@ -1564,8 +1446,9 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
         _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                     \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
             const int r = 4 * q + j;                                                           \
-            float v = acc[cb][r] + bv[j];                                                      \
+            float v = (NP == 2 ? __builtin_ldexpf(acc[cb][r], ku) : acc[cb][r]) + bv[j];       \
             if constexpr (HAS_ADD) v += XCUR[cb][r];                                           \
+            am = fmaxf(am, fabsf(v));                                                          \
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T), L128_ST_AUX);           \
           }                                                                                    \
       }                                                                                        \
@@ -1593,6 +1476,7 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     tile += stride;
     if (tile >= a.ntiles) break;
   }
+  if (a.amax_out != nullptr) amax_commit(am, a.amax_out);
 #undef L128_FETCH
 #undef L128_STAGE
 #undef L128_XLOAD
@@ -1610,8 +1494,51 @@ struct PackJob {
   int gate_half;         // 0, or Ch: interleave 32-row groups of [0,Ch) and [Ch,2Ch)
   int Rpad, ldw, m_off;
   int mspan;             // columns of dst this job owns (multiple of 4, zero filled)
+  unsigned* amax;        // format 3: where wamax_kernel leaves max |src| (device, float bits); the slab holds src * 2^(14 - e)
 };
-struct PackArgs { PackJob job[MAXSEG]; int njob; int bf16; };
+struct PackArgs { PackJob job[MAXSEG]; int njob; int bf16; };     // bf16 = slab format: 0 fp32, 1 bf16, 2 three bf16 pieces, 3 two scaled fp16 pieces
+
+// max |w| of every job's source tensor (format 3 scales the weights by a power of two taken from it): grid
+// (AMAX_SLOTS, njob), block x fills slot x
+__global__ __launch_bounds__(256) void wamax_kernel(const PackArgs pa) {
+  __shared__ float red[4];
+  const PackJob& j = pa.job[blockIdx.y];
+  const long total = (long)j.K * j.R * j.Cm;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int mm = (int)(i % j.Cm);
+    const long rest = i / j.Cm;
+    const int k = (int)(rest % j.R), tap = (int)(rest / j.R);
+    m = fmaxf(m, fabsf(j.src[(long)k * j.s_k + (long)mm * j.s_m + (long)tap * j.s_tap]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) j.amax[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// max |x| over a tensor -> out[AMAX_SLOTS] (float bits), zeroed beforehand: the operand scale of a float32x2 launch
+// whose operand was not produced by one of this library's amax-publishing epilogues
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* out) {
+  float m = 0.f;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {              // four 16-byte loads in flight per thread
+    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v0.x), fabsf(v0.y))), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v1.x), fabsf(v1.y))), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v2.x), fabsf(v2.y))), fmaxf(fabsf(v2.z), fabsf(v2.w)));
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v3.x), fabsf(v3.y))), fmaxf(fabsf(v3.z), fabsf(v3.w)));
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  amax_commit(m, out);
+}
 
 __global__ void pack_kernel(const PackArgs pa) {
   const PackJob& j = pa.job[blockIdx.y];
@@ -1619,10 +1546,13 @@ __global__ void pack_kernel(const PackArgs pa) {
     // modes 1 and 2: per tap a slab of Rpad/16 K steps x [piece NP][k-half 2][ldw] 16-byte words, each
     // word the same piece of 8 consecutive k of one column (conv_gemm_x3_kernel's LDS image); NP = 3
     // (mode 2: exact split) or 1 (mode 1: the weight rounded to bf16; the slab keeps its fp32 stride)
-    const int np = pa.bf16 == 2 ? 3 : 1;
+    // (format 3: two fp16 pieces of w * 2^(14 - e); the slab keeps format 2's stride between taps, so one workspace
+    // layout serves both)
+    const int np = pa.bf16 == 2 ? 3 : (pa.bf16 == 3 ? 2 : 1);
     const int groups = j.Rpad / 8;
     const long total = (long)j.K * groups * j.mspan;
-    const long tap_words = np == 3 ? (long)(j.Rpad / 16) * 6 * j.ldw : (long)(j.Rpad / 4) * j.ldw;
+    const long tap_words = pa.bf16 >= 2 ? (long)(j.Rpad / 16) * 6 * j.ldw : (long)(j.Rpad / 4) * j.ldw;
+    const int kw = pa.bf16 == 3 ? 14 - amax_expo(amax_load(j.amax)) : 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
       const int mp = (int)(i % j.mspan);
       const long rest = i / j.mspan;
@@ -1640,14 +1570,13 @@ __global__ void pack_kernel(const PackArgs pa) {
         const int k0 = 8 * kg + e, k1 = k0 + 1;
         const float v0 = (k0 < j.R && m < j.Cm) ? j.src[(long)k0 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
         const float v1 = (k1 < j.R && m < j.Cm) ? j.src[(long)k1 * j.s_k + (long)m * j.s_m + (long)tap * j.s_tap] : 0.f;
-        split3(v0, v1, h[e / 2], md[e / 2], l[e / 2]);
+        if (pa.bf16 == 3) { split2(v0, v1, kw, h[e / 2], md[e / 2]); l[e / 2] = 0u; }
+        else split3(v0, v1, h[e / 2], md[e / 2], l[e / 2]);
       }
       uint4* d = reinterpret_cast<uint4*>(j.dst) + tap * tap_words + ((long)(kg >> 1) * 2 * np + (kg & 1)) * j.ldw + j.m_off + mp;
       d[0L * j.ldw] = make_uint4(h[0], h[1], h[2], h[3]);
-      if (np == 3) {
-        d[2L * j.ldw] = make_uint4(md[0], md[1], md[2], md[3]);
-        d[4L * j.ldw] = make_uint4(l[0], l[1], l[2], l[3]);
-      }
+      if (np >= 2) d[2L * j.ldw] = make_uint4(md[0], md[1], md[2], md[3]);
+      if (np == 3) d[4L * j.ldw] = make_uint4(l[0], l[1], l[2], l[3]);
     }
     return;
   }
@@ -1699,6 +1628,9 @@ struct WSeg {
   float* gb; float* gb2;   // bias-gradient destinations fed by this segment's gy (nullable)
   int tile0;          // first global n-tile of this segment
   int ptile0;         // first global 256-column tile of this segment (wgrad3_kernel<4, 2>)
+  // float32x2 (NP = 2): absolute maxima (device, float bits) of this segment's x and of its own gy (nullptr with
+  // gy == nullptr: WgradArgs::amax_gy); amax_x == nullptr: the host-known bound amax_x_static
+  const unsigned* amax_x; float amax_x_static; const unsigned* amax_gy;
 };
 struct WgradArgs {
   const float* gy; long gy_bstride;
@@ -1716,6 +1648,8 @@ struct WgradArgs {
   int accumulate;
   const int32_t* skip_flag;       // see GemmArgs::skip_flag
   int x16;                        // matmul mode 1 only: the x operand of every segment (the z tensors) is stored as bf16
+  const unsigned* amax_gy;        // float32x2: absolute maximum of the common gy
+  int f16x2;                      // host: run the float32x2 kernel (every segment carries its maxima)
 };
 
 template <bool BF16>
@@ -2159,7 +2093,7 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 #define W3_LEAN 1             // 256 x 128 tiles, six products: compiled for 128 VGPRs (two 8-wave workgroups per CU)
 #endif
 template <int WM, int NC, int NP, bool X16 = false>
-__global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3) ? 4 : 2) void wgrad3_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2) ? 4 : 2) void wgrad3_kernel(const WgradArgs a) {
   static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(!X16 || NP == 1, "bf16-stored x: mode 1 only");
   constexpr unsigned XSZ = X16 ? 2u : 4u;
@@ -2190,6 +2124,14 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
   for (int i = 1; i < MAXSEG; ++i)
     if (i < a.nseg && ct >= (NC == 1 ? a.seg[i].tile0 : a.seg[i].ptile0)) s = i;
   const WSeg& sg = a.seg[s];
+  // float32x2: this tile's operand scales 2^ka (gy), 2^kb (x) -- a tile belongs to ONE segment, so each operand takes
+  // its own optimum -- and the way back, 2^ku
+  [[maybe_unused]] int ka = 0, kb = 0, ku = 0;
+  if constexpr (NP == 2) {
+    const int eg = amax_expo(amax_load(sg.gy ? sg.amax_gy : a.amax_gy));
+    const int ex = amax_expo(sg.amax_x ? amax_load(sg.amax_x) : __builtin_bit_cast(unsigned, sg.amax_x_static));
+    ka = 14 - eg; kb = 14 - ex; ku = eg + ex - 28;
+  }
   const int ntg = NC == 1 ? ct : sg.tile0 + NC * (ct - sg.ptile0);    // first 128-column slab tile of this workgroup
   const int n0 = (ntg - sg.tile0) * BN;
   const int m0 = mt * BM2;
@@ -2277,8 +2219,15 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
   };
   // staging: this thread's 4 consecutive t of a row are half (s_chunk & 1) of the 8-k group
   // (s_chunk >> 1) of that row; split into the three bf16 pieces and written as 8 bytes per piece
-  auto put = [&](uint4* plane0, int prow, const float4 v) {     // plane0 = &X[stage][0][s_chunk >> 1][row]
+  auto put = [&](uint4* plane0, int prow, const float4 v, [[maybe_unused]] const int kx) {     // plane0 = &X[stage][0][s_chunk >> 1][row]
     uint2* d = reinterpret_cast<uint2*>(plane0) + (s_chunk & 1);
+    if constexpr (NP == 2) {
+      unsigned h0, l0, h1, l1;
+      split2(v.x, v.y, kx, h0, l0);
+      split2(v.z, v.w, kx, h1, l1);
+      d[2 * (0 * 2 * prow)] = make_uint2(h0, h1);
+      d[2 * (1 * 2 * prow)] = make_uint2(l0, l1);
+    } else
     if constexpr (NP == 3) {
       unsigned h0, m0, l0, h1, m1, l1;
       split3(v.x, v.y, h0, m0, l0);
@@ -2300,7 +2249,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
       const float4 v = VM ? RA[i] : zero4;          /* invalid rows arrived as 0; VM: ragged Tout only */ \
-      put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                              \
+      put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v, ka);                          \
       if (real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                                         \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
@@ -2318,75 +2267,50 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
         v = make_float4(o[0], o[1], o[2], o[3]);                                               \
       }                                                                                        \
       if constexpr (X16) put_raw(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);          \
-      else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v);                         \
+      else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v, kb);                     \
     }                                                                                          \
   }
-  constexpr bool LEANW = W3_LEAN && WM == 4 && NC == 1 && NP == 3;
+  constexpr bool LEANW = W3_LEAN && WM == 4 && NC == 1 && NP >= 2;
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
     if constexpr (LEANW) {                 // 128-VGPR form: the A fragments of one 32-row block at a time (same products, same order)
-      bf16x8 bq[2][3];
+      uint4 bq[2][NP];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[j][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + j * 32 + li]);
+        for (int p = 0; p < NP; ++p) bq[j][p] = Bs[cur][p][lk][wn * 64 + j * 32 + li];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        bf16x8 ap[3];
+        uint4 ap[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ap[p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
+        for (int p = 0; p < NP; ++p) ap[p] = As[cur][p][lk][wm * 64 + i * 32 + li];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bq[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bq[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bq[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(ap, bq[j], acc[i][j]);
       }
       return;
     }
-    bf16x8 af[2][NP], bf[2][NP];
+    uint4 af[2][NP], bf[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        if (X3_ABL == 3) {
-          af[i][p] = __builtin_bit_cast(bf16x8, make_uint4(tid + i, p, acc[0][0][0] > 1e30f ? 1u : 0u, 3u));
-          bf[i][p] = af[i][p];
-        } else {
-        af[i][p] = __builtin_bit_cast(bf16x8, As[cur][p][lk][wm * 64 + i * 32 + li]);
-        bf[i][p] = __builtin_bit_cast(bf16x8, Bs[cur][p][lk][wn * 64 + i * 32 + li]);
-        }
+        af[i][p] = As[cur][p][lk][wm * 64 + i * 32 + li];
+        bf[i][p] = Bs[cur][p][lk][wn * 64 + i * 32 + li];
       }
-    auto block = [&](f32x16 (&ac)[2][2], bf16x8 (&bq)[2][NP]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = ac[i][j];
-          if constexpr (NP == 3) {                               // small products first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bq[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bq[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][1], c, 0, 0, 0);
-          }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bq[j][0], c, 0, 0, 0);
-          ac[i][j] = c;
-        }
-    };
-    block(acc, bf);
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(af[i], bf[j], acc[i][j]);
     if constexpr (NC == 2) {
-      bf16x8 bg[2][NP];
+      uint4 bg[2][NP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bg[i][p] = X3_ABL == 3 ? bf[i][p] : __builtin_bit_cast(bf16x8, Bs[cur][p][lk][BN + wn * 64 + i * 32 + li]);
-      block(acc2, bg);
+        for (int p = 0; p < NP; ++p) bg[i][p] = Bs[cur][p][lk][BN + wn * 64 + i * 32 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[i][j] = mfma_chain<NP>(af[i], bg[j], acc2[i][j]);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -2452,7 +2376,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP == 3
         for (int r = 0; r < 16; ++r) {
           const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
           const int col = wn * 64 + ni * 32 + li;
-          slab[row * BN + col] = ac[mi][ni][r];
+          slab[row * BN + col] = NP == 2 ? __builtin_ldexpf(ac[mi][ni][r], ku) : ac[mi][ni][r];
         }
     }
   };
@@ -2548,7 +2472,8 @@ static inline int pad16(int v) { return (v + 15) / 16 * 16; }
 static inline int pad128(int v) { return (v + 127) / 128 * 128; }
 // rows of `ldw` floats one tap's packed slab occupies: the contraction length padded to whole K
 // steps, and half as much again in mode 2 (three bf16 pieces = 6 bytes per weight instead of 4)
-static inline int slab_rows(int c) { const int r = pad16(c); return g_matmul_dtype == 2 ? r + r / 2 : r; }
+// (mode 3's two-fp16-piece slabs need only r, but keep mode 2's stride: one workspace layout serves both kinds of launch)
+static inline int slab_rows(int c) { const int r = pad16(c); return g_matmul_dtype >= 2 ? r + r / 2 : r; }
 
 static bool seg_vec_ok(const Seg& s) {
   return s.tmul == 1 && s.tdiv == 1 && (s.x_cstride % 4 == 0) && (s.x_bstride % 4 == 0) &&
@@ -2601,6 +2526,13 @@ static size_t ksplit_partial_floats(int M, int Tout, int B, int nk) {
 
 template <int EPI>
 static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
+  // the arithmetic of THIS launch: mode 3 is float32x2 (NP = 2) where the caller provided maxima and a format-3 slab
+  // for every segment, mode 2's six-product kernels everywhere else
+  const int mode = g_matmul_dtype == 3 ? (g.f16x2 ? 3 : 2) : g_matmul_dtype;
+  VQ_REQUIRE(!g.f16x2 || g_matmul_dtype == 3, "conv_gemm: float32x2 launch outside matmul mode 3");
+  if (mode == 3)
+    for (int i = 0; i < g.nseg; ++i)
+      VQ_REQUIRE(g.seg[i].wamax && (g.seg[i].amax || g.seg[i].amax_static > 0.f), "conv_gemm: float32x2 segment %d without its maxima", i);
   const bool big = (g.M % 256 == 0) && (EPI != EPI_GATE_BWD);    // 256-row tiles (8 waves)
   const int bm = big ? 256 : 128;
   g.ntile_m = cdiv(g.M, bm);
@@ -2617,14 +2549,14 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     fprintf(stderr, "[gemm] epi %d M %d Tout %d B %d nseg %d K %d blocks %ld tag %d tmul %d tdiv %d\n", EPI, g.M, g.Tout, g.B, g.nseg, ktot, nblk, tag, g.seg[0].tmul, g.seg[0].tdiv);
   }
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
-  if (g_matmul_dtype != 0)          // modes 1 / 2 address a batch item's activations with 32-bit buffer offsets
+  if (mode != 0)          // modes 1 - 3 address a batch item's activations with 32-bit buffer offsets
     for (int i = 0; i < g.nseg; ++i)
       VQ_REQUIRE((long)g.seg[i].cin * g.seg[i].x_cstride * 4 < (1L << 31), "conv_gemm: one batch item of segment %d exceeds 2 GB (Cin * T * 4 bytes)", i);
   // split-K when the caller provided a partial-tile buffer and the shape calls for it
   int nk = 0;
   for (int i = 0; i < g.nseg; ++i) nk += cdiv(g.seg[i].cin, BK);
   g.ksplit = 1;
-  if (EPI == EPI_LINEAR && !big && g.partial != nullptr) {
+  if (EPI == EPI_LINEAR && !big && g.partial != nullptr && g.out[0].amax_out == nullptr) {
     const int sp = plan_ksplit(g.M, g.Tout, g.B, nk);
     if (sp > 1) { g.ksplit = sp; g.ksteps_per_split = cdiv(nk, sp); }
   }
@@ -2642,7 +2574,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if constexpr (EPI == EPI_LINEAR) {
     static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;   // 0: off; 32 / 64: column tile
     const Seg& s0 = g.seg[0];
-    if (lin128 && g_matmul_dtype != 0 && g.nseg == 1 && g.M == 256 && s0.cin == 128 && g.out[1].y == nullptr &&
+    if (lin128 && mode != 0 && g.nseg == 1 && g.M == 256 && s0.cin == 128 && g.out[1].y == nullptr &&
         !g.out[0].relu && !g.out[0].accumulate && s0.tmul == 1 && s0.tdiv == 1 && s0.toff == 0 && s0.Tin == g.Tout &&
         s0.x_cstride == g.Tout && g.Tout % 64 == 0 && s0.vec && s0.ldw >= 256 && g.lerp.P == nullptr &&
         g.skip_flag == nullptr && g.ksplit == 1) {
@@ -2653,6 +2585,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       la.y = g.out[0].y; la.y_bstride = g.out[0].y_bstride;
       la.bias = g.out[0].bias;
       la.T = g.Tout;
+      la.wamax = s0.wamax; la.z_amax = s0.amax; la.z_amax_static = s0.amax_static; la.amax_out = g.out[0].amax_out;
       const int nc = (lin128 == 32 || g.z16) ? 32 : 64;
       la.tiles_per_b = g.Tout / nc; la.ntiles = la.tiles_per_b * g.B;
       static int n_cu = 0;
@@ -2666,7 +2599,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
         if (la.add) LG_LAUNCH((lin128_stream_kernel<NPv, NCv, true>), dim3(nwg), dim3(512), la);     \
         else LG_LAUNCH((lin128_stream_kernel<NPv, NCv, false>), dim3(nwg), dim3(512), la);           \
       } while (0)
-      if (g_matmul_dtype == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
+      if (mode == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
+      else if (mode == 3) L128_LAUNCH(2, 32);
       else if (g.z16) {
         if (la.add) LG_LAUNCH((lin128_stream_kernel<1, 32, true, true>), dim3(nwg), dim3(512), la);
         else LG_LAUNCH((lin128_stream_kernel<1, 32, false, true>), dim3(nwg), dim3(512), la);
@@ -2684,44 +2618,36 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // two taps of one tensor: interleave them channel group by channel group (TAP2).  The choice depends
   // on the contraction only, never on the tile shape, so that a result does not change with the batch size.
   static const int x3_tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
-  const bool tap2 = x3_tap2 && g_matmul_dtype != 0 && g.nseg == 2 && g.ksplit == 1 &&
+  const bool tap2 = x3_tap2 && mode != 0 && g.nseg == 2 && g.ksplit == 1 &&
                     g.seg[0].cin == g.seg[1].cin && g.seg[0].cin % BK == 0 &&
                     g.seg[0].x_cstride == g.seg[1].x_cstride && g.seg[0].x_bstride == g.seg[1].x_bstride &&
                     g.seg[0].Tin == g.seg[1].Tin && g.seg[0].tmul == g.seg[1].tmul && g.seg[0].tdiv == g.seg[1].tdiv &&
                     g.seg[0].ldw == g.seg[1].ldw && g.seg[1].w >= g.seg[0].w &&          // second slab addressed off the first's descriptor
                     (reinterpret_cast<const char*>(g.seg[1].w) - reinterpret_cast<const char*>(g.seg[0].w)) < (1L << 30);
-  // Two taps in the six-product mode: 256 x 128 tiles whose loop fits 128 VGPRs (LEAN in conv_gemm_x3_kernel), TWO
+  // Two taps, two or more pieces per operand: 256 x 128 tiles whose loop fits 128 VGPRs (LEAN in conv_gemm_x3_kernel), TWO
   // workgroups per CU -- one tile's epilogue beside the other's K loop: gate kernel 211 -> 197 us, backward-data
   // 217 -> 198 us at configs[1] against the 256 x 256 tiles, which stay for every other contraction.  Same K
-  // order and products as the other two-tap kernels: the choice never changes a result.
+  // order and products as the 256 x 256-tile two-tap kernel (VQVAE_X3_LEAN=0, the A/B alternate): the choice never changes a result.
   static const int x3_lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
-  const bool lean = x3_lean && X3_LEAN && tap2 && big && g_matmul_dtype != 0 && EPI != EPI_GATE_BWD && x3_nb != 3;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
-  const bool wide = g_matmul_dtype != 0 && big && !lean && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
+  const bool lean = x3_lean && X3_LEAN && tap2 && big && mode != 0 && EPI != EPI_GATE_BWD && x3_nb != 3;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
+  const bool wide = mode != 0 && big && !lean && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
   if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
 #define X3_LAUNCH(WMv, NBv, NPv, blocks, threads)                                                                    \
   do {                                                                                                                \
     if (tap2) LG_LAUNCH((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, true>), dim3((unsigned)(blocks)), dim3(threads), g);  \
     else LG_LAUNCH((conv_gemm_x3_kernel<EPI, WMv, NBv, NPv, false>), dim3((unsigned)(blocks)), dim3(threads), g);      \
   } while (0)
+#define X3_LAUNCH_MODE(WMv, NBv, blocks, threads)                                                                    \
+  do {                                                                                                                \
+    if (mode == 2) X3_LAUNCH(WMv, NBv, 3, blocks, threads);                                                           \
+    else if (mode == 3) X3_LAUNCH(WMv, NBv, 2, blocks, threads);                                                      \
+    else X3_LAUNCH(WMv, NBv, 1, blocks, threads);                                                                     \
+  } while (0)
   // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
   // not instantiated
-  // both taps of ONE tensor, dilation <= WIN_MAX_DIL, 256 x 256 tiles: one staged window per channel group.
-  // (Depends on the contraction and on `wide`, which depends on the launch size -- but the window kernel's K
-  // order and products are the TAP2 kernel's, so the choice never changes a result.)
-  static const int x3_win = getenv("VQVAE_X3_WIN") ? atoi(getenv("VQVAE_X3_WIN")) : 1;
-  if constexpr (EPI != EPI_GATE_BWD) {
-    const int ddil = g.nseg == 2 ? abs(g.seg[0].toff - g.seg[1].toff) : 0;
-    if (x3_win && tap2 && wide && g.seg[0].x == g.seg[1].x && g.seg[0].tmul == 1 && g.seg[0].tdiv == 1 &&
-        ddil >= 1 && ddil <= WIN_MAX_DIL && g.skip_flag == nullptr) {
-      if (g_matmul_dtype == 2) LG_LAUNCH((conv_win_x3_kernel<EPI, 3>), dim3((unsigned)nblk2), dim3(512), g);
-      else LG_LAUNCH((conv_win_x3_kernel<EPI, 1>), dim3((unsigned)nblk2), dim3(512), g);
-      VQ_LAUNCH_CHECK();
-      return 0;
-    }
-  }
   if constexpr (EPI == EPI_LINEAR) {
     if (g.z16) {
-      VQ_REQUIRE(g_matmul_dtype == 1 && big && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1 and 256-row tiles");
+      VQ_REQUIRE(mode == 1 && big && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1 and 256-row tiles");
       for (int i = 0; i < g.nseg; ++i) VQ_REQUIRE(g.seg[i].tmul == 1 && g.seg[i].tdiv == 1, "conv_gemm: bf16-stored activations: stride-1 segments only");
       if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, true>), dim3((unsigned)nblk2), dim3(512), g);
       else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, true>), dim3((unsigned)nblk), dim3(512), g);
@@ -2730,25 +2656,21 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     }
   }
   if constexpr (EPI != EPI_GATE_BWD) {
-    if (big && g_matmul_dtype == 2) {
-      if (wide) X3_LAUNCH(4, 2, 3, nblk2, 512);
-      else X3_LAUNCH(4, 1, 3, nblk, 512);
-    } else if (big && g_matmul_dtype == 1) {
-      if (wide) X3_LAUNCH(4, 2, 1, nblk2, 512);
-      else X3_LAUNCH(4, 1, 1, nblk, 512);
+    if (big && mode != 0) {
+      if (wide) X3_LAUNCH_MODE(4, 2, nblk2, 512);
+      else X3_LAUNCH_MODE(4, 1, nblk, 512);
     } else if (big) {
       LG_LAUNCH((conv_gemm_kernel<EPI, 4, false>), dim3((unsigned)nblk), dim3(512), g);
     }
     if (!big) {
-      if (g_matmul_dtype == 2) X3_LAUNCH(2, 1, 3, grid, 256);
-      else if (g_matmul_dtype == 1) X3_LAUNCH(2, 1, 1, grid, 256);
+      if (mode != 0) X3_LAUNCH_MODE(2, 1, grid, 256);
       else LG_LAUNCH((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), g);
     }
   } else {
-    if (g_matmul_dtype == 2) X3_LAUNCH(2, 1, 3, grid, 256);
-    else if (g_matmul_dtype == 1) X3_LAUNCH(2, 1, 1, grid, 256);
+    if (mode != 0) X3_LAUNCH_MODE(2, 1, grid, 256);
     else LG_LAUNCH((conv_gemm_kernel<EPI, 2, false>), dim3((unsigned)grid), dim3(256), g);
   }
+#undef X3_LAUNCH_MODE
 #undef X3_LAUNCH
 #undef LG_LAUNCH
   VQ_LAUNCH_CHECK();
@@ -2762,18 +2684,25 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   return 0;
 }
 
-static int launch_pack(PackArgs& pa, hipStream_t st) {
+// fmt: the slab format (PackArgs::bf16), -1 = the matmul mode's default (mode 3: format 2 -- its float32x2 launches ask
+// for format 3 explicitly and give every job its AMAX_SLOTS `amax` words)
+static int launch_pack(PackArgs& pa, hipStream_t st, int fmt = -1) {
   if (pa.njob == 0) return 0;
+  pa.bf16 = fmt >= 0 ? fmt : (g_matmul_dtype == 3 ? 2 : g_matmul_dtype);
   long mx = 0;
   for (int i = 0; i < pa.njob; ++i) {
     long t = (long)pa.job[i].K * pa.job[i].Rpad * pa.job[i].mspan;
-    if (g_matmul_dtype != 0) t /= 8;
+    if (pa.bf16 != 0) t /= 8;
     if (t > mx) mx = t;
   }
   int nb = (int)((mx + 255) / 256);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  pa.bf16 = g_matmul_dtype;
+  if (pa.bf16 == 3) {
+    for (int i = 0; i < pa.njob; ++i) VQ_REQUIRE(pa.job[i].amax != nullptr, "pack: format 3 job without an amax slot");
+    hipLaunchKernelGGL(wamax_kernel, dim3(AMAX_SLOTS, pa.njob), dim3(256), 0, st, pa);
+    VQ_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(pack_kernel, dim3(nb, pa.njob), dim3(256), 0, st, pa);
   VQ_LAUNCH_CHECK();
   return 0;
@@ -2786,6 +2715,7 @@ static PackJob pack_fwd_job(float* dst, const float* W, int Cout, int Cin, int K
   j.dst = dst; j.src = W; j.R = Cin; j.Cm = Cout; j.K = K;
   j.s_k = K; j.s_m = (long)Cin * K; j.s_tap = 1;
   j.gate_half = gate_half; j.Rpad = pad16(Cin); j.ldw = ldw; j.m_off = m_off; j.mspan = mspan;
+  j.amax = nullptr;
   return j;
 }
 // A^T slab for the bwd-data GEMM: k=co, m=ci
@@ -2794,6 +2724,7 @@ static PackJob pack_bwd_job(float* dst, const float* W, int Cout, int Cin, int K
   j.dst = dst; j.src = W; j.R = Cout; j.Cm = Cin; j.K = K;
   j.s_k = (long)Cin * K; j.s_m = K; j.s_tap = 1;
   j.gate_half = 0; j.Rpad = pad16(Cout); j.ldw = ldw; j.m_off = 0; j.mspan = ldw;
+  j.amax = nullptr;
   return j;
 }
 
@@ -2877,29 +2808,41 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   // wgrad3_kernel addresses both operands with 32-bit buffer offsets from the tensor base
   fast = fast && (g_matmul_dtype == 0 || (long)w.B * w.gy_bstride * 4 < (1L << 31));
   for (int i = 0; i < w.nseg; ++i) fast = fast && (g_matmul_dtype == 0 || (long)w.B * w.seg[i].x_bstride * 4 < (1L << 31));
+  // the arithmetic of this launch (see launch_gemm): float32x2 when the caller gave every segment its maxima and the
+  // shape runs on wgrad3_kernel; both operands are activations, so falling back to mode 2 needs nothing re-packed
+  VQ_REQUIRE(!w.f16x2 || g_matmul_dtype == 3, "wgrad: float32x2 launch outside matmul mode 3");
+  if (w.f16x2)
+    for (int i = 0; i < w.nseg; ++i)
+      VQ_REQUIRE((w.seg[i].amax_x || w.seg[i].amax_x_static > 0.f) && (w.seg[i].gy ? w.seg[i].amax_gy != nullptr : w.amax_gy != nullptr),
+                 "wgrad: float32x2 segment %d without its maxima", i);
+  const int mode = g_matmul_dtype == 3 ? ((w.f16x2 && fast) ? 3 : 2) : g_matmul_dtype;
   ProfScope ps(tag, st);
   static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
   const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
-  if (fast && g_matmul_dtype == 2 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
+  if (fast && mode == 3 && w.M % 256 == 0) {
+    hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+  } else if (fast && mode == 3) {
+    hipLaunchKernelGGL((wgrad3_kernel<2, 1, 2>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
+  } else if (fast && mode == 2 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 2, 3>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
-  } else if (fast && g_matmul_dtype == 2 && w.M % 256 == 0) {
+  } else if (fast && mode == 2 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 3>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
-  } else if (fast && g_matmul_dtype == 2) {
+  } else if (fast && mode == 2) {
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 3>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
   } else if (w.x16) {
-    bool ok16 = fast && g_matmul_dtype == 1 && w.M % 256 == 0 && w.Tout % W2K == 0;
+    bool ok16 = fast && mode == 1 && w.M % 256 == 0 && w.Tout % W2K == 0;
     for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].toff == 0 && w.seg[i].Tin == w.Tout;
     VQ_REQUIRE(ok16, "wgrad: bf16-stored x operand needs matmul mode 1, unshifted stride-1 segments, 256-row tiles and T %% 16 == 0");
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
-  } else if (fast && g_matmul_dtype == 1 && w.M % 256 == 0) {
+  } else if (fast && mode == 1 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
-  } else if (fast && g_matmul_dtype == 1) {
+  } else if (fast && mode == 1) {
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 1>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
   } else if (fast && w.M % 256 == 0) {
     hipLaunchKernelGGL(wgrad2_kernel<4>, dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast) {
     hipLaunchKernelGGL(wgrad2_kernel<2>, dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
-  } else if (g_matmul_dtype == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
+  } else if (mode == 1) hipLaunchKernelGGL(wgrad_kernel<true>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   else hipLaunchKernelGGL(wgrad_kernel<false>, dim3(p.ntile_m * p.ntile_n, p.nsplit), dim3(NT), 0, st, w);
   VQ_LAUNCH_CHECK();
   const long total = (long)p.ntile_m * BM * p.ntile_n * BN + (long)p.nseg * p.ntile_m * BM;
@@ -2915,7 +2858,7 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
 using namespace vq;
 
 extern "C" int vqvae_set_matmul_dtype(int dtype) {
-  VQ_REQUIRE(dtype >= 0 && dtype <= 2, "set_matmul_dtype: 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 as six bf16 MFMA products)");
+  VQ_REQUIRE(dtype >= 0 && dtype <= 3, "set_matmul_dtype: 0 (fp32 MFMA), 1 (bf16 operands), 2 (fp32 as six bf16 MFMA products) or 3 (fp32 as three fp16 MFMA products)");
   vq::g_matmul_dtype = dtype;
   return 0;
 }
@@ -2970,6 +2913,38 @@ __global__ void phase_split_kernel(const float* __restrict__ x, long rows, int T
   }
 }
 
+// matmul mode 3, generic conv entry points: the float32x2 kernels need the operands' absolute maxima before they run.
+// Nobody hands them to these entry points, so a launch large enough to pay for it (>= 8 GFLOP: proj1 / proj2 at the
+// configs; vqvae_set_f32x2_min_gflop / VQVAE_F16X2_MIN_GFLOP override, 0 = every launch, which is how the parity and
+// accuracy tests reach these kernels at their small shapes) runs
+// absmax_kernel over its activation operand first (one read of the tensor: ~25 us per 126 MB against ~60 us saved);
+// everything smaller keeps mode 2's kernels.  The maxima live in the last 64 bytes of the workspace.
+static double g_f32x2_min_gflop = -1.0;        // < 0: not set (VQVAE_F16X2_MIN_GFLOP, else 8)
+static bool conv_f16x2(const vqvae_conv1d_desc* d) {
+  if (g_matmul_dtype != 3) return false;
+  if (g_f32x2_min_gflop < 0.0) g_f32x2_min_gflop = getenv("VQVAE_F16X2_MIN_GFLOP") ? atof(getenv("VQVAE_F16X2_MIN_GFLOP")) : 8.0;
+  return 2.0 * d->B * d->Tout * (double)d->Cout * d->Cin * d->K >= g_f32x2_min_gflop * 1e9;
+}
+extern "C" int vqvae_set_f32x2_min_gflop(double gflop) {
+  VQ_REQUIRE(gflop >= 0.0, "set_f32x2_min_gflop: negative threshold");
+  g_f32x2_min_gflop = gflop;
+  return 0;
+}
+static int launch_absmax(const float* x, long n, unsigned* out, hipStream_t st) {      // out[AMAX_SLOTS] zeroed beforehand
+  long nb = (n / 16 + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, n, out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int vqvae_absmax(const float* x, size_t n, uint32_t* amax, vqvae_stream_t s) {
+  VQ_REQUIRE(x && amax, "absmax: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  VQ_CHECK_HIP(hipMemsetAsync(amax, 0, AMAX_SLOTS * sizeof(uint32_t), st));
+  return launch_absmax(x, (long)n, amax, st);
+}
+
 extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
   if (!d) return 0;
   int cins[MAXTAPS];
@@ -2981,7 +2956,10 @@ extern "C" size_t vqvae_conv1d_workspace_bytes(const vqvae_conv1d_desc* d) {
   size_t pf = ksplit_partial_floats(d->Cout, d->Tout, d->B, d->K * cdiv(d->Cin, BK));
   size_t pb = ksplit_partial_floats(d->Cin, d->Tin, d->B, d->K * cdiv(d->Cout, BK));
   size_t gm = align_up(pk, 256) + (pf > pb ? pf : pb) * sizeof(float);
-  return align_up(wg > gm ? wg : gm, 256) + 256;
+  return align_up(wg > gm ? wg : gm, 256) + 512;      // (the last 128 bytes: maxima of a float32x2 launch)
+}
+static unsigned* conv_amax_slots(const vqvae_conv1d_desc* d, void* ws) {
+  return reinterpret_cast<unsigned*>((char*)ws + vqvae_conv1d_workspace_bytes(d) - 2 * AMAX_SLOTS * sizeof(unsigned));
 }
 
 extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
@@ -2999,16 +2977,25 @@ extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x,
   const int ldw = pad128(d->Cout), rp = slab_rows(d->Cin);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* pk = (float*)ws;
+  const bool f16 = conv_f16x2(d) && skip_flag == nullptr && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
+  unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
+  if (f16) {
+    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
+    if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
+  }
   PackArgs pa; pa.njob = 1;
   pa.job[0] = pack_fwd_job(pk, W, d->Cout, d->Cin, d->K, 0, ldw, 0, ldw);
-  if (int e = launch_pack(pa, st)) return e;
+  pa.job[0].amax = f16 ? am + AMAX_SLOTS : nullptr;
+  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.nseg = d->K;
+  g.f16x2 = f16 ? 1 : 0;
   for (int j = 0; j < d->K; ++j) {
     Seg& sg = g.seg[j];
     sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
     sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
+    if (f16) { sg.amax = am; sg.wamax = am + AMAX_SLOTS; }
   }
   g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
   g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
@@ -3031,17 +3018,26 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
   const int ldw = pad128(d->Cin), rp = slab_rows(d->Cout);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_bwd_data: workspace too small"); return VQVAE_E_WORKSPACE; }
   float* pk = (float*)ws;
+  const bool f16 = conv_f16x2(d) && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
+  unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
+  if (f16) {
+    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
+    if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am, st)) return e;
+  }
   PackArgs pa; pa.njob = 1;
   pa.job[0] = pack_bwd_job(pk, W, d->Cout, d->Cin, d->K, ldw);
-  if (int e = launch_pack(pa, st)) return e;
+  pa.job[0].amax = f16 ? am + AMAX_SLOTS : nullptr;
+  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.nseg = d->K;
+  g.f16x2 = f16 ? 1 : 0;
   for (int j = 0; j < d->K; ++j) {
     Seg& sg = g.seg[j];
     sg.x = gy; sg.x_bstride = (long)d->Cout * d->Tout; sg.x_cstride = d->Tout; sg.cin = d->Cout; sg.Tin = d->Tout;
     // t_out(gy) = (u + pad - j*dil) / stride
     sg.tmul = 1; sg.toff = d->pad - j * d->dil; sg.tdiv = d->stride;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
+    if (f16) { sg.amax = am; sg.wamax = am + AMAX_SLOTS; }
   }
   g.M = d->Cin; g.Tout = d->Tin; g.B = d->B;
   g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;
@@ -3103,6 +3099,14 @@ extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const fl
   }
   w.seg[0].gb = gb; w.accumulate = accumulate;
   w.skip_flag = skip_flag;
+  if (conv_f16x2(d) && !phases && d->stride == 1 && skip_flag == nullptr && ws_bytes >= vqvae_conv1d_workspace_bytes(d)) {
+    unsigned* am = conv_amax_slots(d, ws);
+    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
+    if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
+    if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am + AMAX_SLOTS, st)) return e;
+    w.f16x2 = 1; w.amax_gy = am + AMAX_SLOTS;
+    for (int j = 0; j < d->K; ++j) w.seg[j].amax_x = am;
+  }
   return launch_wgrad(w, p, (float*)ws, VQVAE_PROF_CONV_WGRAD, st);
 }
 
@@ -3111,9 +3115,11 @@ extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const fl
 // ---------------------------------------------------------------------------
 namespace {
 struct RbLayout {
-  size_t gh, pk_d, pk_c, pk_o, pk_gz_r, pk_gz_s, pk_bd, pk_bc, slabs, total;   // float offsets
+  size_t gh, pk_d, pk_c, pk_o, pk_gz_r, pk_gz_s, pk_bd, pk_bc, hdr, slabs, total;   // float offsets
   WgradPlan p_h, p_r, p_s;
 };
+
+enum { HDR_D = 0, HDR_O = AMAX_SLOTS, HDR_GZ_R = 2 * AMAX_SLOTS, HDR_GZ_S = 3 * AMAX_SLOTS, HDR_BD = 4 * AMAX_SLOTS, HDR_N = 5 };   // word offsets into RbLayout::hdr
 
 static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   RbLayout L;
@@ -3128,6 +3134,7 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   L.pk_gz_s = take((size_t)slab_rows(d->Cs) * pad128(Ch));             // bwd gz from g_skip
   L.pk_bd = take((size_t)d->K * slab_rows(d->Cd) * pad128(d->Cr));     // bwd-data dilated conv
   L.pk_bc = take((size_t)slab_rows(d->Cd) * pad128(d->Cc));            // bwd-data cond proj
+  L.hdr = take(HDR_N * AMAX_SLOTS);                                    // float32x2: max |W| of each format-3 slab (HDR_* x AMAX_SLOTS words)
   int cins[MAXSEG];
   for (int j = 0; j < d->K; ++j) cins[j] = d->Cr;
   cins[d->K] = d->Cc;
@@ -3169,6 +3176,28 @@ static int check_rb(const vqvae_resblock_desc* d) {
 }
 }  // namespace
 
+// What vqvae_resstack_pack wrote where: the slabs' layout depends on the matmul mode at pack time, and the kernels that
+// read them are chosen by the mode at call time -- a vqvae_set_matmul_dtype between the two would make them read one
+// format as another, silently.  Host-side tag per packed buffer, checked by every _packed entry point.
+static std::mutex g_packed_mu;
+static std::map<const char*, std::pair<size_t, int>> g_packed_fmt;       // base -> (bytes, matmul mode at pack time)
+static void packed_register(const void* base, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_packed_mu);
+  const char* b = (const char*)base;
+  for (auto it = g_packed_fmt.begin(); it != g_packed_fmt.end();)          // drop stale overlapping entries (the pool reuses addresses)
+    it = (it->first < b + bytes && b < it->first + it->second.first) ? g_packed_fmt.erase(it) : ++it;
+  g_packed_fmt[b] = std::make_pair(bytes, g_matmul_dtype);
+}
+static int packed_check(const void* p) {
+  std::lock_guard<std::mutex> lk(g_packed_mu);
+  auto it = g_packed_fmt.upper_bound((const char*)p);
+  VQ_REQUIRE(it != g_packed_fmt.begin(), "packed slabs %p were not written by vqvae_resstack_pack", p);
+  --it;
+  VQ_REQUIRE((const char*)p < it->first + it->second.first, "packed slabs %p were not written by vqvae_resstack_pack", p);
+  VQ_REQUIRE(it->second.second == g_matmul_dtype, "packed slabs were written in matmul mode %d, used in mode %d", it->second.second, g_matmul_dtype);
+  return 0;
+}
+
 extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
   if (!d || d->Cd <= 0) return 0;
   return rb_layout(d).total * sizeof(float) + 256;
@@ -3180,8 +3209,12 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
                              const float* x, const float* cond,
                              const vqvae_resblock_cproj* cproj, float* res, float* skip,
                              int skip_accumulate, float* gates, float* z, void* ws,
-                             size_t ws_bytes, const float* packed, vqvae_stream_t s) {
+                             size_t ws_bytes, const float* packed, const vqvae_resblock_amax* am, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
+  // matmul mode 3: the packed chain runs the float32x2 kernels (vqvae_resstack_pack wrote format-3 slabs) and needs the
+  // caller's maxima; the pack-per-call form keeps mode 2's kernels
+  const bool f16 = g_matmul_dtype == 3 && packed != nullptr;
+  if (f16) VQ_REQUIRE(am && am->x && (res == nullptr || am->res), "resblock_fwd_packed: matmul mode 3 needs amax->x (and amax->res with a residual output)");
   VQ_REQUIRE(p && x && (cond || cproj) && gates && z && ws, "resblock_fwd: null pointer");
   VQ_REQUIRE(p->Wd && (cproj || p->Wc) && (skip == nullptr || p->Ws) && (res == nullptr || p->Wr), "resblock_fwd: null weight");
   if (cproj) VQ_REQUIRE(cproj->P && cproj->v0 && cproj->w0 && cproj->w1 && cproj->Tl >= 2, "resblock_fwd: bad cproj");
@@ -3221,7 +3254,9 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
       sg.x = x; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
       sg.tmul = 1; sg.toff = -(d->K - 1 - j) * d->dil; sg.tdiv = 1;
       sg.w = w + L.pk_d + (size_t)j * rp * ldd; sg.ldw = ldd;
+      if (f16) { sg.amax = am->x; sg.wamax = reinterpret_cast<const unsigned*>(w + L.hdr) + HDR_D; }
     }
+    g.f16x2 = f16 ? 1 : 0;
     if (cproj) {      // condition projection (incl. its bias) arrives pre-computed at latent rate
       g.lerp.P = cproj->P; g.lerp.p_bstride = cproj->P_bstride; g.lerp.Tl = cproj->Tl;
       g.lerp.v0 = cproj->v0; g.lerp.w0 = cproj->w0; g.lerp.w1 = cproj->w1;
@@ -3245,11 +3280,13 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     Seg& sg = g.seg[0];
     sg.x = z; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
     sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + L.pk_o; sg.ldw = ldo;
+    if (f16) { sg.amax_static = 1.f; sg.wamax = reinterpret_cast<const unsigned*>(w + L.hdr) + HDR_O; g.f16x2 = 1; }   // |z| = |tanh * sigmoid| <= 1
     g.M = Mo; g.Tout = T; g.B = d->B;
     int o = 0;
     if (res) {
       g.out[0].y = res; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
       g.out[0].add = x; g.out[0].add_bstride = (long)d->Cr * T; g.out[0].bias = p->br;
+      g.out[0].amax_out = am ? am->res : nullptr;
       o = 1;
     }
     if (skip) {
@@ -3267,15 +3304,16 @@ extern "C" int vqvae_resblock_fwd(const vqvae_resblock_desc* d, const vqvae_resb
                                   const vqvae_resblock_cproj* cproj, float* res, float* skip,
                                   int skip_accumulate, float* gates, float* z, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
-  return resblock_fwd_impl(d, p, x, cond, cproj, res, skip, skip_accumulate, gates, z, ws, ws_bytes, nullptr, s);
+  return resblock_fwd_impl(d, p, x, cond, cproj, res, skip, skip_accumulate, gates, z, ws, ws_bytes, nullptr, nullptr, s);
 }
 
 extern "C" int vqvae_resblock_fwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                                          const float* x, const vqvae_resblock_cproj* cproj, float* res,
                                          float* gates, float* z, void* ws, size_t ws_bytes,
-                                         const void* packed, vqvae_stream_t s) {
+                                         const void* packed, const vqvae_resblock_amax* amax, vqvae_stream_t s) {
   VQ_REQUIRE(packed, "resblock_fwd_packed: null packed slabs");
-  return resblock_fwd_impl(d, p, x, nullptr, cproj, res, nullptr, 0, gates, z, ws, ws_bytes, (const float*)packed, s);
+  if (int e = packed_check(packed)) return e;
+  return resblock_fwd_impl(d, p, x, nullptr, cproj, res, nullptr, 0, gates, z, ws, ws_bytes, (const float*)packed, amax, s);
 }
 
 extern "C" size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d) {
@@ -3299,21 +3337,24 @@ extern "C" int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
   hipStream_t st = (hipStream_t)s;
   const int Ch = d->Cd / 2;
   const int ldd = pad128(d->Cd), ldz = pad128(Ch), ldr = pad128(d->Cr);
+  const bool f16 = g_matmul_dtype == 3;      // float32x2 chain: two scaled fp16 pieces, max |W| of every slab in the block's header
+  packed_register(packed, per * sizeof(float) * nblocks);
   PackArgs pa; pa.njob = 0;
-  auto flush = [&]() -> int { if (pa.njob == 0) return 0; const int e = launch_pack(pa, st); pa.njob = 0; return e; };
+  auto flush = [&]() -> int { if (pa.njob == 0) return 0; const int e = launch_pack(pa, st, f16 ? 3 : -1); pa.njob = 0; return e; };
+  auto add = [&](PackJob j, float* w, int slot) { j.amax = f16 ? reinterpret_cast<unsigned*>(w + L.hdr) + slot : nullptr; pa.job[pa.njob++] = j; };
   for (int l = 0; l < nblocks; ++l) {
     float* w = (float*)packed + (size_t)l * per - L.pk_d;
     const vqvae_resblock_params& p = params[l];
     VQ_REQUIRE(p.Wd && p.Ws && (!has_res[l] || p.Wr), "resstack_pack: null weight in block %d", l);
     if (pa.njob + 5 > MAXSEG) { if (int e = flush()) return e; }
-    pa.job[pa.njob++] = pack_fwd_job(w + L.pk_d, p.Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd);
+    add(pack_fwd_job(w + L.pk_d, p.Wd, d->Cd, d->Cr, d->K, Ch, ldd, 0, ldd), w, HDR_D);
     if (has_res[l]) {
       const int ldo = pad128(d->Cr);
-      pa.job[pa.njob++] = pack_fwd_job(w + L.pk_o, p.Wr, d->Cr, Ch, 1, 0, ldo, 0, ldo);
-      pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_r, p.Wr, d->Cr, Ch, 1, ldz);
+      add(pack_fwd_job(w + L.pk_o, p.Wr, d->Cr, Ch, 1, 0, ldo, 0, ldo), w, HDR_O);
+      add(pack_bwd_job(w + L.pk_gz_r, p.Wr, d->Cr, Ch, 1, ldz), w, HDR_GZ_R);
     }
-    pa.job[pa.njob++] = pack_bwd_job(w + L.pk_gz_s, p.Ws, d->Cs, Ch, 1, ldz);
-    pa.job[pa.njob++] = pack_bwd_job(w + L.pk_bd, p.Wd, d->Cd, d->Cr, d->K, ldr);
+    add(pack_bwd_job(w + L.pk_gz_s, p.Ws, d->Cs, Ch, 1, ldz), w, HDR_GZ_S);
+    add(pack_bwd_job(w + L.pk_bd, p.Wd, d->Cd, d->Cr, d->K, ldr), w, HDR_BD);
   }
   return flush();
 }
@@ -3323,8 +3364,10 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
                                   const float* z, const float* g_res, const float* g_skip,
                                   float* gx, float* gcond, int gcond_accumulate, float* gh_out,
                                   const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
-                                  size_t ws_bytes, const float* packed, vqvae_stream_t s) {
+                                  size_t ws_bytes, const float* packed, const vqvae_resblock_amax* am, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
+  const bool f16 = g_matmul_dtype == 3 && packed != nullptr;      // see resblock_fwd_impl
+  if (f16) VQ_REQUIRE(am && am->g_skip && am->gh && (g_res == nullptr || am->g_res), "resblock_bwd_packed: matmul mode 3 needs amax->g_skip, amax->gh (and amax->g_res with a residual gradient)");
   VQ_REQUIRE(p && x && gates && z && g_skip && ws && gr, "resblock_bwd: null pointer");
   VQ_REQUIRE(cond || (!gcond && !gr->gWc && !gr->gbc), "resblock_bwd: condition gradients requested without a condition tensor");
   hipStream_t st = (hipStream_t)s;
@@ -3355,14 +3398,18 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
       Seg& sg = g.seg[n++];
       sg.x = g_res; sg.x_bstride = (long)d->Cr * T; sg.x_cstride = T; sg.cin = d->Cr; sg.Tin = T;
       sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = wpk + L.pk_gz_r; sg.ldw = ldz;
+      if (f16) { sg.amax = am->g_res; sg.wamax = reinterpret_cast<const unsigned*>(wpk + L.hdr) + HDR_GZ_R; }
     }
     Seg& ss = g.seg[n++];
     ss.x = g_skip; ss.x_bstride = (long)d->Cs * T; ss.x_cstride = T; ss.cin = d->Cs; ss.Tin = T;
     ss.tmul = 1; ss.toff = 0; ss.tdiv = 1; ss.w = wpk + L.pk_gz_s; ss.ldw = ldz;
+    if (f16) { ss.amax = am->g_skip; ss.wamax = reinterpret_cast<const unsigned*>(wpk + L.hdr) + HDR_GZ_S; }
+    g.f16x2 = f16 ? 1 : 0;
     g.nseg = n;
     g.M = Ch; g.Tout = T; g.B = d->B;
     g.out[0].y = gh; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].rows = Ch;
     g.out[0].add = gates; g.out[0].add_bstride = (long)d->Cd * T;
+    g.out[0].amax_out = am ? am->gh : nullptr;
     if (int e = launch_gemm<EPI_GATE_BWD>(g, VQVAE_PROF_RESBLOCK_BWD_GZ, st)) return e;
   }
   // K4: gx = g_res + sum_j Wd_j^T gh[t + (K-1-j) dil]
@@ -3375,10 +3422,13 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
       sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
       sg.tmul = 1; sg.toff = (d->K - 1 - j) * d->dil; sg.tdiv = 1;
       sg.w = wpk + L.pk_bd + (size_t)j * rp * ldr; sg.ldw = ldr;
+      if (f16) { sg.amax = am->gh; sg.wamax = reinterpret_cast<const unsigned*>(wpk + L.hdr) + HDR_BD; }
     }
+    g.f16x2 = f16 ? 1 : 0;
     g.M = d->Cr; g.Tout = T; g.B = d->B;
     g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
     g.out[0].add = g_res; g.out[0].add_bstride = (long)d->Cr * T;
+    g.out[0].amax_out = am ? am->gx : nullptr;
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GX, st)) return e;
   }
   // K5: gcond (+)= Wc^T gh
@@ -3445,19 +3495,21 @@ extern "C" int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resb
                                   const vqvae_resblock_grads* gr, int grads_accumulate, void* ws,
                                   size_t ws_bytes, vqvae_stream_t s) {
   return resblock_bwd_impl(d, p, x, cond, gates, z, g_res, g_skip, gx, gcond, gcond_accumulate, gh_out, gr,
-                           grads_accumulate, ws, ws_bytes, nullptr, s);
+                           grads_accumulate, ws, ws_bytes, nullptr, nullptr, s);
 }
 
 // the chain part of a block's backward (gz, gate derivative -> gh_out, backward-data -> gx) on packed slabs
 extern "C" int vqvae_resblock_bwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                                          const float* x, const float* gates, const float* z,
                                          const float* g_res, const float* g_skip, float* gx, float* gh_out,
-                                         void* ws, size_t ws_bytes, const void* packed, vqvae_stream_t s) {
+                                         void* ws, size_t ws_bytes, const void* packed,
+                                         const vqvae_resblock_amax* amax, vqvae_stream_t s) {
   VQ_REQUIRE(packed, "resblock_bwd_packed: null packed slabs");
+  if (int e = packed_check(packed)) return e;
   vqvae_resblock_grads none;
   memset(&none, 0, sizeof(none));
   return resblock_bwd_impl(d, p, x, nullptr, gates, z, g_res, g_skip, gx, nullptr, 0, gh_out, &none, 0, ws, ws_bytes,
-                           (const float*)packed, s);
+                           (const float*)packed, amax, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -3496,7 +3548,7 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
   }
   size_t m = skip_pk > gc_pk ? skip_pk : gc_pk;
   if (wg > m) m = wg;
-  return m * sizeof(float) + 1024;
+  return m * sizeof(float) + 1024 + MAXSEG * AMAX_SLOTS * sizeof(unsigned);     // (+ the weights' maxima of a float32x2 skip sum)
 }
 
 extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
@@ -3512,13 +3564,18 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   const int ld = pad128(d->Cs), rp = slab_rows(Ch);
   float* w = (float*)ws;
   float* bsum = w + (size_t)nblocks * rp * ld;
+  // matmul mode 3: float32x2 -- the operand is the gate output, |z| <= 1 by construction, so only the weights' maxima
+  // (one per block, behind the bias sums) have to be found
+  const bool f16 = g_matmul_dtype == 3;
+  unsigned* wam = reinterpret_cast<unsigned*>(bsum + pad128(d->Cs));
   PackArgs pa; pa.njob = 0;
   PtrList bl;
   for (int l = 0; l < nblocks; ++l) {
-    pa.job[pa.njob++] = pack_fwd_job(w + (size_t)l * rp * ld, Ws[l], d->Cs, Ch, 1, 0, ld, 0, ld);
+    pa.job[pa.njob] = pack_fwd_job(w + (size_t)l * rp * ld, Ws[l], d->Cs, Ch, 1, 0, ld, 0, ld);
+    pa.job[pa.njob++].amax = f16 ? wam + l * AMAX_SLOTS : nullptr;
     bl.p[l] = bs[l];
   }
-  if (int e = launch_pack(pa, st)) return e;
+  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
   hipLaunchKernelGGL(bias_sum_list_kernel, dim3(cdiv(d->Cs, 256)), dim3(256), 0, st, bl, nblocks, d->Cs, bsum);
   VQ_LAUNCH_CHECK();
   GemmArgs g; memset(&g, 0, sizeof(g));
@@ -3527,7 +3584,9 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
     Seg& sg = g.seg[l];
     sg.x = z[l]; sg.x_bstride = (long)Ch * T; sg.x_cstride = T; sg.cin = Ch; sg.Tin = T;
     sg.tmul = 1; sg.toff = 0; sg.tdiv = 1; sg.w = w + (size_t)l * rp * ld; sg.ldw = ld;
+    if (f16) { sg.amax_static = 1.f; sg.wamax = wam + l * AMAX_SLOTS; }
   }
+  g.f16x2 = f16 ? 1 : 0;
   g.M = d->Cs; g.Tout = T; g.B = d->B;
   g.out[0].y = skip; g.out[0].y_bstride = (long)d->Cs * T; g.out[0].rows = d->Cs;
   g.out[0].bias = bsum;
@@ -3569,7 +3628,7 @@ extern "C" int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblock
 extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nblocks,
                                          const float* g_skip, const float* const* z,
                                          float* const* gWs, float* const* gbs, int accumulate,
-                                         void* ws, size_t ws_bytes, vqvae_stream_t s) {
+                                         void* ws, size_t ws_bytes, const uint32_t* g_skip_amax, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_wgrad: 1..%d blocks", MAXSEG);
   VQ_REQUIRE(g_skip && z && gWs && ws, "resstack_skip_wgrad: null pointer");
@@ -3588,10 +3647,12 @@ extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nbloc
     sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
     sg.gw = gWs[l]; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
     wa.gbl[l] = gbs ? gbs[l] : nullptr;
+    sg.amax_x_static = 1.f;                                   // |z| <= 1
   }
   wa.ngbl = gbs ? nblocks : 0;
   wa.accumulate = accumulate;
   wa.x16 = z_bf16(d) ? 1 : 0;
+  if (g_matmul_dtype == 3 && g_skip_amax) { wa.f16x2 = 1; wa.amax_gy = g_skip_amax; }
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 
@@ -3600,7 +3661,8 @@ extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nbloc
 extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblocks,
                                         const float* const* g_res, const float* const* z,
                                         float* const* gWr, float* const* gbr, int accumulate,
-                                        void* ws, size_t ws_bytes, vqvae_stream_t s) {
+                                        void* ws, size_t ws_bytes, const uint32_t* const* g_res_amax,
+                                        vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_res_wgrad: 1..%d blocks", MAXSEG);
   VQ_REQUIRE(g_res && z && gWr && ws, "resstack_res_wgrad: null pointer");
@@ -3617,9 +3679,13 @@ extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblock
     sg.tmul = 1; sg.toff = 0; sg.tdiv = 1;
     sg.gw = gWr[l]; sg.gw_co_stride = Ch; sg.gw_ci_stride = 1;
     sg.gb = gbr ? gbr[l] : nullptr;
+    sg.amax_x_static = 1.f;                                   // |z| <= 1
+    sg.amax_gy = g_res_amax ? g_res_amax[l] : nullptr;
+    if (!sg.amax_gy) g_res_amax = nullptr;                    // one segment without its maximum: the whole launch keeps mode 2's kernel
     cz[n++] = Ch;
   }
   if (n == 0) return 0;
+  if (g_matmul_dtype == 3 && g_res_amax) wa.f16x2 = 1;
   WgradPlan p = plan_wgrad(d->Cr, d->B, T, cz, n);
   if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_res_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cr * T; wa.M = d->Cr; wa.Tout = T; wa.B = d->B;
@@ -3661,7 +3727,8 @@ extern "C" int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x
 extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblocks, const int* dils,
                                         const float* const* x, const float* const* gh,
                                         float* const* gWd, float* const* gbd, int accumulate,
-                                        void* ws, size_t ws_bytes, vqvae_stream_t s) {
+                                        void* ws, size_t ws_bytes, const uint32_t* const* x_amax,
+                                        const uint32_t* const* gh_amax, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks * d->K <= MAXSEG, "resstack_dil_wgrad: nblocks * filter_size must be 1..%d", MAXSEG);
   VQ_REQUIRE(dils && x && gh && gWd && ws, "resstack_dil_wgrad: null pointer");
@@ -3679,9 +3746,13 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
       sg.tmul = 1; sg.toff = -(d->K - 1 - j) * dils[l]; sg.tdiv = 1;
       sg.gw = gWd[l] ? gWd[l] + j : nullptr; sg.gw_co_stride = (long)d->Cr * d->K; sg.gw_ci_stride = d->K;
       sg.gb = (j == 0 && gbd) ? gbd[l] : nullptr;
+      sg.amax_x = x_amax ? x_amax[l] : nullptr;
+      sg.amax_gy = gh_amax ? gh_amax[l] : nullptr;
+      if (!sg.amax_x || !sg.amax_gy) x_amax = gh_amax = nullptr;      // (see resstack_res_wgrad)
       cins[n++] = d->Cr;
     }
   }
+  if (g_matmul_dtype == 3 && x_amax && gh_amax) wa.f16x2 = 1;
   WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, n);
   if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_dil_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;

@@ -876,7 +876,7 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
     hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
-    if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() == 2) {
+    if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() >= 2) {      // modes 2 and 3: the sweep on the bf16 matrix pipe
       int nb = (int)(((long)k * d / 2 + 255) / 256);
       if (nb > 2048) nb = 2048;
       hipLaunchKernelGGL(vq_wsplit_kernel, dim3(nb), dim3(256), 0, st, W, k, d, wsplit);

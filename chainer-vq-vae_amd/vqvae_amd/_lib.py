@@ -37,6 +37,11 @@ class ResblockCproj(C.Structure):
     _fields_ = [('P', P), ('P_bstride', c_long), ('Tl', c_int), ('v0', P), ('w0', P), ('w1', P)]
 
 
+class ResblockAmax(C.Structure):
+    """vqvae_resblock_amax: device uint32 slots (float bit patterns of absolute maxima), matmul mode 3."""
+    _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx')]
+
+
 class ResblockGrads(C.Structure):
     _fields_ = [(n, P) for n in ('gWd', 'gbd', 'gWc', 'gbc', 'gWr', 'gbr', 'gWs', 'gbs')]
 
@@ -88,6 +93,8 @@ PROTOTYPES = {
     'vqvae_set_matmul_dtype': (c_int, [c_int]),
     'vqvae_get_matmul_dtype': (c_int, []),
     'vqvae_set_wgrad_impl': (c_int, [c_int]),
+    'vqvae_absmax': (c_int, [P, c_size_t, P, P]),
+    'vqvae_set_f32x2_min_gflop': (c_int, [c_double]),
     'vqvae_conv1d_workspace_bytes': (c_size_t, [C.POINTER(Conv1dDesc)]),
     'vqvae_conv1d_fwd': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, P]),
     'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),
@@ -103,21 +110,22 @@ PROTOTYPES = {
     'vqvae_resstack_pack': (c_int, [C.POINTER(ResblockDesc), c_int, C.POINTER(ResblockParams),
                                     C.POINTER(c_int), P, c_size_t, P]),
     'vqvae_resblock_fwd_packed': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P,
-                                          C.POINTER(ResblockCproj), P, P, P, P, c_size_t, P, P]),
+                                          C.POINTER(ResblockCproj), P, P, P, P, c_size_t, P,
+                                          C.POINTER(ResblockAmax), P]),
     'vqvae_resblock_bwd_packed': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P,
-                                          P, P, P, P, P, c_size_t, P, P]),
+                                          P, P, P, P, P, c_size_t, P, C.POINTER(ResblockAmax), P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
                                         c_size_t, P]),
     'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
                                          c_size_t, P]),
     'vqvae_resstack_skip_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, P, PP, PP, PP, c_int, P,
-                                          c_size_t, P]),
+                                          c_size_t, P, P]),
     'vqvae_resstack_res_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, PP, c_int, P,
-                                         c_size_t, P]),
+                                         c_size_t, PP, P]),
     'vqvae_resstack_dil_wgrad_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_dil_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, C.POINTER(c_int), PP, PP, PP, PP,
-                                         c_int, P, c_size_t, P]),
+                                         c_int, P, c_size_t, PP, PP, P]),
     'vqvae_vq_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'vqvae_vq_nearest_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P,
                                      c_size_t, P]),
@@ -165,6 +173,7 @@ PROTOTYPES = {
 
 # elementwise op codes / profiler tags (mirror the header)
 MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gemm.hip)
+AMAX_SLOTS = 16                   # uint32 words per absolute maximum (vqvae_absmax, vqvae_resblock_amax)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
     EW_MUL_SCALAR_DEV = range(10)
 PROF_RESBLOCK_GATE, PROF_RESBLOCK_OUT, PROF_RESBLOCK_BWD_GZ, PROF_RESBLOCK_BWD_GX, \

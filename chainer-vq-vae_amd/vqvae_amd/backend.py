@@ -118,7 +118,8 @@ def wait_event(s, event):
     _lib.call('vqvae_stream_wait_event', s, event.h)
 
 
-_MATMUL_CODES = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3': 2, 'fp32x3': 2}
+_MATMUL_CODES = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3': 2, 'fp32x3': 2,
+                 'float32x2': 3, 'fp32x2': 3}
 
 
 def default_matmul_dtype():
@@ -151,6 +152,14 @@ def set_matmul_dtype(name):
         raise ValueError('set_matmul_dtype(%r): expected one of %s' % (name, sorted(_MATMUL_CODES)))
     _state['matmul_explicit'] = True
     _set_matmul_code(_MATMUL_CODES[name])
+
+
+def set_f32x2_min_gflop(gflop):
+    """'float32x2' only: the smallest generic conv launch (in GFLOP) that runs the three-product kernels -- they need
+    one extra pass over the operand for its absolute maximum; default 8 (proj1 / proj2 at the configs), 0 = every
+    launch (how the tests reach those kernels at their small shapes).  ResidualNet's chain is not affected: its
+    maxima travel with the tensors."""
+    _lib.call('vqvae_set_f32x2_min_gflop', float(gflop))
 
 
 def synchronize():

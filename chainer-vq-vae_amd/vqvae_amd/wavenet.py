@@ -147,6 +147,14 @@ class ResidualStackFunction(FunctionNode):
                       P_all.ptr, ws.ptr, ws.nbytes, _S())
             tb = F.resize_tables(Tl, x.shape[2])
         self.packed = None
+        self.amax = None
+        if self.lat is not None and PACK_ONCE and _lib.load().vqvae_get_matmul_dtype() == 3:
+            # matmul mode 3 (float32x2): the absolute maximum of every tensor of the chain travels with it as a
+            # group of _lib.AMAX_SLOTS device uint32 (float bits) -- groups x_l | gh_l | g_res_l | g_skip; the kernels'
+            # epilogues raise the words of what they store (atomicMax), only the tensors that arrive from outside
+            # are scanned
+            self.amax = backend.zeros(((3 * nb + 1) * _lib.AMAX_SLOTS,), np.uint32)
+            _lib.call('vqvae_absmax', x.ptr, x.size, self.amax.ptr, _S())
         if self.lat is not None and PACK_ONCE:
             # every block's weight slabs (forward and backward forms), re-laid once for this step
             d0 = _rb_desc(x, cond, inputs[2], inputs[8], self.dilations[0])
@@ -171,9 +179,13 @@ class ResidualStackFunction(FunctionNode):
                 cp = _lib.ResblockCproj(P_all.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, Tl,
                                         tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
                 if self.packed is not None:
+                    am = None
+                    if self.amax is not None:
+                        am = C.byref(_lib.ResblockAmax(self._slot(i), None if last else self._slot(i + 1),
+                                                       None, None, None, None))
                     _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), h.ptr, C.byref(cp),
                               _p(res), gates.ptr, z.ptr, ws.ptr, ws.nbytes,
-                              self.packed.ptr + i * self.packed_stride, _S())
+                              self.packed.ptr + i * self.packed_stride, am, _S())
                 else:
                     _lib.call('vqvae_resblock_fwd', C.byref(d), C.byref(prm), h.ptr, None, C.byref(cp),
                               _p(res), None, 0, gates.ptr, z.ptr, ws.ptr, ws.nbytes, _S())
@@ -196,6 +208,10 @@ class ResidualStackFunction(FunctionNode):
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
 
+    def _slot(self, i):
+        """Device address of group i of self.amax (x_l: l, gh_l: nb + l, g_res_l: 2 nb + l, g_skip: 3 nb)."""
+        return self.amax.ptr + 4 * _lib.AMAX_SLOTS * i
+
     def backward(self, indexes, gys):
         in_vars = self.get_retained_inputs()
         ins = [v.data for v in in_vars]
@@ -203,6 +219,9 @@ class ResidualStackFunction(FunctionNode):
         lat = self.lat
         g_skip = gys[0].data
         nb = len(self.dilations)
+        f16 = self.amax is not None
+        if f16:
+            _lib.call('vqvae_absmax', g_skip.ptr, g_skip.size, self._slot(3 * nb), _S())
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb
@@ -243,11 +262,14 @@ class ResidualStackFunction(FunctionNode):
             if overlap:
                 backend.wait_event(side, backend.Event().record(_S()))    # their gh are complete
             dils = (C.c_int * len(blocks))(*[self.dilations[i] for i in blocks])
+            xam = (C.c_void_p * len(blocks))(*[self._slot(i) for i in blocks]) if f16 else None
+            gam = (C.c_void_p * len(blocks))(*[self._slot(nb + i) for i in blocks]) if f16 else None
             _lib.call('vqvae_resstack_dil_wgrad', C.byref(d0), len(blocks), dils,
                       _lib.ptr_array([self.saved[i][0] for i in blocks]),
                       _lib.ptr_array([ghs[i] for i in blocks]),
                       _lib.ptr_array([gdil[i][0] for i in blocks]),
-                      _lib.ptr_array([gdil[i][1] for i in blocks]), 0, ws_side.ptr, ws_side.nbytes, side)
+                      _lib.ptr_array([gdil[i][1] for i in blocks]), 0, ws_side.ptr, ws_side.nbytes,
+                      xam, gam, side)
 
         # skip-conv weight gradients need only g_skip and the saved z_l: start them right away
         gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
@@ -260,7 +282,7 @@ class ResidualStackFunction(FunctionNode):
             zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
             _lib.call('vqvae_resstack_skip_wgrad', C.byref(d0), hi - lo, g_skip.ptr, zs,
                       _lib.ptr_array(gWs[lo:hi]), _lib.ptr_array(gbs[lo:hi]), 0, ws_side.ptr,
-                      ws_side.nbytes, side)
+                      ws_side.nbytes, self._slot(3 * nb) if f16 else None, side)
 
         pending = [nb]          # res-conv weight gradients are issued for blocks [lo, pending)
 
@@ -278,8 +300,12 @@ class ResidualStackFunction(FunctionNode):
                 a, b = lo + glo, lo + ghi
                 wsm = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), b - a))
                 zs = _lib.ptr_array([self.saved[i][2] for i in range(a, b)])
+                ram = None
+                if f16:      # g_res_l was published by block l + 1's backward-data launch
+                    ram = (C.c_void_p * (b - a))(*[None if g_ress[i] is None else self._slot(2 * nb + i)
+                                                   for i in range(a, b)])
                 _lib.call('vqvae_resstack_res_wgrad', C.byref(d0), b - a, _lib.ptr_array(g_ress[a:b]), zs,
-                          _lib.ptr_array(gWr[a:b]), _lib.ptr_array(gbr[a:b]), 0, wsm.ptr, wsm.nbytes, _S())
+                          _lib.ptr_array(gWr[a:b]), _lib.ptr_array(gbr[a:b]), 0, wsm.ptr, wsm.nbytes, ram, _S())
             pending[0] = lo
 
         for i in range(nb - 1, -1, -1):
@@ -296,9 +322,14 @@ class ResidualStackFunction(FunctionNode):
             if lat is not None:
                 # chain on the main stream: gz, gate derivative -> gh, then gx
                 if self.packed is not None:
+                    am = None
+                    if f16:      # in: g_res_i, g_skip; out: gh_i and gx = g_res_{i-1}
+                        am = C.byref(_lib.ResblockAmax(
+                            None, None, None if g_res is None else self._slot(2 * nb + i), self._slot(3 * nb),
+                            self._slot(nb + i), self._slot(2 * nb + i - 1) if (gx is not None and i > 0) else None))
                     _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), h.ptr, gates.ptr,
                               z.ptr, _p(g_res), g_skip.ptr, _p(gx), gh.ptr, ws.ptr, ws.nbytes,
-                              self.packed.ptr + i * self.packed_stride, _S())
+                              self.packed.ptr + i * self.packed_stride, am, _S())
                 else:
                     none = _lib.ResblockGrads(*([None] * 8))
                     _lib.call('vqvae_resblock_bwd', C.byref(d), C.byref(prm), h.ptr, None, gates.ptr,
@@ -373,6 +404,7 @@ class ResidualStackFunction(FunctionNode):
             grads[2 + 8 * i + 7] = gbs[i]
         self.saved = None                      # release activations
         self.packed = None
+        self.amax = None
         grads[0] = g_res if 0 in indexes else None
         return tuple(grads)
 

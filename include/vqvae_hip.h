@@ -91,9 +91,27 @@ int vqvae_prof_read(int tag, double* total_ms, int* launches);
  *      0: fp32 operands on v_mfma_f32_32x32x2_f32.
  *      1: operands rounded to bf16 (round-to-nearest-even), v_mfma_f32_32x32x16_bf16, fp32
  *        accumulation -- BASELINE configs[4].
- *      Workspace sizes depend on the mode (packed weight slabs are 1.5x larger in mode 2): query
+ *      3: fp32 products on the fp16 matrix pipe, THREE v_mfma_f32_32x32x16_f16 per product (`float32x2`): both
+ *        operands scaled by a power of two per tensor (taken from the tensor's absolute maximum) and split into
+ *        hi + lo fp16; hi*hi + hi*lo + lo*hi, fp32 accumulate.  hi + lo carries 22 significand bits + a sign --
+ *        one fp32 rounding per operand -- and a 16-deep K step is rounded once instead of eight times, so against
+ *        float64 it is at or below the error of modes 0 and 2 (tests/test_gpu_kernels.py).  The kernels need each
+ *        operand's absolute maximum BEFORE they run: ResidualNet's packed chain hands them from launch to launch
+ *        (vqvae_resblock_amax; producers publish max |y| from their epilogues), the generic conv entry points
+ *        find them with one extra pass over the operand when the launch is large (>= 8 GFLOP) and run mode 2's
+ *        kernels otherwise.  Half of mode 2's matrix-pipe time.
+ *      Workspace sizes depend on the mode (packed weight slabs are 1.5x larger in modes 2 and 3): query
  *      them after setting it.                                                                    */
 int vqvae_set_matmul_dtype(int dtype);
+/* An absolute maximum is VQVAE_AMAX_SLOTS device words: the bit patterns of non-negative floats (unsigned order ==
+ * float order) whose maximum is max |x[i]| -- producers raise one word per workgroup with atomicMax (spreading the
+ * same-address atomics), consumers take the maximum of all.  The form in which matmul mode 3 passes a tensor's
+ * scale from its producer to its consumers.  vqvae_absmax zeroes the words, then scans x.       */
+#define VQVAE_AMAX_SLOTS 16
+int vqvae_absmax(const float* x, size_t n, uint32_t* amax, vqvae_stream_t s);
+/* matmul mode 3: smallest generic conv launch (GFLOP = 2 B Tout Cout Cin K / 1e9) that pays for the extra pass over
+ * its operand and runs the float32x2 kernels; default 8, 0 = every launch (tests).                */
+int vqvae_set_f32x2_min_gflop(double gflop);
 int vqvae_get_matmul_dtype(void);
 /* weight-gradient kernel choice: 0 = automatic (the 16-byte-LDS fp32 kernel where it applies),
  * 1 = always the generic kernel (A/B checks) */
@@ -205,6 +223,17 @@ int vqvae_resblock_bwd(const vqvae_resblock_desc* d, const vqvae_resblock_params
  *        block l's slice starts at packed + l * vqvae_resstack_packed_bytes(d).
  *      The _packed entry points are the latent-rate-condition chain only (cproj given, no per-block
  *      skip output, no per-block condition / parameter gradients: ResidualNet batches those).   */
+/* matmul mode 3 only (NULL / ignored otherwise): where the absolute maxima of the chain's tensors live -- device
+ * groups of VQVAE_AMAX_SLOTS uint32 as written by vqvae_absmax.  Inputs must be final when the launch runs; outputs
+ * are raised with atomicMax by the producing kernel's epilogue and must have been zeroed by the caller.      */
+typedef struct {
+  const uint32_t* x;        /* fwd in : max |x|      (the block's input)                               */
+  uint32_t* res;            /* fwd out: max |res|    (the next block's x); NULL with res == NULL       */
+  const uint32_t* g_res;    /* bwd in : max |g_res|  ; NULL with g_res == NULL                         */
+  const uint32_t* g_skip;   /* bwd in : max |g_skip|                                                  */
+  uint32_t* gh;             /* bwd out: max |gh_out| (also read by the backward-data launch)           */
+  uint32_t* gx;             /* bwd out: max |gx|     (the previous block's g_res); may be NULL         */
+} vqvae_resblock_amax;
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
                         const vqvae_resblock_params* params, const int* has_res, void* packed,
@@ -212,13 +241,14 @@ int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
 int vqvae_resblock_fwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                               const float* x, const vqvae_resblock_cproj* cproj, float* res,
                               float* gates, float* z, void* ws, size_t ws_bytes,
-                              const void* packed, vqvae_stream_t s);
+                              const void* packed, const vqvae_resblock_amax* amax, vqvae_stream_t s);
 /* gz = Wr^T g_res + Ws^T g_skip, gate derivative -> gh_out (B,Cd,T), gx = g_res + conv^T(gh_out);
  * g_res / gx may be NULL as in vqvae_resblock_bwd.                                            */
 int vqvae_resblock_bwd_packed(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
                               const float* x, const float* gates, const float* z,
                               const float* g_res, const float* g_skip, float* gx, float* gh_out,
-                              void* ws, size_t ws_bytes, const void* packed, vqvae_stream_t s);
+                              void* ws, size_t ws_bytes, const void* packed,
+                              const vqvae_resblock_amax* amax, vqvae_stream_t s);
 
 /* Weight gradients of the dilated conv only: gWd (+)= gh x_taps^T, gbd (+)= rowsum(gh), from
  * the gh that vqvae_resblock_bwd wrote to gh_out.  Split out so ResidualNet can run it on a
@@ -241,15 +271,18 @@ int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
 int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* Wc, const float* const* gh, float* gcond,
                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
+/*      The trailing *_amax arguments of the three weight-gradient entries: matmul mode 3's operand maxima
+ *      (device uint32 slots / HOST arrays of such pointers); NULL keeps mode 2's kernels.      */
 int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nblocks, const float* g_skip,
                               const float* const* z, float* const* gWs, float* const* gbs,
-                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
+                              int accumulate, void* ws, size_t ws_bytes, const uint32_t* g_skip_amax,
+                              vqvae_stream_t s);
 /*      res_wgrad : gWr_l (+)= g_res_l z_l^T, gbr_l (+)= rowsum(g_res_l) for every l with
  *      g_res[l] != NULL (the last block has none) -- one launch                      */
 int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* g_res, const float* const* z,
                              float* const* gWr, float* const* gbr, int accumulate, void* ws,
-                             size_t ws_bytes, vqvae_stream_t s);
+                             size_t ws_bytes, const uint32_t* const* g_res_amax, vqvae_stream_t s);
 /* dilated-conv weight / bias gradients of nblocks blocks (nblocks * K <= 24) in one launch: block l
  * contributes K segments (x[l] shifted by -(K-1-j)*dils[l], output gradient gh[l]); gWd[l] (Cd,Cr,K),
  * gbd[l] (Cd) -- NULL entries are skipped.  Workspace from the _workspace_bytes query.            */
@@ -257,6 +290,7 @@ size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_desc* d, in
 int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblocks, const int* dils,
                              const float* const* x, const float* const* gh, float* const* gWd,
                              float* const* gbd, int accumulate, void* ws, size_t ws_bytes,
+                             const uint32_t* const* x_amax, const uint32_t* const* gh_amax,
                              vqvae_stream_t s);
 
 /* ---- vector quantiser: StraightThrough.forward / backward (utils.py:176-231).

@@ -23,10 +23,13 @@ def gpu():
     return backend
 
 
-@pytest.fixture(params=['float32x3', 'float32'])
+@pytest.fixture(params=['float32x2', 'float32x3', 'float32'])
 def matmul_mode(request, gpu):
-    """Both fp32-accurate matmul modes: 'float32x3' (six bf16 MFMA products per fp32 product, the
-    default) and 'float32' (fp32 MFMA); 'bfloat16' has its own tests below."""
+    """The three fp32-accurate matmul modes: 'float32x2' (three fp16 MFMA products per fp32 product of scaled
+    two-piece operands), 'float32x3' (six bf16 MFMA products of an exact three-way split) and 'float32'
+    (fp32 MFMA); 'bfloat16' has its own tests below."""
     gpu.set_matmul_dtype(request.param)
+    gpu.set_f32x2_min_gflop(0.0)        # 'float32x2': the generic convs take the three-product kernels at the tests' small shapes too
     yield request.param
+    gpu.set_f32x2_min_gflop(8.0)
     gpu.set_matmul_dtype(gpu.default_matmul_dtype())

@@ -501,10 +501,11 @@ ACC_CASES = [(2, 32, 256, 32, 4, 2, 1, 1), (2, 96, 300, 80, 2, 1, 8, 8), (2, 40,
 @pytest.mark.parametrize('case', ACC_CASES)
 def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
     """'float32x3' computes every fp32 product as six bf16 MFMA products of an exact three-way split
-    of both operands (csrc/conv_gemm.hip, matmul mode 2).  It is an fp32 mode, not a reduced-precision
-    one: against a float64 evaluation, forward, backward-data and backward-weight are (1) within
-    2e-6 of the result's scale and (2) no further away than the fp32 MFMA path ('float32') is, up to
-    25 % + 1e-7 of slack for the different summation order."""
+    of both operands (csrc/conv_gemm.hip, matmul mode 2), 'float32x2' as three fp16 MFMA products of a
+    two-piece split of operands scaled by a power of two per tensor (mode 3).  Both are fp32 modes, not
+    reduced-precision ones: against a float64 evaluation, forward, backward-data and backward-weight are
+    (1) within 2e-6 of the result's scale and (2) no further away than the fp32 MFMA path ('float32') is,
+    up to 25 % + 1e-7 of slack for the different summation order."""
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     B, Cin, Tin, Cout, K, stride, pad, dil = case
@@ -517,7 +518,8 @@ def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
     gx64, gW64 = _bwd64(x, W, gy, stride, pad, dil)
     err = {}
     try:
-        for mode in ('float32', 'float32x3'):
+        gpu.set_f32x2_min_gflop(0.0)        # every launch of 'float32x2' on its own kernels
+        for mode in ('float32', 'float32x3', 'float32x2'):
             gpu.set_matmul_dtype(mode)
             vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
             y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil)
@@ -528,19 +530,22 @@ def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
             ew = np.abs(vW.grad.get()[..., 0] - gW64).max() / np.abs(gW64).max()
             err[mode] = (ey, ex, ew)
     finally:
+        gpu.set_f32x2_min_gflop(8.0)
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
-    for name, e3, e1 in zip(('y', 'gx', 'gW'), err['float32x3'], err['float32']):
-        assert e3 <= 2e-6, '%s: float32x3 is %.3e of scale from float64' % (name, e3)
-        assert e3 <= 1.25 * e1 + 1e-7, '%s: float32x3 %.3e vs fp32 MFMA %.3e (of scale, against float64)' % (name, e3, e1)
+    for mode in ('float32x3', 'float32x2'):
+        for name, e3, e1 in zip(('y', 'gx', 'gW'), err[mode], err['float32']):
+            assert e3 <= 2e-6, '%s: %s is %.3e of scale from float64' % (name, mode, e3)
+            assert e3 <= 1.25 * e1 + 1e-7, '%s: %s %.3e vs fp32 MFMA %.3e (of scale, against float64)' % (name, mode, e3, e1)
 
 
-
+@pytest.mark.parametrize('mode', ['float32x3', 'float32x2'])
 @pytest.mark.parametrize('scale', [1e-15, 1.0, 1e15])
-def test_float32x3_is_scale_invariant(gpu, scale):
+def test_float32x3_is_scale_invariant(gpu, scale, mode):
     """The three-way split works on significands: scaling the operands by 2^k-ish factors (here
     1e-15 .. 1e15, far inside the bf16 = fp32 exponent range) leaves the relative error against
     float64 where it was.  (Operands below ~2^-110 would lose their low pieces to the denormal
-    range -- gradually, like any fp32 arithmetic near underflow.)"""
+    range -- gradually, like any fp32 arithmetic near underflow.)  'float32x2' scales every operand by a
+    power of two taken from its own absolute maximum before it splits it, with the same effect."""
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     B, Cin, Tin, Cout, K, stride, pad, dil = 2, 96, 300, 80, 2, 1, 8, 8
@@ -549,12 +554,14 @@ def test_float32x3_is_scale_invariant(gpu, scale):
     W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K) / scale ** 0.5).astype(np.float32)
     b = np.zeros(Cout, np.float32)
     y64 = _conv64(x, W, b, stride, pad, dil)
-    gpu.set_matmul_dtype('float32x3')
+    gpu.set_matmul_dtype(mode)
+    gpu.set_f32x2_min_gflop(0.0)
     try:
         y = F.convolution_1d(Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b)),
                              stride=stride, pad=pad, dilate=dil)
         err = np.abs(y.data.get()[..., 0].astype(np.float64) - y64).max() / np.abs(y64).max()
     finally:
+        gpu.set_f32x2_min_gflop(8.0)
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
     assert err <= 1e-6, 'scale %g: %.3e of scale from float64' % (scale, err)
 
@@ -645,7 +652,7 @@ def test_resstack_workspace_queries_cover_every_group_size(gpu):
         gb = [DeviceArray((Cr,), np.float32) for _ in range(n)]
         _lib.call('vqvae_resstack_res_wgrad', C.byref(d), n, _lib.ptr_array([g[i % 2] for i in range(n)]),
                   _lib.ptr_array([z[i % 2] for i in range(n)]), _lib.ptr_array(gW), _lib.ptr_array(gb), 0,
-                  ws.ptr, ws.nbytes, gpu.stream())
+                  ws.ptr, ws.nbytes, None, gpu.stream())
         for i in (0, n - 1):
             want = np.einsum('bot,bit->oi', gh[i % 2].astype(np.float64), zh[i % 2].astype(np.float64))
             assert_close_scaled(gW[i].get(), want, 1e-4, 'res wgrad, group of %d, block %d' % (n, i))
@@ -661,7 +668,7 @@ def test_resstack_workspace_queries_cover_every_group_size(gpu):
         gb = [DeviceArray((Cd,), np.float32) for _ in range(n)]
         _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), n, dils, _lib.ptr_array([x] * n),
                   _lib.ptr_array([ghd] * n), _lib.ptr_array(gW), _lib.ptr_array(gb), 0, ws2.ptr,
-                  ws2.nbytes, gpu.stream())
+                  ws2.nbytes, None, None, gpu.stream())
         i = n - 1
         dil = 2 ** i
         xs = np.zeros_like(xh); xs[:, :, dil:] = xh[:, :, :-dil]              # tap 0 sees x[t - dil]
