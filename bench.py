@@ -47,16 +47,21 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chi
 # residual 1x1 conv is a separate launch the extra term is 0.
 ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
                    '+ latent-rate condition lerp + tanh*sigmoid gate)')
-ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU> '
+ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 3> '
                       '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
                       'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
                       '+ latent-rate condition lerp + tanh*sigmoid gate)')
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense
-# what the whole chip's matrix pipe sustains on the six-product stream with REAL operands (N(0,1) values split into
-# three bf16 pieces; registers only, no LDS / memory): tools/ubench/mfma_power.hip, profiles/r3/ubench_mfma_power.txt
-# (zeros: 2 130-2 180; the power limit).  Reported beside the nominal peak, never instead of it.
-SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA = 1670.0
-X3_PRODUCTS = 6                     # bf16 MFMA products per fp32 product in matmul mode 'float32x3'
+ROOFLINE_KERNEL_X2 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 2> '
+                      '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
+                      'every fp32 product = 3 fp16 MFMA products of a scaled hi + lo operand split, fp32 accumulate '
+                      '+ latent-rate condition lerp + tanh*sigmoid gate)')
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (bf16 and fp16 run at the same rate)
+# what the whole chip's matrix pipe sustains on the product stream alone with REAL operands (N(0,1) values split into
+# their pieces; registers only, no LDS / memory): tools/ubench/mfma_power.hip (six bf16 products, profiles/r3/
+# ubench_mfma_power.txt) and tools/ubench/f16x2_probe.hip (three fp16 products, profiles/r4/ubench_f16x2_probe.txt);
+# zeros: 2 130-2 180 / 1 830: the power limit.  Reported beside the nominal peak, never instead of it.
+SUSTAINED_MFMA_TFLOPS_REAL_DATA = {'float32x3': 1670.0, 'float32x2': 1577.0}
+PRODUCTS_PER_FP32 = {'float32x3': 6, 'float32x2': 3}     # 16-bit MFMA products per algorithmic fp32 product
 
 
 def FUSED_RES_FLOP_PER_POS(cfg):
@@ -197,6 +202,13 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def GATE_BYTES(cfg, B):
+    """Algorithmic HBM bytes of one gate launch: 4 * (N Cr + N 1.5 Cd + K Cr Cd + B Cd T')."""
+    N = B * cfg['length']
+    return 4.0 * (N * cfg['residual'] + N * 1.5 * cfg['dilated'] + cfg['filter_size'] * cfg['residual'] * cfg['dilated']
+                  + B * cfg['dilated'] * (cfg['length'] // 64))
+
+
 def measured_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
     (profiles/roofline_traffic.json, written by tools/pmc_traffic.py from the counter CSVs of
@@ -330,7 +342,8 @@ def run_c4(args, rank, n, local):
     seen = comm.ranks_seen()
     if rank == 0:
         mode = backend.default_matmul_dtype() if not getattr(args, 'matmul', None) else args.matmul
-        x3 = mode == 'float32x3'
+        x3 = mode in ('float32x3', 'float32x2')          # (mode 3 runs the VQ sweep on mode 2's six-product kernel)
+        X3_PRODUCTS = 6
         peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS
         flop = 2.0 * N * k * d                              # expansion form, re-check not counted
         byts = 4.0 * (N * d + k * d + N + N * d)            # z read, codebook once, idx write, e write
@@ -396,7 +409,7 @@ def main():
     ap.add_argument('--bf16', action='store_true',
                     help='bf16 MFMA operands with fp32 accumulation (configs[4] precision)')
     ap.add_argument('--matmul', choices=['float32x2', 'float32x3', 'float32'], default=None,
-                    help="fp32 matmul mode: 'float32x3' (default; fp32 products as six bf16 MFMA products of an "
+                    help="fp32 matmul mode: 'float32x2' (default; fp32 products as three fp16 MFMA products of scaled two-piece operands), 'float32x3' (fp32 products as six bf16 MFMA products of an "
                          "exact three-way operand split) or 'float32' (v_mfma_f32_32x32x2_f32)")
     ap.add_argument('--index-input', action='store_true',
                     help='feed x_dec as mu-law bin indices produced on the device (device-side input '
@@ -512,7 +525,7 @@ def main():
     losses = [float(l.data.get()) for l in upd.last_losses]
     seen = comm.ranks_seen()
     ref_ms = None
-    if n == 1 and mode == 'float32x3' and not args.no_cpu_baseline:
+    if n == 1 and mode in PRODUCTS_PER_FP32 and not args.no_cpu_baseline:
         # the same step with the fp32 MFMA kernels, for reference (not part of the timed region above)
         backend.set_matmul_dtype('float32')
         for _ in range(2):
@@ -536,13 +549,14 @@ def main():
         # contraction (computed once at the latent rate and lerped in the epilogue)
         flop_conv = 2.0 * B * T * cfg['dilated'] * cfg['filter_size'] * cfg['residual']
         flop = flop_conv + FUSED_RES_FLOP_PER_POS(cfg) * B * T
-        x3 = mode == 'float32x3'
-        # the pipe that bounds the kernel: fp32 MFMA; the bf16 MFMA pipe ('bfloat16'); or the bf16 pipe
-        # doing X3_PRODUCTS products per algorithmic fp32 product ('float32x3')
+        x3 = mode in PRODUCTS_PER_FP32
+        X3_PRODUCTS = PRODUCTS_PER_FP32.get(mode, 1)
+        # the pipe that bounds the kernel: fp32 MFMA; the 16-bit MFMA pipe ('bfloat16'); or that pipe doing
+        # X3_PRODUCTS products per algorithmic fp32 product ('float32x3': 6 bf16, 'float32x2': 3 fp16)
         peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else (PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS)
         avg_ms = tot.value / max(cnt.value, 1)
         ach = flop / (avg_ms * 1e-3) / 1e12 if cnt.value else None
-        key = ('c2' if args.workload == 'c2' else 'c5') + ('_bf16' if args.bf16 else ('' if x3 else '_fp32mfma')) + '_B%d' % B
+        key = ('c2' if args.workload == 'c2' else 'c5') + ('_bf16' if args.bf16 else {'float32x2': '', 'float32x3': '_x3', 'float32': '_fp32mfma'}[mode]) + '_B%d' % B
         traffic, tsrc = measured_traffic(key)
         out = {
             'metric': 'audio samples/sec, VQ-VAE fwd+bwd+Adam step, 16 kHz mu-law (whole job)',
@@ -562,8 +576,9 @@ def main():
                         'slowest rank to arrive); rank_ms = each rank\'s own wall time per step before the closing barrier',
                 'cpu_affinity_rank0': affinity},
             'dtype': ('bf16 operands, f32 accumulate' if args.bf16 else
-                      ('f32 (fp32 tensors; each fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate)'
-                       if mode == 'float32x3' else 'f32')),
+                      {'float32x3': 'f32 (fp32 tensors; each fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate)',
+                       'float32x2': 'f32 (fp32 tensors; each fp32 product = 3 fp16 MFMA products of a power-of-two-scaled hi + lo operand split, fp32 accumulate)',
+                       'float32': 'f32'}[mode]),
             'matmul': {'bfloat16': 'operands rounded to bf16 (RNE), v_mfma_f32_32x32x16_bf16, fp32 accumulate',
                        'float32': 'v_mfma_f32_32x32x2_f32',
                        'float32x3': 'fp32 operands, fp32 results: each operand split EXACTLY into three bf16 '
@@ -586,18 +601,24 @@ def main():
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
             'trainable_params': int(n_params),
             'losses_last_step': losses,
-            'roofline': {'bound': 'mfma', 'kernel': ROOFLINE_KERNEL_X3 if x3 else ROOFLINE_KERNEL,
+            'roofline': {'bound': 'mfma', 'kernel': {'float32x3': ROOFLINE_KERNEL_X3, 'float32x2': ROOFLINE_KERNEL_X2}.get(mode, ROOFLINE_KERNEL),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                          'peak_is': ('dense bf16 MFMA peak' if args.bf16 else
-                                     ('dense bf16 MFMA peak / %d bf16 products per fp32 product; achieved counts '
+                                     ('dense 16-bit MFMA peak (2500) / %d MFMA products per fp32 product; achieved counts '
                                       'algorithmic fp32 FLOPs' % X3_PRODUCTS if x3 else 'fp32 MFMA peak')),
                          'frac': (ach / peak) if ach else None,
                          'achieved_vs_fp32_mfma_peak': (ach / PEAK_FP32_MFMA_TFLOPS) if (ach and not args.bf16) else None,
-                         'achieved_vs_measured_sustained_mfma': ((ach * X3_PRODUCTS / SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA)
-                                                                 if (ach and x3) else None),
-                         'sustained_is': ('%.0f TFLOP/s bf16: the six-product MFMA stream alone on real operands, whole chip '
-                                          '(tools/ubench/mfma_power.hip; %.0f nominal)'
-                                          % (SUSTAINED_BF16_MFMA_TFLOPS_REAL_DATA, PEAK_BF16_MFMA_TFLOPS)) if x3 else None,
+                         'achieved_vs_measured_sustained_mfma': ((ach * X3_PRODUCTS / SUSTAINED_MFMA_TFLOPS_REAL_DATA[mode])
+                                                                 if (ach and x3 and not args.bf16) else None),
+                         'sustained_is': ('%.0f TFLOP/s: the %d-product MFMA stream alone on real operands, whole chip '
+                                          '(tools/ubench/mfma_power.hip, f16x2_probe.hip; %.0f nominal)'
+                                          % (SUSTAINED_MFMA_TFLOPS_REAL_DATA[mode], X3_PRODUCTS, PEAK_BF16_MFMA_TFLOPS))
+                                         if (x3 and not args.bf16) else None,
+                         'hbm': {'achieved_algorithmic': (GATE_BYTES(cfg, B) / (avg_ms * 1e-3) / 1e9) if cnt.value else None,
+                                 'peak': 8000.0, 'unit': 'GB/s',
+                                 'frac': (GATE_BYTES(cfg, B) / (avg_ms * 1e-3) / 1e9 / 8000.0) if cnt.value else None,
+                                 'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B),
+                                 'note': 'x read once, gates + z written once, weights, latent-rate condition slice (DESIGN.md section 3)'},
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},

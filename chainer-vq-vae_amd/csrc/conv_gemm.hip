@@ -2318,24 +2318,60 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
   const int nsteps = g1 - g0;
   if constexpr (LEANW) {
     // one register set, fetched ONE step ahead: with two workgroups on the CU the other one's MFMAs cover the
-    // wait a late load costs this one, and the second set's 15 registers are what kept the loop above 128
+    // wait a late load costs this one, and the second set's 15 registers are what kept the loop above 128.
+    // Interior steps -- the shifted 16-t window inside the row, no ragged tail: all but the first dil / 16 steps of a
+    // row -- take their own fetch / stage code behind a wave-uniform branch (the single set is waited for with
+    // vmcnt(0) anyway, so a branch around its loads costs nothing): no validity selects, no re-alignment, the row
+    // bases carried in two scalars.  With both kinds in one macro hipcc turned the edge path's arithmetic into
+    // selects that every step paid: 130 VALU + 100 SALU per step beside 12 MFMAs (round 4: the MFMAs halved and this
+    // became the loop).  Whole pairs in the loop, an odd last step behind it (single exit, see conv_gemm_x3_kernel).
     if (nsteps > 0) {
-      W3_FETCH(pra, prb, pvm, pbs, pbt);
-      W3_STAGE(pra, prb, pvm, pbs, pbt, 0, true);
+      unsigned base_a = 4u * (unsigned)((long)b * a.gy_bstride), base_b = XSZ * (unsigned)((long)b * sg.x_bstride);
+      const unsigned adv_a = 4u * (unsigned)a.gy_bstride, adv_b = XSZ * (unsigned)sg.x_bstride;
+      const int s_toff = sg.toff, s_tin = sg.Tin;
+      auto adv = [&]() {
+        tb += W2K;
+        if (tb >= spb * W2K) { tb = 0; ++b; base_a += adv_a; base_b += adv_b; }
+      };
+      bool pfast = false;
+#define W3L_FETCH()                                                                            \
+      pfast = !ragged && tb + s_toff >= 0 && tb + W2K + s_toff <= s_tin;     /* wave-uniform */ \
+      if (pfast) {                                                                             \
+        const unsigned soa = base_a + 4u * (unsigned)tb, sob = base_b + XSZ * (unsigned)(tb + s_toff); \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                         \
+          pra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[i], soa, W3_LD_AUX)); \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
+          prb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbx, vobk[i], sob, W3_LD_AUX)); \
+      } else W3_FETCH(pra, prb, pvm, pbs, pbt)
+#define W3L_STAGE(STAGE, REAL)                                                                 \
+      if (pfast) {                                                                             \
+        const bool real_ = (REAL);                                                             \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                       \
+          const float4 v = pra[i];                                                             \
+          put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v, ka);                      \
+          if (do_bias && real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                          \
+        }                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
+          put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, prb[i], kb);                 \
+      } else W3_STAGE(pra, prb, pvm, pbs, pbt, STAGE, REAL)
+      W3L_FETCH();
+      W3L_STAGE(0, true);
       __syncthreads();
-      for (int i = 0; i < nsteps; i += 2) {
-        if (i + 1 < nsteps) advance();
-        W3_FETCH(pra, prb, pvm, pbs, pbt);                  // step i + 1 (past the end: re-reads the last step, unused)
+      for (int i = 0; i + 1 < nsteps; i += 2) {
+        adv();
+        W3L_FETCH();                                        // step i + 1
         mma(I0{});
-        W3_STAGE(pra, prb, pvm, pbs, pbt, 1, i + 1 < nsteps);
+        W3L_STAGE(1, true);
         __syncthreads();
-        if (i + 1 >= nsteps) break;
-        if (i + 2 < nsteps) advance();
-        W3_FETCH(pra, prb, pvm, pbs, pbt);                  // step i + 2
+        if (i + 2 < nsteps) adv();
+        W3L_FETCH();                                        // step i + 2 (past the end: re-reads the last step, unused)
         mma(I1{});
-        W3_STAGE(pra, prb, pvm, pbs, pbt, 0, i + 2 < nsteps);
+        W3L_STAGE(0, i + 2 < nsteps);
         __syncthreads();
       }
+      if (nsteps & 1) mma(I0{});
+#undef W3L_FETCH
+#undef W3L_STAGE
     }
   } else
   if (nsteps > 0) {
@@ -2819,7 +2855,9 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   ProfScope ps(tag, st);
   static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
   const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
-  if (fast && mode == 3 && w.M % 256 == 0) {
+  if (fast && mode == 3 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
+    hipLaunchKernelGGL((wgrad3_kernel<4, 2, 2>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
+  } else if (fast && mode == 3 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && mode == 3) {
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 2>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);

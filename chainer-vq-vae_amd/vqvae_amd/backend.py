@@ -123,9 +123,10 @@ _MATMUL_CODES = {'float32': 0, 'fp32': 0, 'bfloat16': 1, 'bf16': 1, 'float32x3':
 
 
 def default_matmul_dtype():
-    """The matmul mode a process starts in: $VQVAE_MATMUL if set, else 'float32x3' (fp32 products
-    on the bf16 matrix pipe; as accurate as 'float32', the fp32 MFMA path, and 1.4x faster)."""
-    name = os.environ.get('VQVAE_MATMUL', 'float32x3')
+    """The matmul mode a process starts in: $VQVAE_MATMUL if set, else 'float32x2' (fp32 products as three
+    fp16 MFMA products; as accurate as 'float32', the fp32 MFMA path, and 1.85x faster; 'float32x3', six bf16
+    products of an exact split, was the default until round 4)."""
+    name = os.environ.get('VQVAE_MATMUL', 'float32x2')
     if name not in _MATMUL_CODES:
         raise ValueError('VQVAE_MATMUL=%r: expected one of %s' % (name, sorted(_MATMUL_CODES)))
     return name
@@ -136,9 +137,12 @@ def _set_matmul_code(code):
 
 
 def set_matmul_dtype(name):
-    """'float32' (fp32 MFMA), 'bfloat16' (operands rounded to bf16, fp32 accumulate) or
+    """'float32' (fp32 MFMA), 'bfloat16' (operands rounded to bf16, fp32 accumulate),
     'float32x3' (fp32 products as six bf16 MFMA products of an exact three-way operand split:
-    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2").
+    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2") or
+    'float32x2' (the default: three fp16 MFMA products of a two-piece split of operands scaled by a power of
+    two per tensor -- "matmul mode 3": fp32 accuracy at 0.19 of the fp32 MFMA time; the tensors' absolute maxima
+    travel with them through ResidualNet's chain, other large convs scan their operand once).
     An explicit choice survives a later backend.init(); workspace sizes depend on the mode, so
     choose it before building workspaces.
 
