@@ -411,9 +411,12 @@ def main():
     ap.add_argument('--matmul', choices=['float32x2', 'float32x3', 'float32'], default=None,
                     help="fp32 matmul mode: 'float32x2' (default; fp32 products as three fp16 MFMA products of scaled two-piece operands), 'float32x3' (fp32 products as six bf16 MFMA products of an "
                          "exact three-way operand split) or 'float32' (v_mfma_f32_32x32x2_f32)")
-    ap.add_argument('--index-input', action='store_true',
-                    help='feed x_dec as mu-law bin indices produced on the device (device-side input '
-                         'pipeline) instead of the reference\'s one-hot float tensor')
+    ap.add_argument('--index-input', action='store_true', help='(the default since round 4; kept for the scripts)')
+    ap.add_argument('--onehot-input', action='store_true',
+                    help="feed x_dec as the reference's resident fp32 one-hot (utils.py:85-87) instead of device-computed "
+                         "bin indices")
+    ap.add_argument('--no-fresh-input', action='store_true',
+                    help='skip the second timed region (ms_per_step_with_input: a fresh host minibatch every step)')
     ap.add_argument('--no-overlap', action='store_true',
                     help='single stream (the default since the float32x3 kernels; kept for the profile scripts)')
     ap.add_argument('--overlap', action='store_true',
@@ -471,13 +474,18 @@ def main():
     opt.setup(model)
 
     B = cfg['batch_per_gpu']
-    shards = []
+    # The feed.  Default: the device-side input pipeline's form (raw crops -> bin INDICES on the device);
+    # --onehot-input: the reference's call surface (a 125.8 MB fp32 one-hot x_dec, utils.py:85-87), which the device
+    # scans back into indices every step.  The mixture-of-logistics workload feeds raw samples either way.
+    index_input = (not args.onehot_input) and not cfg.get('use_logistic', False)
+    shards, host_batches = [], []
     for s in range(2):                      # two distinct resident minibatches, alternated
         ex = synth_examples(B, cfg, seed=71 + 1000 * rank + s)
-        if args.index_input:
+        raw = np.stack([e[0][0, :, 0] for e in ex])
+        host_batches.append((raw, np.array([e[2] for e in ex], np.int32)))
+        if index_input:
             from vqvae_amd.inputs import DeviceInputPipeline
-            raw = np.stack([e[0][0, :, 0] for e in ex])
-            shards.append(DeviceInputPipeline(cfg['quantize'])(raw, np.array([e[2] for e in ex])))
+            shards.append(DeviceInputPipeline(cfg['quantize'])(raw, host_batches[-1][1]))
         else:
             shards.append(V.concat_examples(ex, device=local))
     it = ResidentIterator(shards)
@@ -524,6 +532,32 @@ def main():
     _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
     losses = [float(l.data.get()) for l in upd.last_losses]
     seen = comm.ranks_seen()
+    # The same job with the input leg INSIDE the step (updaters.py:8): every step consumes a minibatch that was in host
+    # memory when the previous step started -- page-locked double buffer, copy stream, binning on the device
+    # (inputs.StreamingInputIterator).  Timed like the main region, reported beside it, never as `value`.
+    fresh_ms = None
+    if index_input and not args.no_fresh_input:
+        from vqvae_amd.inputs import StreamingInputIterator
+        for s in range(2, 8):               # eight distinct host minibatches, cycled
+            ex = synth_examples(B, cfg, seed=71 + 1000 * rank + s)
+            host_batches.append((np.stack([e[0][0, :, 0] for e in ex]), np.array([e[2] for e in ex], np.int32)))
+        cyc = [0]
+
+        def source():
+            cyc[0] += 1
+            return host_batches[cyc[0] % len(host_batches)]
+        upd._iterators['main'] = StreamingInputIterator(source, B, cfg['length'], cfg['quantize'])
+        for _ in range(2):
+            upd.update()
+        comm.barrier()
+        backend.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            upd.update()
+        backend.synchronize()
+        comm.barrier()
+        fresh_ms = 1e3 * comm.max_scalar(time.perf_counter() - t1) / args.steps
+        upd._iterators['main'] = it
     ref_ms = None
     if n == 1 and mode in PRODUCTS_PER_FP32 and not args.no_cpu_baseline:
         # the same step with the fp32 MFMA kernels, for reference (not part of the timed region above)
@@ -564,6 +598,11 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'ms_per_step_with_input': fresh_ms,
+            'with_input_is': (None if fresh_ms is None else
+                              'the same %d steps with the input leg inside the step: each minibatch starts in host memory '
+                              '(8 distinct host minibatches, cycled), page-locked double buffer -> copy stream -> mu-law '
+                              'binning on the device (0.5 MB of waveform per step instead of the 125.8 MB one-hot)' % args.steps),
             'comm_ms_per_step': comm_ms_step_max if timed_comm else None,
             'multi_rank_diagnostics': None if not timed_comm else {
                 'allreduce_ms_per_step_max_over_ranks': comm_ms_step_max,
@@ -589,7 +628,8 @@ def main():
                        'float32x2': 'fp32 operands, fp32 results: each operand scaled by a power of two per tensor and split '
                                     'into two fp16 (hi + lo), three products on v_mfma_f32_32x32x16_f16 with fp32 accumulate; '
                                     'error against float64 at or below the fp32 MFMA path\'s (same test)'}[mode],
-            'data': 'synthetic' + (' (x_dec as device-computed bin indices)' if args.index_input else ''),
+            'data': 'synthetic' + (' (x_dec as device-computed mu-law bin indices)' if index_input else
+                                   (' (x_dec as the reference\'s fp32 one-hot)' if not cfg.get('use_logistic', False) else '')),
             'samples_per_sec_per_gpu': value / n,
             'config': {'workload': ('BASELINE configs[%d]: batch %d/GPU, length 7680, mu-law q=256, '
                                     'd=64 k=512, n_loop=2 n_layer=10, residual=dilated=skip=256, '

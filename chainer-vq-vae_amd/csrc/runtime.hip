@@ -104,6 +104,19 @@ int vqvae_memcpy_h2d(void* dst, const void* src, size_t bytes, vqvae_stream_t s)
   VQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)s));   // pageable host memory: keep it simple & safe
   return 0;
 }
+// Page-locked host memory + a copy that only ENQUEUES: the input leg of a training step (updaters.py:8: the
+// converter's host -> device copy) on a copy stream, overlapped with the previous step's kernels.
+int vqvae_host_alloc(void** p, size_t bytes) {
+  VQ_REQUIRE(p, "vqvae_host_alloc: null");
+  VQ_CHECK_HIP(hipHostMalloc(p, bytes ? bytes : 4, hipHostMallocDefault));
+  return 0;
+}
+int vqvae_host_free(void* p) { if (p) VQ_CHECK_HIP(hipHostFree(p)); return 0; }
+int vqvae_memcpy_h2d_async(void* dst, const void* pinned_src, size_t bytes, vqvae_stream_t s) {
+  if (!bytes) return 0;
+  VQ_CHECK_HIP(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+  return 0;
+}
 int vqvae_memcpy_d2h(void* dst, const void* src, size_t bytes, vqvae_stream_t s) {
   if (!bytes) return 0;
   VQ_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -113,6 +126,11 @@ int vqvae_memcpy_d2h(void* dst, const void* src, size_t bytes, vqvae_stream_t s)
 int vqvae_memcpy_d2d(void* dst, const void* src, size_t bytes, vqvae_stream_t s) {
   if (!bytes) return 0;
   VQ_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return 0;
+}
+int vqvae_memcpy2d_d2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, vqvae_stream_t s) {
+  if (!width || !height) return 0;
+  VQ_CHECK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)s));
   return 0;
 }
 int vqvae_memset(void* p, int v, size_t bytes, vqvae_stream_t s) {

@@ -75,7 +75,11 @@ PROTOTYPES = {
     'vqvae_free': (c_int, [P]),
     'vqvae_memcpy_h2d': (c_int, [P, c_void_p, c_size_t, P]),
     'vqvae_memcpy_d2h': (c_int, [c_void_p, P, c_size_t, P]),
+    'vqvae_host_alloc': (c_int, [C.POINTER(c_void_p), c_size_t]),
+    'vqvae_host_free': (c_int, [c_void_p]),
+    'vqvae_memcpy_h2d_async': (c_int, [P, c_void_p, c_size_t, P]),
     'vqvae_memcpy_d2d': (c_int, [P, P, c_size_t, P]),
+    'vqvae_memcpy2d_d2d': (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     'vqvae_memset': (c_int, [P, c_int, c_size_t, P]),
     'vqvae_stream_create': (c_int, [C.POINTER(c_void_p)]),
     'vqvae_stream_destroy': (c_int, [P]),

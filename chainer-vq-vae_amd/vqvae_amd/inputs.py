@@ -110,3 +110,101 @@ class DeviceInputPipeline(object):
         t = self.bins_device(backend.to_device(raw[:, 1:])).reshape(B, L1 - 1, 1)   # quantized[1:]
         spk = backend.to_device(np.asarray(speaker, np.int32))
         return x_enc, x_dec, spk, t
+
+
+class _Pinned(object):
+    """A page-locked host buffer viewed as a NumPy array (source of asynchronous host -> device copies)."""
+
+    def __init__(self, shape, dtype):
+        import ctypes as C
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.call('vqvae_host_alloc', C.byref(p), self.nbytes)
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=self.dtype).reshape(self.shape)
+
+    def __del__(self):
+        try:
+            _lib.load().vqvae_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+class StreamingInputIterator(object):
+    """The input leg of a real training step (updaters.py:8, 37-38; utils.py:85-110): every ``next()`` hands the
+    updater a minibatch that was in HOST memory when the previous step started.
+
+    ``source()`` returns ``(raw, speaker)`` -- float32 (B, L+1) peak-normalised crops and int (B,) speaker ids, i.e.
+    Preprocess's output before the mu-law transform.  The crops (0.5 MB at B = 16 instead of the 125.8 MB one-hot)
+    are copied into one of two page-locked buffers and sent to the device on a copy stream while the previous step's
+    kernels run; the main stream waits for the copy's event, bins the waveform on the device (bit-exact with
+    utils.py:18-23) and the step consumes x_enc / bin indices / targets exactly as from DeviceInputPipeline.
+    Double buffering: set k's host and device buffers are reused two calls later -- the main stream's work on them
+    (binning, encoder, loss) has been enqueued by then, and the copy that overwrites them is ordered behind it by an
+    event recorded at hand-over."""
+
+    yields_rank_shard = True
+
+    class _Set(object):
+        pass
+
+    def __init__(self, source, batch, length, quantize=256):
+        self.source, self.B, self.L1 = source, int(batch), int(length) + 1
+        self.pipe = DeviceInputPipeline(quantize)
+        self.copy_stream = backend.pool_stream(7)
+        self.sets = []
+        for _ in range(2):
+            s = self._Set()
+            s.h_raw = _Pinned((self.B, self.L1), np.float32)
+            s.h_spk = _Pinned((self.B,), np.int32)
+            s.d_raw = DeviceArray((self.B, 1, self.L1, 1), np.float32)
+            s.d_spk = DeviceArray((self.B,), np.int32)
+            s.ready = backend.Event()         # the copy has landed
+            s.free = None                     # the main stream's readers of d_raw / d_spk are all enqueued (and this marks their end)
+            s.submitted = False
+            self.sets.append(s)
+        self.i = 0
+        self._submit(self.sets[0])
+
+    def _submit(self, s):
+        """Host side of one hand-over: fill set ``s``'s page-locked buffers, enqueue its copies on the copy stream."""
+        if s.submitted:
+            _lib.call('vqvae_event_synchronize', s.ready.h)      # the last copy FROM these host buffers has completed
+        raw, spk = self.source()
+        np.copyto(s.h_raw.array, np.asarray(raw, np.float32).reshape(self.B, self.L1))
+        np.copyto(s.h_spk.array, np.asarray(spk, np.int32).reshape(self.B))
+        if s.free is not None:
+            backend.wait_event(self.copy_stream, s.free)         # ... and everything that read the device buffers
+        _lib.call('vqvae_memcpy_h2d_async', s.d_raw.ptr, s.h_raw.ptr, s.h_raw.nbytes, self.copy_stream)
+        _lib.call('vqvae_memcpy_h2d_async', s.d_spk.ptr, s.h_spk.ptr, s.h_spk.nbytes, self.copy_stream)
+        s.ready.record(self.copy_stream)
+        s.submitted = True
+
+    def next(self):
+        cur = self.sets[self.i & 1]
+        self.i += 1
+        main = backend.stream()
+        backend.wait_event(main, cur.ready)
+        B, L1 = self.B, self.L1
+        # bins of the whole crop in one launch; quantized[:-1] -> decoder input (indices), quantized[1:] -> targets
+        q_all = self.pipe.bins_device(cur.d_raw.reshape(B, L1))
+        x_dec = IndexInput((B, L1 - 1), self.pipe.quantize)
+        t = DeviceArray((B, L1 - 1, 1), np.int32)
+        _shift_rows(q_all, x_dec, 0)
+        _shift_rows(q_all, t, 1)
+        x_enc, spk = cur.d_raw.copy(), cur.d_spk.copy()          # (the step's Variables may outlive the set's turn)
+        cur.free = backend.Event().record(main)                  # every reader of cur's device buffers is enqueued
+        self._submit(self.sets[self.i & 1])                      # the NEXT batch travels under this step's kernels
+        return self.Batch((x_enc, x_dec, spk, t))
+
+    class Batch(object):
+        def __init__(self, arrays):
+            self.arrays = arrays
+
+
+def _shift_rows(q_all, out, shift):
+    """out[b, :] = q_all[b, shift : shift + L] (int32 rows of L+1 -> rows of L): one device-to-device 2-D copy."""
+    B, L1 = q_all.shape
+    L = L1 - 1
+    _lib.call('vqvae_memcpy2d_d2d', out.ptr, 4 * L, q_all.ptr + 4 * shift, 4 * L1, 4 * L, B, backend.stream())

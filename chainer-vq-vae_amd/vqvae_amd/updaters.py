@@ -88,20 +88,37 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         self.overlap_comm = overlap_comm
         self._buckets = None
 
-    def _grad_buckets(self, optimizer):
+    def _grad_buckets(self, optimizer, model):
         """(early, late): contiguous [offset, size) runs of the gradient arena.  `late` = what
-        loss2 / loss3 still write (vq.W, the encoder: updaters.py:16-18), `early` = the rest."""
+        loss2 / loss3 still write after loss1's backward -- the parameters of ``model.vq`` and
+        ``model.encoder`` (updaters.py:16-18), found BY IDENTITY in the optimizer's layout, whatever the
+        links are called and wherever the VAE sits inside ``optimizer.target`` -- `early` = the rest.
+        A model without those two links, or one whose late set comes out empty, has no early bucket at
+        all (raises): exchanging a gradient before its last writer has run would be silently wrong."""
         key = core.param_epoch('layout')
         if self._buckets is None or self._buckets[0] != key:
+            enc, vq = getattr(model, 'encoder', None), getattr(model, 'vq', None)
+            if enc is None or vq is None:
+                raise RuntimeError('overlap_comm needs a model with .encoder and .vq links (the parameters the '
+                                   'codebook / commitment losses still write after the reconstruction loss); got %s'
+                                   % type(model).__name__)
+            late_ids = {id(p) for link in (enc, vq) for p in link.params() if p.data is not None}
+            by_name = {n: p for n, p in optimizer.target.namedparams()}
             early, late = [], []
+            n_late = 0
             for name, off, size in optimizer.layout():
                 if off + size > optimizer.n_train:
                     continue                       # EMA shadows: no gradient
-                dst = late if (name.startswith('/encoder') or name.startswith('/vq')) else early
+                is_late = id(by_name[name]) in late_ids
+                n_late += is_late
+                dst = late if is_late else early
                 if dst and dst[-1][0] + dst[-1][1] == off:
                     dst[-1] = (dst[-1][0], dst[-1][1] + size)
                 else:
                     dst.append((off, size))
+            if n_late != len(late_ids):
+                raise RuntimeError('overlap_comm: %d of the %d encoder / vq parameters are in the optimizer\'s arena -- '
+                                   'is optimizer.target the model whose losses are back-propagated?' % (n_late, len(late_ids)))
             self._buckets = (key, early, late)
         return self._buckets[1], self._buckets[2]
 
@@ -132,6 +149,12 @@ class VQVAE_ParallelUpdater(StandardUpdater):
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place
         optimizer.update()
 
+    def loss_func_model(self, model):
+        """The link whose .encoder / .vq the three losses route into: ``loss_func`` when it is such a link (a custom
+        loss_func wrapping the VAE must expose them itself), else optimizer.target."""
+        lf = self.loss_func
+        return lf if (lf is not None and hasattr(lf, 'encoder') and hasattr(lf, 'vq')) else model
+
     def _check_replicas(self, optimizer):
         """Parameters adopted after setup (lazily shaped links) were initialised by each rank's own
         initializer stream, and nothing broadcasts parameters here (the reference's copyparams,
@@ -158,7 +181,7 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         adopt = getattr(optimizer, 'adopt_new_params', None)
         if adopt is not None and adopt() and self.comm.size > 1:
             self._check_replicas(optimizer)
-        early, late = self._grad_buckets(optimizer)
+        early, late = self._grad_buckets(optimizer, self.loss_func_model(model))
         main, side = backend.stream(), backend.side_stream()
         backend.wait_event(side, backend.Event().record(main))      # loss1's gradients are complete
         for off, size in early:

@@ -49,7 +49,15 @@ int vqvae_malloc(void** p, size_t bytes);
 int vqvae_free(void* p);
 int vqvae_memcpy_h2d(void* dst, const void* host_src, size_t bytes, vqvae_stream_t s);
 int vqvae_memcpy_d2h(void* host_dst, const void* src, size_t bytes, vqvae_stream_t s);
+/* page-locked host memory, and a host -> device copy from it that only enqueues (the caller orders its consumers with
+ * an event): the converter's copy of updaters.py:8 on a copy stream, under the previous step's kernels            */
+int vqvae_host_alloc(void** p, size_t bytes);
+int vqvae_host_free(void* p);
+int vqvae_memcpy_h2d_async(void* dst, const void* pinned_host_src, size_t bytes, vqvae_stream_t s);
 int vqvae_memcpy_d2d(void* dst, const void* src, size_t bytes, vqvae_stream_t s);
+/* `height` rows of `width` bytes, row pitches in bytes (a shifted window of every row of a 2-D array) */
+int vqvae_memcpy2d_d2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                       size_t height, vqvae_stream_t s);
 int vqvae_memset(void* p, int byte_value, size_t bytes, vqvae_stream_t s);
 int vqvae_stream_create(vqvae_stream_t* s);
 int vqvae_stream_destroy(vqvae_stream_t s);

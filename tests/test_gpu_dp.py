@@ -94,3 +94,67 @@ def test_bench_two_ranks_spawned_from_bare_invocation(gpu):
     else:
         assert n.value < 2, err[-2000:]
         assert 'ncclCommInitRank' in err or 'rccl' in err.lower() or 'nccl' in err.lower(), err[-2000:]
+
+
+def test_overlapped_exchange_orders_its_streams_without_host_syncs(gpu):
+    """overlap_comm with a communicator that only ENQUEUES (like RCCL): a fake all-reduce that doubles the bucket
+    with an asynchronous kernel on whatever stream it is handed -- no device or stream synchronisation anywhere
+    in the step.  If the side stream's exchange of the early bucket were not ordered behind loss1's backward, or the
+    optimizer not behind the side stream, the overlapped run would read or double half-written gradients; it must
+    equal the non-overlapped run bit for bit, step after step.  A model whose encoder / vq parameters are not in the
+    optimizer's arena must be refused instead of landing in the early bucket."""
+    import helpers as H
+    import vqvae_oracle as O
+    import vqvae_amd as V
+    from vqvae_amd import _lib, backend
+    from vqvae_amd.optimizers import Adam
+
+    class AsyncDoubling(object):
+        size, rank, always_reduce = 2, 0, True
+
+        def __init__(self):
+            self.calls = 0
+
+        def allreduce_grad(self, flat, stream=None):
+            st = backend.stream() if stream is None else stream
+            _lib.call('vqvae_elementwise', _lib.EW_SCALE, flat.size, flat.ptr, None, flat.ptr, 2.0, 0.0, st)
+            self.calls += 1
+            return flat
+
+        def max_scalar(self, v):
+            return v
+
+        def barrier(self):
+            pass
+
+    cfg = dict(H.SMALL)
+    x_enc, x_dec, spk, t = O.synth_batch(4, length=1024, n_speaker=cfg['n_speaker'], seed=5)
+
+    class It(object):
+        def next(self):
+            return [(x_enc[i][..., None], x_dec[i][..., None], spk[i], t[i][..., None]) for i in range(4)]
+
+    def run(overlap):
+        _, model = H.build_model(cfg, seed=9)
+        model.to_gpu()
+        opt = Adam(1e-4)
+        opt.setup(model)
+        comm = AsyncDoubling()
+        upd = V.VQVAE_ParallelUpdater(It(), opt, comm=comm, device=0, overlap_comm=overlap)
+        upd.comm.size = 1            # the whole batch on this rank; always_reduce keeps the exchange
+        for _ in range(4):
+            upd.update()
+        return opt.params.get(), comm.calls, upd
+
+    pa, ca, upd = run(True)
+    pb, cb, _ = run(False)
+    assert ca > cb == 4
+    np.testing.assert_array_equal(pa, pb)
+    early, late = upd._grad_buckets(upd.get_optimizer('main'), upd.get_optimizer('main').target)
+    assert early and late and sum(s for _, s in late) < sum(s for _, s in early)
+
+    class NotAVAE(object):
+        pass
+    upd._buckets = None
+    with pytest.raises(RuntimeError):
+        upd._grad_buckets(upd.get_optimizer('main'), NotAVAE())

@@ -329,3 +329,53 @@ def test_training_reduces_the_losses(gpu):
     assert np.isfinite(hist).all()
     assert last[0] < 0.8 * first[0], (first, last)
     assert last[1] < first[1] and abs(last[2] - 0.25 * last[1]) < 1e-6 * max(1.0, last[1])
+
+
+@pytest.mark.gpu
+def test_streaming_input_step_equals_resident_step(gpu):
+    """The input leg inside the step (inputs.StreamingInputIterator: host minibatch -> page-locked double buffer ->
+    copy stream -> mu-law binning on the device) feeds the updater the same bits as the resident device-side pipeline:
+    three steps from fresh host minibatches == three steps from the same minibatches already on the device, bit for
+    bit -- losses and every parameter (updaters.py:8, 37-38; utils.py:85-110)."""
+    import vqvae_oracle as O
+    import vqvae_amd as V
+    from vqvae_amd.inputs import DeviceInputPipeline, StreamingInputIterator
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    B, L = 3, 512
+    host = []
+    for s in range(3):
+        x_enc, _, spk, _ = O.synth_batch(B, length=L, n_speaker=cfg['n_speaker'], seed=200 + s)
+        host.append((np.ascontiguousarray(x_enc[:, 0, :], np.float32), np.asarray(spk, np.int32)))
+
+    class _Resident(object):
+        def __init__(self):
+            pipe = DeviceInputPipeline(256)
+            self.batches = [pipe(raw, spk) for raw, spk in host]
+            self.i = 0
+
+        def next(self):
+            self.i += 1
+            return self.batches[self.i - 1]
+
+    def run(make_it, conv):
+        _, model = H.build_model(cfg, seed=3)
+        model.to_gpu()
+        opt = Adam(2e-4)
+        opt.setup(model)
+        upd = V.VQVAE_StandardUpdater(make_it(), opt, converter=conv, device=0)
+        losses = []
+        for _ in range(3):
+            upd.update()
+            losses.append([l.data.get().copy() for l in upd.last_losses])
+        return losses, {n: p.data.get().copy() for n, p in model.namedparams()}
+
+    it = iter(host)
+    la, pa = run(lambda: StreamingInputIterator(lambda: next(it, host[-1]), B, L, 256), lambda b, d: b.arrays)
+    lb, pb = run(_Resident, lambda b, d: b)
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+    assert set(pa) == set(pb)
+    for n in pa:
+        np.testing.assert_array_equal(pa[n], pb[n], err_msg=n)

@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --no-header -p no:cacheprovider -k "float32x3_is or scale_invariant or conv1d_fwd_bwd or resblock or random_shapes" 2>&1 | tail -15
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --matmul float32x2 2>&1 | tail -3 | cut -c1-600
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_dp.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -5
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench_q.json; tail -3 gpurun_out/bench.err
+python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/bench_q.json').read()); r = d['roofline']
+print('bench: ms/step %.3f (with input %s)  %.4g samples/s | gate kernel %.1f TF frac %.3f avg %.1f us' % (d['ms_per_step'], d.get('ms_per_step_with_input'), d['value'], r['achieved'], r['frac'], 1e3 * r['avg_launch_ms']))
+PY
