@@ -184,7 +184,17 @@ def cpu_baseline(cfg):
     nthr = min(probe, key=probe.get)
     times = timed(nthr, 3)
     med = float(np.median(times))
-    return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': nthr, 'kind': 'port',
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.lower().startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': cfg['length'] / med, 'unit': 'samples/s', 'cores': nthr, 'cores_is': 'BLAS threads used',
+            'cores_visible': cores, 'cpu_model': model, 'kind': 'port',
             'sample': '%d full training steps (fwd + 3-loss bwd + Adam + EMA) at batch 1, length %d '
                       '(BASELINE configs[0]) after 1 warm-up, median %.2f s/step with %d BLAS threads '
                       '(thread count chosen from %s on one step each; %d cores visible); NumPy '

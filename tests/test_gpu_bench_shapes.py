@@ -153,11 +153,9 @@ def test_config1_whole_step_matches_oracle(gpu):
         dn = H._dev_name(name, True)
         got = g_dev[dn].reshape(arr.shape).astype(np.float64)
         err = float(np.abs(got - arr).max() / max(np.abs(arr).max(), 1e-30))
-        if err > 1e-4:
-            over.append((err, dn))
-        assert err <= 2e-4, 'configs[1] grad %s: %.3e of scale' % (dn, err)
-    print('configs[1]: %d of %d gradient tensors are between 1e-4 and 2e-4 of scale: %s'
-          % (len(over), len(G), sorted(over, reverse=True)[:8]))
+        over.append((err, dn))
+        assert err <= 1e-4, 'configs[1] grad %s: %.3e of scale (north_star: 1e-4)' % (dn, err)
+    print('configs[1]: worst of %d gradient tensors, of scale: %s' % (len(G), sorted(over, reverse=True)[:4]))
     named = dict(model.namedparams())
     for name, arr in O.flatten_params(P):
         dn = H._dev_name(name, True)
@@ -167,7 +165,7 @@ def test_config1_whole_step_matches_oracle(gpu):
 def test_pack_once_equals_pack_per_call(gpu):
     """ResidualNet packs the weight slabs of all its blocks once per step (vqvae_resstack_pack + the _packed entry
     points); the stand-alone entry points pack inside every call.  Same slabs, same kernels: the skip output and every
-    gradient must agree bit for bit."""
+    gradient must agree bit for bit ('float32x3'; in 'float32x2' the two forms run different fp32-accurate kernels: 1e-5)."""
     from vqvae_amd import functions as F, wavenet
     from vqvae_amd.core import Variable
     from vqvae_amd.wavenet import ResidualStackFunction
@@ -200,10 +198,20 @@ def test_pack_once_equals_pack_per_call(gpu):
             return out
         finally:
             wavenet.PACK_ONCE = old
-    a, b = run(True), run(False)
-    assert len(a) == len(b) and len(a) > 20
-    for u, v in zip(a, b):
-        np.testing.assert_array_equal(u, v)
+    try:
+        for mode in ('float32x3', 'float32x2'):
+            gpu.set_matmul_dtype(mode)
+            a, b = run(True), run(False)
+            assert len(a) == len(b) and len(a) > 20
+            for u, v in zip(a, b):
+                if mode == 'float32x3':
+                    np.testing.assert_array_equal(u, v)
+                else:
+                    # 'float32x2': the packed chain runs the three-product kernels (the tensors' maxima travel with
+                    # them), the pack-per-call entry points mode 2's: two fp32-accurate evaluations of one chain
+                    assert np.abs(u - v).max() <= 1e-5 * max(np.abs(v).max(), 1e-30)
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
 _WIN_WORKER = r"""

@@ -3,6 +3,9 @@ the NumPy oracle is too slow to restate everything: one residual block against t
 channel / time extent, and size-independent properties of the path -- linearity and adjointness
 of the conv contractions (forward, backward-data, backward-weight), causality, independence of
 the batch elements, the ln(256) starting loss and agreement of data-parallel shards."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -95,13 +98,31 @@ def _full_model(seed):
     return P, model
 
 
-def test_full_size_step_properties(gpu):
+@pytest.mark.parametrize('mode', ['float32x2', 'float32x3'])
+def test_full_size_step_properties(gpu, mode):
     """Whole configs[1] training step (B = 16): starting loss1 ~ ln 256 (loss1.png starts at 5.5),
-    loss3 = beta * loss2, batch elements do not interact (sample 5 alone gives the same logits bit
-    for bit), and the decoder is causal end to end."""
+    loss3 = beta * loss2, batch elements do not interact (sample 5 alone gives the same logits), and the
+    decoder is causal end to end.  'float32x3': bit for bit.  'float32x2' scales every tensor by a power of
+    two taken from ITS absolute maximum -- over the whole batch, over all times -- so another batch composition or
+    a change in the future can move a scale and with it the last bits of everything: there the two properties
+    hold to fp32 rounding (1e-5 of the logits' scale; measured 2.4e-6)."""
     from vqvae_amd.core import Variable
     import vqvae_amd as V
+    gpu.set_matmul_dtype(mode)
+    try:
+        _full_size_step_properties(gpu, mode, Variable, V)
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+
+
+def _full_size_step_properties(gpu, mode, Variable, V):
     P, model = _full_model(2)
+
+    def same(a, b):
+        if mode == 'float32x3':
+            np.testing.assert_array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
     x_enc, x_dec, spk, t = O.synth_batch(B, length=T, n_speaker=FULL['n_speaker'], seed=71)
     args = [Variable(_dev(gpu, x_enc[..., None])), Variable(_dev(gpu, x_dec[..., None])),
             Variable(_dev(gpu, spk)), Variable(_dev(gpu, t[..., None]))]
@@ -118,12 +139,12 @@ def test_full_size_step_properties(gpu):
             return model.decoder(Variable(_dev(gpu, xd[..., None])), cond).data.get()
         y_all = logits(x_enc, x_dec, spk)
         y_5 = logits(x_enc[5:6], x_dec[5:6], spk[5:6])
-        np.testing.assert_array_equal(y_all[5:6], y_5)
+        same(y_all[5:6], y_5)
         # end-to-end causality of the decoder input (the condition is left alone)
         xd2 = x_dec[5:6].copy()
         xd2[:, :, 6000:] = np.roll(xd2[:, :, 6000:], 7, axis=1)
         y_5b = logits(x_enc[5:6], xd2, spk[5:6])
-        np.testing.assert_array_equal(y_5b[:, :, :6000], y_5[:, :, :6000])
+        same(y_5b[:, :, :6000], y_5[:, :, :6000])
         assert np.abs(y_5b[:, :, 6000:] - y_5[:, :, 6000:]).max() > 1e-3
 
 
@@ -148,3 +169,76 @@ def test_full_size_gradients_are_sums_over_shards(gpu):
     for name, g in g_all.items():
         # every loss is a MEAN over its minibatch: full-batch grad = (g_a + g_b) / 2
         assert_close_scaled(g, 0.5 * (g_a[name] + g_b[name]), 2e-4, 'shard sum ' + name)
+
+
+def _vq_indices(gpu, z_dev, W_dev, B, d, T, k, mode):
+    """vqvae_vq_nearest_fwd through the C ABI on resident inputs -> (idx host (B, T), rows re-checked)."""
+    import ctypes as C
+    from vqvae_amd import _lib
+    from vqvae_amd.backend import DeviceArray
+    idx = DeviceArray((B, T), np.int32)
+    nre = DeviceArray((1,), np.int32)
+    ws = gpu.workspace(_lib.load().vqvae_vq_workspace_bytes(B, d, T, k))
+    _lib.call('vqvae_vq_nearest_fwd', z_dev.ptr, W_dev.ptr, B, d, T, k, mode, idx.ptr, None, nre.ptr, ws.ptr, ws.nbytes,
+              gpu.stream())
+    return idx.get(), int(nre.get()[0])
+
+
+def test_vq_configs3_full_size_default_path_equals_exact_path(gpu):
+    """BASELINE configs[3] at the size bench.py --workload c4 runs (N = 1 048 560 latent rows = 8 738 x 120, k = 8192,
+    d = 128; SURVEY 8d inputs): the default search (MFMA sweep on the matrix pipe, candidate lists of the flagged
+    rows, reference-order distances of the candidates) must give the index of the all-exact path (mode 1: every code
+    of every row in the reference's operation order, utils.py:189-203) for EVERY row, and the oracle's own argmin on
+    a sample of rows.  (Until round 4 the full size was only spot-checked on 64 rows inside the bench.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import bench
+    N, d, k, T = 1048560, 128, 8192, 120
+    B = N // T
+    rows, W = bench.vq_stress_inputs(N, d, k)
+    z = np.ascontiguousarray(rows.reshape(B, T, d).transpose(0, 2, 1))
+    zd, Wd = gpu.to_device(z), gpu.to_device(W)
+    idx0, nre = _vq_indices(gpu, zd, Wd, B, d, T, k, 0)
+    idx1, _ = _vq_indices(gpu, zd, Wd, B, d, T, k, 1)
+    np.testing.assert_array_equal(idx0, idx1)
+    assert 0 < nre < 0.2 * N
+    pick = np.linspace(0, N - 1, 96).astype(np.int64)
+    got = idx0.reshape(-1)
+    for r in pick:
+        dist = np.zeros(k, np.float32)
+        for c in range(d):
+            dist = dist + (rows[r, c] - W[:, c]) ** 2          # utils.py:189-203 summation order
+        assert int(np.argmin(dist)) == int(got[r]), r
+
+
+def test_vq_candidate_list_overflow_takes_the_all_codes_path(gpu):
+    """The candidate re-check lists at most 16 codes per flagged row; a row with more candidates inside the band must
+    fall through to the all-codes re-check (vq_exact_cand_kernel -> overflow list).  Crafted input at the size where
+    the candidate path is active (N >= 4096 rows, k >= 1024): a quarter of the rows sit exactly on a code that the
+    codebook holds 40 times (40 exact ties: first index wins, utils.py:207 numpy.argmin), another quarter on a code held
+    17 times with perturbations of 1 ulp in one component (17 near-ties); the rest are ordinary rows.  Every row must
+    equal the all-exact path and the duplicated rows must return the FIRST of their copies."""
+    rs = np.random.RandomState(77)
+    B, T, d, k = 64, 120, 128, 4096
+    N = B * T
+    W = (rs.standard_normal((k, d)) / np.sqrt(d)).astype(np.float32)
+    dup = rs.permutation(k)
+    c40, c17 = np.sort(dup[:40]), np.sort(dup[40:57])
+    W[c40] = W[c40[0]]
+    base = W[c17[0]].copy()
+    for j, c in enumerate(c17):
+        W[c] = base
+        if j:
+            W[c, j % d] = np.nextafter(base[j % d], np.float32(np.inf))
+    rows = (rs.standard_normal((N, d))).astype(np.float32)
+    kind = rs.randint(0, 4, N)
+    rows[kind == 0] = W[c40[0]]
+    rows[kind == 1] = base
+    z = np.ascontiguousarray(rows.reshape(B, T, d).transpose(0, 2, 1))
+    zd, Wd = gpu.to_device(z), gpu.to_device(W)
+    idx0, nre = _vq_indices(gpu, zd, Wd, B, d, T, k, 0)
+    idx1, _ = _vq_indices(gpu, zd, Wd, B, d, T, k, 1)
+    np.testing.assert_array_equal(idx0, idx1)
+    flat = idx0.reshape(-1)
+    assert (flat[kind == 0] == c40[0]).all()
+    assert (flat[kind == 1] == c17[0]).all()
+    assert nre >= int((kind <= 1).sum())
