@@ -425,6 +425,8 @@ def main():
     ap.add_argument('--onehot-input', action='store_true',
                     help="feed x_dec as the reference's resident fp32 one-hot (utils.py:85-87) instead of device-computed "
                          "bin indices")
+    ap.add_argument('--graph', action='store_true', help='replay the step as a hipGraph also with a communicator (n > 1)')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches every step')
     ap.add_argument('--no-fresh-input', action='store_true',
                     help='skip the second timed region (ms_per_step_with_input: a fresh host minibatch every step)')
     ap.add_argument('--no-overlap', action='store_true',
@@ -499,11 +501,26 @@ def main():
         else:
             shards.append(V.concat_examples(ex, device=local))
     it = ResidentIterator(shards)
+    # The step as ONE hipGraph launch (updaters.GraphedStep: recorded after two eager steps, bit-identical to the eager
+    # step -- tests/test_gpu_model.py::test_graphed_step_equals_eager_step).  Single-rank runs by default; --graph forces
+    # it with a communicator too (RCCL inside a capture has not run on this pool), --no-graph keeps every step eager.
+    use_graph = (not args.no_graph) and (args.graph or (n == 1 and not args.force_comm))
     upd = V.VQVAE_ParallelUpdater(it, opt, comm=comm, converter=resident_converter, device=local,
-                                  overlap_comm=args.overlap_comm)
+                                  overlap_comm=args.overlap_comm, graph=use_graph)
 
     for _ in range(max(args.warmup, 1)):
         upd.update()
+    if use_graph:
+        try:
+            for _ in range(6):                  # (lazily shaped parameters appear at step 1, the recording at step 3)
+                if upd._graphed is not None:
+                    break
+                upd.update()
+            if upd._graphed is None:
+                raise RuntimeError('no recording after the warm-up steps')
+        except Exception as e:                  # never lose the measurement to the capture: eager steps
+            sys.stderr.write('bench: hipGraph capture of the step failed (%s); running eager steps\n' % e)
+            use_graph = upd.graph = False
     backend.synchronize()
     if opt.uninitialized_params():
         raise SystemExit('bench: parameters without storage after warm-up: %s' % opt.uninitialized_params())
@@ -512,7 +529,8 @@ def main():
     tag = _lib.PROF_RESBLOCK_GATE
     lib = _lib.load()
     lib.vqvae_prof_reset()
-    lib.vqvae_prof_enable(1 << tag)
+    if not use_graph:
+        lib.vqvae_prof_enable(1 << tag)      # (a replayed recording carries no per-launch events: timed below, eagerly)
     timed_comm = hasattr(comm, 'time_comm')
     if timed_comm:
         comm.time_comm = True            # HIP events around every all-reduce, on the stream it runs on
@@ -526,6 +544,22 @@ def main():
     comm.barrier()
     dt = time.perf_counter() - t0
     lib.vqvae_prof_enable(0)
+    roofline_pass = 'the timed steps'
+    if use_graph:
+        # per-launch time of the dominant kernel: the same job, the same kernels, launched eagerly with the dispatch's own
+        # start / stop events (hipExtLaunchKernelGGL) right after the timed region
+        upd.graph = False
+        upd.update()
+        backend.synchronize()
+        lib.vqvae_prof_enable(1 << tag)
+        k_eager = min(args.steps, 10)
+        for _ in range(k_eager):
+            upd.update()
+        backend.synchronize()
+        lib.vqvae_prof_enable(0)
+        upd.graph = True
+        roofline_pass = ('%d eager steps of the same job right after the timed region (the timed steps are hipGraph replays, '
+                         'which carry no per-launch events)' % k_eager)
     comm_ms, comm_calls = comm.comm_time_ms() if timed_comm else (0.0, 0)
     if timed_comm:
         comm.time_comm = False
@@ -571,6 +605,7 @@ def main():
     ref_ms = None
     if n == 1 and mode in PRODUCTS_PER_FP32 and not args.no_cpu_baseline:
         # the same step with the fp32 MFMA kernels, for reference (not part of the timed region above)
+        upd.graph = False
         backend.set_matmul_dtype('float32')
         for _ in range(2):
             upd.update()
@@ -582,6 +617,7 @@ def main():
         backend.synchronize()
         ref_ms = 1e3 * (time.perf_counter() - t1) / k
         backend.set_matmul_dtype(mode)
+        upd.graph = use_graph
 
     if rank == 0:
         T = cfg['length']
@@ -608,6 +644,8 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'step_execution': ('one hipGraph launch per step (recorded after two eager steps; bit-identical to the eager step)'
+                               if use_graph else 'eager launches'),
             'ms_per_step_with_input': fresh_ms,
             'with_input_is': (None if fresh_ms is None else
                               'the same %d steps with the input leg inside the step: each minibatch starts in host memory '
@@ -670,7 +708,7 @@ def main():
                                  'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B),
                                  'note': 'x read once, gates + z written once, weights, latent-rate condition slice (DESIGN.md section 3)'},
                          'traffic': traffic, 'traffic_source': tsrc,
-                         'launches': cnt.value, 'avg_launch_ms': avg_ms,
+                         'launches': cnt.value, 'avg_launch_ms': avg_ms, 'avg_launch_ms_measured_over': roofline_pass,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
         }
         if ref_ms is not None:

@@ -921,8 +921,12 @@ __global__ void split_kernel(const float* __restrict__ src, const PtrList32 dst,
 }
 
 // ---- Adam / EMA ------------------------------------------------------------
+// lr_table != nullptr: the step size is lr_table[*step] -- a captured step (hipGraph) is replayed with the next entry
+// every time; step_inc_kernel advances the counter behind the update
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr, float c1, float c2, float eps) {
+                            float* __restrict__ v, size_t n, float lr, float c1, float c2, float eps,
+                            const float* __restrict__ lr_table, const int32_t* __restrict__ step) {
+  if (lr_table != nullptr) lr = lr_table[*step];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i];
@@ -933,6 +937,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(lr, mi), __fadd_rn(__fsqrt_rn(vi), eps)));
   }
 }
+
+__global__ void step_inc_kernel(int32_t* step) { *step += 1; }
 
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ tgt, size_t n, float d,
                            float om) {
@@ -1230,7 +1236,19 @@ int vqvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, doub
   VQ_REQUIRE(p && g && m && v, "adam_step: null pointer");
   if (!n) return 0;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n,
-                     (float)lr_t, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+                     (float)lr_t, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (const float*)nullptr, (const int32_t*)nullptr);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* lr_table,
+                        int32_t* step, double beta1, double beta2, double eps, vqvae_stream_t s) {
+  VQ_REQUIRE(p && g && m && v && lr_table && step, "adam_step_dev: null pointer");
+  if (!n) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n,
+                     0.f, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, lr_table, (const int32_t*)step);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step);
   VQ_LAUNCH_CHECK();
   return 0;
 }

@@ -201,6 +201,12 @@ extern "C" int vqvae_graph_capture_begin(vqvae_stream_t s) {
   VQ_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
   return 0;
 }
+// relaxed capture: the capturing thread may still call hipMalloc / hipEventCreate (the Python-side pool allocator and
+// event pool may have to grow while a whole training step is being recorded)
+extern "C" int vqvae_graph_capture_begin_relaxed(vqvae_stream_t s) {
+  VQ_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeRelaxed));
+  return 0;
+}
 extern "C" int vqvae_graph_capture_end(vqvae_stream_t s, void** graph_exec) {
   VQ_REQUIRE(graph_exec, "graph_capture_end: null output");
   hipGraph_t g = nullptr;

@@ -159,6 +159,7 @@ PROTOTYPES = {
     'vqvae_elementwise': (c_int, [c_int, c_size_t, P, P, P, c_float, c_float, P]),
     'vqvae_sum': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'vqvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, P]),
+    'vqvae_adam_step_dev': (c_int, [P, P, P, P, c_size_t, P, P, c_double, c_double, c_double, P]),
     'vqvae_ema_step': (c_int, [P, P, c_size_t, c_double, P]),
     'vqvae_comm_unique_id': (c_int, [c_char_p]),
     'vqvae_comm_init': (c_int, [C.POINTER(c_void_p), c_int, c_int, c_char_p]),
@@ -170,6 +171,7 @@ PROTOTYPES = {
     'vqvae_wavenet_gen_run_workspace_bytes': (c_size_t, [C.POINTER(GenDesc)]),
     'vqvae_wavenet_gen_run': (c_int, [C.POINTER(GenDesc), c_int, c_int, P, c_size_t, P]),
     'vqvae_graph_capture_begin': (c_int, [P]),
+    'vqvae_graph_capture_begin_relaxed': (c_int, [P]),
     'vqvae_graph_capture_end': (c_int, [P, C.POINTER(c_void_p)]),
     'vqvae_graph_launch': (c_int, [P, P]),
     'vqvae_graph_destroy': (c_int, [P]),

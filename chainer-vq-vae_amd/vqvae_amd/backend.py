@@ -198,28 +198,69 @@ def _round(nbytes):
     return max(256, (nbytes + 255) // 256 * 256)
 
 
+class Arena(object):
+    """The memory of ONE captured launch sequence (a training step recorded into a hipGraph, updaters.GraphedStep).
+    While the arena is active every new block is served from the arena's own free lists (else from the pool) and
+    belongs to the arena from then on: when its last reference drops it returns to the ARENA, never to the pool, so
+    the addresses the recorded kernels were given can only be reused by the recording itself -- in the same order at
+    every replay -- and by nothing else, for as long as the arena lives.  ``release()`` hands everything back."""
+
+    def __init__(self):
+        self.free = {}           # nbytes -> [ptr]: blocks of this arena nobody references right now
+        self.alive = True
+
+    def release(self):
+        """Idle blocks go back to the pool now, blocks still referenced when their last reference drops."""
+        if not self.alive:
+            return
+        self.alive = False
+        for nbytes, ptrs in self.free.items():
+            _state['pool'].setdefault(nbytes, []).extend(ptrs)
+            _state['pool_bytes'] += nbytes * len(ptrs)
+        self.free = {}
+
+
+def arena_begin(arena):
+    if _state.get('arena') is not None:
+        raise RuntimeError('an allocation arena is already active')
+    _state['arena'] = arena
+
+
+def arena_end():
+    _state['arena'] = None
+
+
 class _Block(object):
-    __slots__ = ('ptr', 'nbytes', '__weakref__')
+    __slots__ = ('ptr', 'nbytes', 'arena', '__weakref__')
 
     def __init__(self, nbytes):
         nbytes = _round(nbytes)
-        free = _state['pool'].get(nbytes)
-        if free:
-            self.ptr = free.pop()
-            _state['pool_bytes'] -= nbytes
+        arena = _state.get('arena')
+        self.arena = arena
+        afree = arena.free.get(nbytes) if arena is not None else None
+        if afree:
+            self.ptr = afree.pop()
         else:
-            stream()
-            p = C.c_void_p()
-            _lib.call('vqvae_malloc', C.byref(p), nbytes)
-            self.ptr = p.value
+            free = _state['pool'].get(nbytes)
+            if free:
+                self.ptr = free.pop()
+                _state['pool_bytes'] -= nbytes
+            else:
+                stream()
+                p = C.c_void_p()
+                _lib.call('vqvae_malloc', C.byref(p), nbytes)
+                self.ptr = p.value
         self.nbytes = nbytes
         _state['live_bytes'] += nbytes
 
     def __del__(self):
         try:
+            _state['live_bytes'] -= self.nbytes
+            if self.arena is not None and self.arena.alive:
+                self.arena.free.setdefault(self.nbytes, []).append(self.ptr)
+                return
             _state['pool'].setdefault(self.nbytes, []).append(self.ptr)
             _state['pool_bytes'] += self.nbytes
-            _state['live_bytes'] -= self.nbytes
         except Exception:      # interpreter shutdown
             pass
 

@@ -119,11 +119,48 @@ class Adam(object):
 
     def update(self):
         """One Adam step on every trainable parameter (chainer Adam update rule)."""
+        if self._recording:
+            # inside a hipGraph capture (updaters.GraphedStep): the step size comes from the device-side schedule,
+            # nothing host-dependent goes into the recorded launch
+            _lib.call('vqvae_adam_step_dev', self.params.ptr, self.grads.ptr, self.m.ptr, self.v.ptr, self.n_train,
+                      self._lr_table.ptr, self._step_dev.ptr, float(self.beta1), float(self.beta2), float(self.eps),
+                      backend.stream())
+            return
         self.adopt_new_params()
         self.t += 1
         _lib.call('vqvae_adam_step', self.params.ptr, self.grads.ptr, self.m.ptr, self.v.ptr,
                   self.n_train, float(self.lr), float(self.beta1), float(self.beta2),
                   float(self.eps), backend.stream())
+
+    # ---- device-side schedule for a captured step ------------------------------------------------
+    _recording = False
+    _lr_table = None
+    SCHEDULE_HORIZON = 4096
+
+    def sync_schedule(self):
+        """Makes lr_table[*step] the step size of update number ``self.t + 1`` (what the next replayed step must
+        use): a no-op while the device counter is where the host's ``t`` says; otherwise -- first use, the horizon
+        reached, eager steps in between -- the table is refilled from ``t`` (one small synchronous upload)."""
+        if (self._lr_table is not None and self._sched_next == self.t + 1
+                and self.t + 1 - self._sched_base <= self.SCHEDULE_HORIZON):
+            return
+        base, t_save = self.t, self.t
+        tbl = np.empty(self.SCHEDULE_HORIZON, np.float32)
+        for i in range(self.SCHEDULE_HORIZON):
+            self.t = base + 1 + i
+            tbl[i] = np.float32(self.lr)             # the same double -> float32 rounding as vqvae_adam_step's cast
+        self.t = t_save
+        if self._lr_table is None:
+            self._lr_table = backend.empty((self.SCHEDULE_HORIZON,), np.float32)
+            self._step_dev = backend.empty((1,), np.int32)
+        self._lr_table.set(tbl)
+        self._step_dev.set(np.zeros(1, np.int32))
+        self._sched_base, self._sched_next = base, base + 1
+
+    def replayed(self):
+        """Host-side bookkeeping of one replayed (or just captured and launched) step."""
+        self.t += 1
+        self._sched_next = self.t + 1
 
     def layout(self):
         """[(name, offset, size)] of the flat arena (trainable first)."""

@@ -23,14 +23,126 @@ def concat_examples(batch, device=None):
     return tuple(out)
 
 
+class GraphedStep(object):
+    """One training step (updaters.py:13-19: forward, three-loss backward, optimizer update) recorded ONCE into a
+    hipGraph and replayed: ~330 kernel launches, their Python-level autograd bookkeeping and ~4 ms of host time per
+    step become one hipGraphLaunch.  What makes the recording replayable:
+      * the minibatch is copied into staging arrays at fixed addresses before every replay (the recording reads those);
+      * every buffer the recording allocates lives in a backend.Arena that nothing else can take from, so the
+        addresses baked into the recorded launches stay valid and are reused only by the recording itself;
+      * Adam's step size is read from a device-side schedule (optimizers.Adam.sync_schedule, vqvae_adam_step_dev);
+      * the losses (and whatever else the step left behind) are arrays of the arena: after a replay they hold the
+        new values.
+    The recording is keyed by the input signature, the parameter layout and the matmul mode: anything else (another
+    batch size, lazily created parameters, a re-laid arena) falls back to an eager step and records again."""
+
+    def __init__(self, key, stage, arena, graph, losses, keep):
+        self.key, self.stage, self.arena, self.graph, self.losses, self.keep = key, stage, arena, graph, losses, keep
+
+    def load(self, in_arrays):
+        for dst, src in zip(self.stage, in_arrays):
+            dst.copy_from(src)
+
+    def launch(self):
+        from . import _lib
+        _lib.call('vqvae_graph_launch', self.graph, backend.stream())
+
+    def release(self):
+        from . import _lib
+        if self.graph is not None:
+            backend.synchronize()
+            _lib.call('vqvae_graph_destroy', self.graph)
+            self.graph = None
+            self.losses = self.keep = None
+            self.arena.release()
+
+
+def _like(a):
+    """A fresh device array of ``a``'s shape, dtype and class (IndexInput keeps its quantize)."""
+    out = a.__class__.__new__(a.__class__)
+    backend.DeviceArray.__init__(out, a.shape, a.dtype)
+    for slot in getattr(a.__class__, '__slots__', ()):
+        if slot not in ('ptr', 'shape', 'dtype', '_block', '__weakref__') and hasattr(a, slot):
+            setattr(out, slot, getattr(a, slot))
+    return out
+
+
 class StandardUpdater(object):
-    def __init__(self, iterator, optimizer, converter=concat_examples, device=0, loss_func=None):
+    def __init__(self, iterator, optimizer, converter=concat_examples, device=0, loss_func=None, graph=False):
         self._iterators = iterator if isinstance(iterator, dict) else {'main': iterator}
         self._optimizers = optimizer if isinstance(optimizer, dict) else {'main': optimizer}
         self.converter = converter
         self.device = device
         self.loss_func = loss_func
         self.iteration = 0
+        # graph=True: record the step into a hipGraph after ``graph_warmup`` eager steps and replay it (GraphedStep)
+        self.graph = bool(graph)
+        self.graph_warmup = 2
+        self._graphed = None
+        self._eager_steps = 0
+
+    # ---- captured step ---------------------------------------------------------------------------
+    def _step_key(self, in_arrays, optimizer):
+        from . import _lib
+        sig = tuple((type(a).__name__, tuple(a.shape), str(a.dtype)) for a in in_arrays)
+        return (sig, core.param_epoch('layout'), core.param_epoch('init'), _lib.load().vqvae_get_matmul_dtype(),
+                backend.overlap_enabled(), id(optimizer))
+
+    def _run_step(self, in_arrays, body):
+        """``body(in_arrays)`` = forward + backward (+ exchange) + optimizer.update, eagerly or through the recording."""
+        optimizer = self._optimizers['main']
+        if not self.graph:
+            return body(in_arrays)
+        in_arrays = tuple(in_arrays)
+        if any(not isinstance(a, backend.DeviceArray) for a in in_arrays):
+            raise TypeError('graph=True needs device-resident input arrays')
+        key = self._step_key(in_arrays, optimizer)
+        g = self._graphed
+        if g is not None and g.key == key:
+            optimizer.sync_schedule()
+            g.load(in_arrays)
+            g.launch()
+            optimizer.replayed()
+            self.last_losses = g.losses
+            return
+        if g is not None:
+            g.release()
+            self._graphed = None
+        if self._eager_steps < self.graph_warmup or optimizer.uninitialized_params():
+            self._eager_steps += 1
+            body(in_arrays)
+            if self._step_key(in_arrays, optimizer) != key:      # parameters appeared / moved during this step
+                self._eager_steps = min(self._eager_steps, self.graph_warmup - 1)
+            return
+        self._graphed = self._record(in_arrays, key, body, optimizer)
+
+    def _record(self, in_arrays, key, body, optimizer):
+        from . import _lib
+        import ctypes as C
+        stage = [_like(a) for a in in_arrays]
+        optimizer.sync_schedule()
+        arena = backend.Arena()
+        st = backend.stream()
+        graph = C.c_void_p()
+        backend.synchronize()
+        backend.arena_begin(arena)
+        optimizer._recording = True
+        try:
+            _lib.call('vqvae_graph_capture_begin_relaxed', st)
+            try:
+                body(stage)
+            finally:
+                _lib.call('vqvae_graph_capture_end', st, C.byref(graph))
+        finally:
+            optimizer._recording = False
+            backend.arena_end()
+        # nothing has executed yet: this step runs as the first launch of the recording
+        keep = [dict(backend._state['ws'])]          # the scratch buffers the recording reads and writes
+        g = GraphedStep(key, stage, arena, graph, self.last_losses, keep)
+        g.load(in_arrays)
+        g.launch()
+        optimizer.replayed()
+        return g
 
     def get_optimizer(self, name):
         return self._optimizers[name]
@@ -62,9 +174,12 @@ class VQVAE_StandardUpdater(StandardUpdater):
         optimizer = self._optimizers['main']
         in_arrays = self.converter(self._iterators['main'].next(), self.device)
         loss_func = self.loss_func or optimizer.target
-        self.last_losses = loss_func(*in_arrays)
-        three_loss_backward(optimizer.target, self.last_losses)
-        optimizer.update()
+
+        def body(arrays):
+            self.last_losses = loss_func(*arrays)
+            three_loss_backward(optimizer.target, self.last_losses)
+            optimizer.update()
+        self._run_step(in_arrays, body)
 
 
 class VQVAE_ParallelUpdater(StandardUpdater):
@@ -78,9 +193,9 @@ class VQVAE_ParallelUpdater(StandardUpdater):
     optimizer's alpha must already be lr/n (train.py:101)."""
 
     def __init__(self, iterator, optimizer, comm=None, converter=concat_examples, device=0,
-                 loss_func=None, overlap_comm=False):
+                 loss_func=None, overlap_comm=False, graph=False):
         super(VQVAE_ParallelUpdater, self).__init__(iterator, optimizer, converter, device,
-                                                    loss_func)
+                                                    loss_func, graph=graph)
         self.comm = comm or SingleCommunicator()
         # opt-in: exchange the gradients that are final after the reconstruction loss's backward (decoder,
         # condition embed: 95 % of the arena) on the side stream while the codebook / commitment losses
@@ -132,7 +247,9 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         else:
             shard = strided_shard(it.next(), self.comm.rank, n)   # batch[rank::n], as the reference (updaters.py:37-38)
         in_arrays = self.converter(shard, self.device)
+        self._run_step(in_arrays, lambda arrays: self._step_body(arrays, optimizer, model, n))
 
+    def _step_body(self, in_arrays, optimizer, model, n):
         with core.force_backprop_mode():
             self.last_losses = (self.loss_func or model)(*in_arrays)
         exchange = n > 1 or getattr(self.comm, 'always_reduce', False)
@@ -143,7 +260,7 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         # parameters created during this forward (lazily shaped links, net.py:34-43) join the
         # flat arenas BEFORE the exchange, so their gradients are summed like everyone else's
         adopt = getattr(optimizer, 'adopt_new_params', None)
-        if adopt is not None and adopt() and n > 1:
+        if not optimizer._recording and adopt is not None and adopt() and n > 1:
             self._check_replicas(optimizer)
         if exchange:
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place

@@ -430,6 +430,11 @@ int vqvae_split(const float* src, float* const* dsts, int n, size_t count, int a
  *      scalars are rounded to fp32 exactly where NumPy would (weak Python scalars). */
 int vqvae_adam_step(float* p, const float* g, float* m, float* v, size_t n,
                     double lr_t, double beta1, double beta2, double eps, vqvae_stream_t s);
+/* the same update with lr_t = lr_table[*step] (entries already rounded to fp32 by the host), *step advanced by one
+ * behind it: the form a captured training step (vqvae_graph_*) is replayed with -- nothing about the schedule
+ * crosses the host-device boundary per step                                                                */
+int vqvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* lr_table,
+                        int32_t* step, double beta1, double beta2, double eps, vqvae_stream_t s);
 /* ExponentialMovingAverage (utils.py:151-155): ema = decay*target + (1-decay)*ema */
 int vqvae_ema_step(float* ema, const float* target, size_t n, double decay,
                    vqvae_stream_t s);
@@ -517,6 +522,9 @@ int vqvae_wavenet_gen_run(const vqvae_gen_desc* d, int t0, int steps, void* ws, 
 /* ---- hipGraph capture/replay of a launch sequence on one stream (launch-bound inner loops:
  *      the per-sample chain of generate.py:105-145)                                          */
 int vqvae_graph_capture_begin(vqvae_stream_t s);
+/* the same with hipStreamCaptureModeRelaxed: the host side may allocate while it records (a whole training step,
+ * updaters.py:13-19, driven by the Python-level graph of FunctionNodes)                                    */
+int vqvae_graph_capture_begin_relaxed(vqvae_stream_t s);
 int vqvae_graph_capture_end(vqvae_stream_t s, void** graph_exec);
 int vqvae_graph_launch(void* graph_exec, vqvae_stream_t s);
 int vqvae_graph_destroy(void* graph_exec);

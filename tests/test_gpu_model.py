@@ -379,3 +379,62 @@ def test_streaming_input_step_equals_resident_step(gpu):
     assert set(pa) == set(pb)
     for n in pa:
         np.testing.assert_array_equal(pa[n], pb[n], err_msg=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('index_input', [False, True])
+def test_graphed_step_equals_eager_step(gpu, index_input):
+    """updaters.GraphedStep: the training step recorded into a hipGraph (after two eager warm-up steps) and replayed
+    gives, step after step, the bits of the eager step -- losses, every parameter, Adam's moments and step count --
+    on alternating minibatches (the staging copy), across a change of batch size (falls back to eager, records again)
+    and with an eager step in between (the device-side Adam schedule re-synchronises)."""
+    import vqvae_amd as V
+    from vqvae_amd.inputs import DeviceInputPipeline
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    L = 512
+    sizes = [3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3]
+    data = []
+    for s, Bq in enumerate(sizes):
+        x_enc, x_dec, spk, t = O.synth_batch(Bq, length=L, n_speaker=cfg['n_speaker'], seed=300 + s)
+        if index_input:
+            data.append((np.ascontiguousarray(x_enc[:, 0, :], np.float32), np.asarray(spk, np.int32)))
+        else:
+            data.append([(x_enc[i][..., None], x_dec[i][..., None], spk[i], t[i][..., None]) for i in range(Bq)])
+
+    def run(graph):
+        _, model = H.build_model(cfg, seed=4)
+        model.to_gpu()
+        opt = Adam(2e-4)
+        opt.setup(model)
+        pipe = DeviceInputPipeline(256)
+
+        class It(object):
+            i = 0
+
+            def next(self):
+                It.i += 1
+                d = data[It.i - 1]
+                return pipe(*d) if index_input else d
+        It.i = 0
+        conv = (lambda b, dev: b) if index_input else V.concat_examples
+        upd = V.VQVAE_StandardUpdater(It(), opt, converter=conv, device=0, graph=graph)
+        losses, replays = [], 0
+        for k in range(len(sizes)):
+            if k == 7:
+                upd.graph = False           # one eager step in the middle of a replayed run
+            upd.update()
+            upd.graph = graph
+            replays += int(graph and upd._graphed is not None)
+            losses.append([l.data.get().copy() for l in upd.last_losses])
+        return losses, opt.params.get(), opt.m.get(), opt.v.get(), opt.t, replays
+
+    la, pa, ma, va, ta, ra = run(True)
+    lb, pb, mb, vb, tb, rb = run(False)
+    assert ra >= 5 and rb == 0 and ta == tb == len(sizes)
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ma, mb)
+    np.testing.assert_array_equal(va, vb)
