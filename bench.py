@@ -438,7 +438,9 @@ def main():
                          "'strong' = global batch 128 split over the N ranks (128/N per GPU)")
     ap.add_argument('--overlap-comm', action='store_true',
                     help='exchange the decoder / condition-embed gradient bucket on the side stream while the '
-                         'codebook and commitment losses still back-propagate (VQVAE_ParallelUpdater(overlap_comm=True))')
+                         'codebook and commitment losses still back-propagate (VQVAE_ParallelUpdater(overlap_comm=True)); '
+                         'the default with more than one rank')
+    ap.add_argument('--no-overlap-comm', action='store_true', help='N > 1: the whole arena in one all-reduce on the main stream')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -467,6 +469,16 @@ def main():
     from vqvae_amd import _lib, backend
     from vqvae_amd.comm import RcclCommunicator, SingleCommunicator
     backend.init(local)
+    # N > 1: this rank's host memory and threads next to its GPU (the page-locked input buffers, the Python heap)
+    numa = None
+    if n > 1 and not os.environ.get('VQVAE_NO_AFFINITY'):
+        import ctypes as C
+        from vqvae_amd.comm import bind_to_numa_node, gpu_numa_node
+        bus = C.create_string_buffer(32)
+        if _lib.load().vqvae_device_pci_bus_id(bus, 32) == 0:
+            numa = bind_to_numa_node(gpu_numa_node(bus.value.decode()))
+            numa['pci_bus_id'] = bus.value.decode()
+    args.overlap_comm = (args.overlap_comm or n > 1) and not args.no_overlap_comm
     if args.bf16:
         backend.set_matmul_dtype('bfloat16')
     elif args.matmul:
@@ -484,6 +496,8 @@ def main():
     model, opt = build(cfg, n)
     model.to_gpu(local)
     opt.setup(model)
+    # start-up self-test of the exchange (rank ids through sum / max all-reduces, identical parameters on every rank)
+    comm_self_test = comm.self_test(opt.params) if hasattr(comm, 'self_test') else None
 
     B = cfg['batch_per_gpu']
     # The feed.  Default: the device-side input pipeline's form (raw crops -> bin INDICES on the device);
@@ -661,7 +675,7 @@ def main():
                 'rank_ms_per_step_max': rank_ms_max, 'rank_ms_per_step_min': rank_ms_min,
                 'note': 'all-reduce time = HIP events around ncclAllReduce on its stream (includes waiting for the '
                         'slowest rank to arrive); rank_ms = each rank\'s own wall time per step before the closing barrier',
-                'cpu_affinity_rank0': affinity},
+                'cpu_affinity_rank0': affinity, 'numa_binding_rank0': numa, 'startup_self_test': comm_self_test},
             'dtype': ('bf16 operands, f32 accumulate' if args.bf16 else
                       {'float32x3': 'f32 (fp32 tensors; each fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate)',
                        'float32x2': 'f32 (fp32 tensors; each fp32 product = 3 fp16 MFMA products of a power-of-two-scaled hi + lo operand split, fp32 accumulate)',

@@ -91,6 +91,14 @@ int vqvae_device_info(char* name, int cap, int* n_cu, size_t* total_mem) {
   return 0;
 }
 
+int vqvae_device_pci_bus_id(char* out, int cap) {       // "0000:c1:00.0": which sysfs device (NUMA node) the current GPU is
+  VQ_REQUIRE(out && cap >= 16, "device_pci_bus_id: buffer of >= 16 bytes");
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  VQ_CHECK_HIP(hipDeviceGetPCIBusId(out, cap, dev));
+  return 0;
+}
+
 int vqvae_malloc(void** p, size_t bytes) {
   VQ_REQUIRE(p, "vqvae_malloc: null");
   VQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 4));

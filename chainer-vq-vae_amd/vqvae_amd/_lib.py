@@ -71,6 +71,7 @@ PROTOTYPES = {
     'vqvae_device_count': (c_int, [C.POINTER(c_int)]),
     'vqvae_set_device': (c_int, [c_int]),
     'vqvae_device_info': (c_int, [c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_size_t)]),
+    'vqvae_device_pci_bus_id': (c_int, [c_char_p, c_int]),
     'vqvae_malloc': (c_int, [C.POINTER(c_void_p), c_size_t]),
     'vqvae_free': (c_int, [P]),
     'vqvae_memcpy_h2d': (c_int, [P, c_void_p, c_size_t, P]),

@@ -102,6 +102,71 @@ def _read_owned(path):
         os.close(fd)
 
 
+def exchange_unique_id(rank, make_id, timeout=300.0):
+    """The file rendezvous (no GPU, no library involved): rank 0 calls ``make_id()`` -> 128 bytes and publishes them,
+    every other rank waits for the file and reads it.  Returns (path, the 128 bytes).  The caller (rank 0) removes the
+    file once every rank has joined."""
+    path = _rendezvous_path()
+    if rank == 0:
+        raw = make_id()
+        _publish(path, raw)
+        return path, raw
+    t0 = time.time()
+
+    def fresh():
+        # a file left behind by a crashed earlier job with the same key is not ours: ranks of
+        # one job start within seconds of each other, rank 0's file cannot be minutes old
+        try:
+            return os.path.getmtime(path) > t0 - 120.0
+        except OSError:
+            return False
+    while not fresh():
+        if time.time() - t0 > timeout:
+            raise RuntimeError('RCCL rendezvous timed out waiting for %s' % path)
+        time.sleep(0.05)
+    return path, _read_owned(path)
+
+
+def gpu_numa_node(pci_bus_id):
+    """NUMA node of a PCI device from sysfs ('0000:c1:00.0' -> int, None when unknown / -1)."""
+    try:
+        with open('/sys/bus/pci/devices/%s/numa_node' % pci_bus_id.lower()) as fh:
+            node = int(fh.read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_to_numa_node(node):
+    """Prefer ``node`` for this process's future page allocations (set_mempolicy(MPOL_PREFERRED)) and run on its
+    cores: the page-locked input buffers and the Python heap of a rank then live next to its GPU.  Returns a dict
+    describing what was done (for the bench line); never raises."""
+    out = {'numa_node': node, 'mempolicy': None, 'cpus': None}
+    if node is None:
+        return out
+    try:
+        with open('/sys/devices/system/node/node%d/cpulist' % node) as fh:
+            cpus = set()
+            for part in fh.read().strip().split(','):
+                a, _, b = part.partition('-')
+                cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            out['cpus'] = [min(allowed), max(allowed), len(allowed)]
+    except (OSError, ValueError, AttributeError):
+        pass
+    try:
+        libc = C.CDLL(None, use_errno=True)
+        mask = (C.c_ulong * 16)()
+        mask[node // (8 * C.sizeof(C.c_ulong))] = 1 << (node % (8 * C.sizeof(C.c_ulong)))
+        rc = libc.syscall(238 if os.uname().machine == 'x86_64' else 237, 1, mask, C.c_ulong(16 * 8 * C.sizeof(C.c_ulong)))   # set_mempolicy(MPOL_PREFERRED)
+        out['mempolicy'] = 'preferred' if rc == 0 else 'set_mempolicy errno %d' % C.get_errno()
+    except Exception as e:              # no libc / seccomp: report, carry on
+        out['mempolicy'] = 'unavailable (%s)' % type(e).__name__
+    return out
+
+
 class RcclCommunicator(object):
     always_reduce = True      # a 1-rank communicator still exercises the all-reduce (self-test)
 
@@ -112,27 +177,12 @@ class RcclCommunicator(object):
         local = int(os.environ.get('LOCAL_RANK', self.rank)) if device is None else device
         backend.init(local)
         self._lib, self._backend = _lib, backend
-        path = _rendezvous_path()
-        idbuf = C.create_string_buffer(128)
-        if self.rank == 0:
-            _lib.call('vqvae_comm_unique_id', idbuf)
-            _publish(path, idbuf.raw)
-        else:
-            t0 = time.time()
-
-            def fresh():
-                # a file left behind by a crashed earlier job with the same key is not ours: ranks of
-                # one job start within seconds of each other, rank 0's file cannot be minutes old
-                try:
-                    return os.path.getmtime(path) > t0 - 120.0
-                except OSError:
-                    return False
-            while not fresh():
-                if time.time() - t0 > timeout:
-                    raise RuntimeError('RCCL rendezvous timed out waiting for %s' % path)
-                time.sleep(0.05)
-            raw = _read_owned(path)
-            idbuf = C.create_string_buffer(raw, 128)
+        def make_id():
+            buf = C.create_string_buffer(128)
+            _lib.call('vqvae_comm_unique_id', buf)
+            return buf.raw
+        path, raw = exchange_unique_id(self.rank, make_id, timeout)
+        idbuf = C.create_string_buffer(raw, 128)
         comm = C.c_void_p()
         # RCCL prints a version banner on first init; keep stdout clean for callers that
         # parse it (bench.py prints exactly one JSON line): route fd 1 to stderr meanwhile
@@ -203,6 +253,32 @@ class RcclCommunicator(object):
         self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, self._scalar.ptr, 1,
                        self._backend.stream())
         return n.value, int(round(float(self._scalar.get()[0])))
+
+    def self_test(self, arena=None):
+        """Start-up check of the exchange itself, before any step depends on it: the all-reduced sum / max / min of
+        the rank ids must be n(n-1)/2, n-1 and 0, and (with ``arena`` = the parameter arena) every rank must hold the
+        same parameters.  Returns a dict for bench.py's multi_rank_diagnostics; raises when a collective lies."""
+        n, r = self.size, self.rank
+        from . import _lib
+        self._scalar.set(np.array([float(r)], np.float32))
+        self._lib.call('vqvae_comm_allreduce_sum_f32', self._comm, self._scalar.ptr, 1, self._backend.stream())
+        s = float(self._scalar.get()[0])
+        hi, lo = self.max_scalar(float(r)), -self.max_scalar(-float(r))
+        out = {'rank_id_sum': s, 'rank_id_max': hi, 'rank_id_min': lo, 'expected_sum': n * (n - 1) / 2.0}
+        if s != n * (n - 1) / 2.0 or hi != n - 1 or lo != 0:
+            raise RuntimeError('RCCL self-test failed on rank %d: sum / max / min of the rank ids = %r / %r / %r with %d ranks'
+                               % (r, s, hi, lo, n))
+        if arena is not None:
+            tot = self._backend.zeros((1,), np.float32)
+            ws = self._backend.workspace(4096 * 4)
+            _lib.call('vqvae_sum', arena.ptr, arena.size, 1.0, tot.ptr, ws.ptr, ws.nbytes, self._backend.stream())
+            v = float(tot.get()[0])
+            chi, clo = self.max_scalar(v), -self.max_scalar(-v)
+            out.update(param_checksum_max=chi, param_checksum_min=clo)
+            if chi != clo:
+                raise RuntimeError('data-parallel replicas start from different parameters: checksum %r .. %r across ranks'
+                                   % (clo, chi))
+        return out
 
     def close(self):
         if self._comm is not None:

@@ -45,6 +45,7 @@ int vqvae_abi_version(void);
 int vqvae_device_count(int* n);
 int vqvae_set_device(int dev);
 int vqvae_device_info(char* name, int name_cap, int* n_cu, size_t* total_mem);
+int vqvae_device_pci_bus_id(char* out, int cap);   /* of the current device, e.g. "0000:c1:00.0" (-> its NUMA node in sysfs) */
 int vqvae_malloc(void** p, size_t bytes);
 int vqvae_free(void* p);
 int vqvae_memcpy_h2d(void* dst, const void* host_src, size_t bytes, vqvae_stream_t s);

@@ -158,3 +158,27 @@ def test_overlapped_exchange_orders_its_streams_without_host_syncs(gpu):
     upd._buckets = None
     with pytest.raises(RuntimeError):
         upd._grad_buckets(upd.get_optimizer('main'), NotAVAE())
+
+
+def test_numa_binding_of_a_rank(gpu, tmp_path):
+    """What bench.py does at start-up with more than one rank -- find the GPU's PCI bus id, its NUMA node in sysfs,
+    prefer that node's memory and cores -- in a child process: it must report what it did and never fail a run."""
+    code = (
+        "import sys, json, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "from vqvae_amd import _lib, backend, comm\n"
+        "backend.init(0)\n"
+        "bus = C.create_string_buffer(32)\n"
+        "assert _lib.load().vqvae_device_pci_bus_id(bus, 32) == 0\n"
+        "node = comm.gpu_numa_node(bus.value.decode())\n"
+        "out = comm.bind_to_numa_node(node)\n"
+        "x = backend.to_device(__import__('numpy').ones(1024, 'f'))\n"
+        "assert float(x.get().sum()) == 1024.0\n"
+        "print('NUMA', json.dumps(dict(out, bus=bus.value.decode())))\n"
+    ) % os.path.join(ROOT, 'chainer-vq-vae_amd')
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith('NUMA')][0]
+    info = json.loads(line[5:])
+    assert ':' in info['bus']
+    print(info)

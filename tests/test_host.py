@@ -4,6 +4,8 @@ Link tree (names, shapes, parameter counts), and that NOTHING computes on the ho
 import ctypes as C
 import os
 import re
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -447,3 +449,51 @@ def test_hot_kernels_keep_their_staging_in_registers(tmp_path):
         assert hits, 'no kernel matching %s in the compiled module' % key
         for name, (got_lds, scratch, vgpr, spills) in hits:
             assert vgpr <= 128 and 2 * got_lds <= 160 * 1024, '%s: %d VGPRs, %d B of LDS: not two workgroups per CU' % (name, vgpr, got_lds)
+
+
+def test_file_rendezvous_with_eight_ranks(tmp_path):
+    """The RCCL id hand-off of an 8-rank node (comm.exchange_unique_id: rank 0 publishes 128 bytes through a file in a
+    private per-user directory, ranks 1..7 wait for it and read it) with real processes and no GPU: every
+    rank must end up with rank 0's bytes, late starters included, and a stale file of an earlier job with the same key
+    must not be taken for this job's."""
+    import subprocess
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from vqvae_amd import comm\n"
+        "rank = int(os.environ['RANK'])\n"
+        "time.sleep(0.15 * (rank %% 3))\n"
+        "path, raw = comm.exchange_unique_id(rank, lambda: bytes((7 * i + 3) %% 256 for i in range(128)), timeout=60)\n"
+        "open(os.path.join(%r, 'got_%%d' %% rank), 'wb').write(raw)\n"
+    ) % (os.path.join(ROOT, 'chainer-vq-vae_amd'), str(tmp_path))
+    env = dict(os.environ, VQVAE_RDZV_ID='test_rdzv_%d' % os.getpid(), XDG_RUNTIME_DIR=str(tmp_path), WORLD_SIZE='8')
+    # a stale file with this job's key, three minutes old: must be ignored until rank 0 replaces it
+    from vqvae_amd import comm
+    old_env = {k: os.environ.get(k) for k in ('VQVAE_RDZV_ID', 'XDG_RUNTIME_DIR')}
+    os.environ.update(VQVAE_RDZV_ID=env['VQVAE_RDZV_ID'], XDG_RUNTIME_DIR=env['XDG_RUNTIME_DIR'])
+    try:
+        stale = comm._rendezvous_path()
+        comm._publish(stale, b'\xff' * 128)
+        os.utime(stale, (time.time() - 180, time.time() - 180))
+    finally:
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    procs = [subprocess.Popen([sys.executable, '-c', code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in (3, 5, 1, 7, 2, 6, 4)]          # the readers first ...
+    time.sleep(0.5)
+    procs.append(subprocess.Popen([sys.executable, '-c', code], env=dict(env, RANK='0', LOCAL_RANK='0')))   # ... rank 0 last
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    for r in range(8):
+        assert open(os.path.join(str(tmp_path), 'got_%d' % r), 'rb').read() == want, r
+
+
+def test_numa_helpers_never_raise():
+    from vqvae_amd import comm
+    assert comm.gpu_numa_node('ffff:ff:1f.7') is None
+    out = comm.bind_to_numa_node(None)
+    assert out['numa_node'] is None and out['mempolicy'] is None
