@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
 
   // LEAN (256 x 128 tiles, two taps, NP >= 2): the loop in 128 VGPRs, so that TWO 8-wave workgroups share a
   // CU and one tile's epilogue -- 13 % of the gate kernel's time with nothing beside it
-  // (tools/abl_gate.sh) -- runs beside the other's K loop.  What it gives up against the loop below: the
+  // (profiles/r3/abl_gate_epilogue.txt) -- runs beside the other's K loop.  What it gives up against the loop below: the
   // weights (L2-resident) are fetched ONE step ahead into a single register set, only the activations two;
   // the A fragments of one 32-row block at a time.
   constexpr bool LEAN = (NB == 1 && NP >= 2 && TAP2 && WM == 4 && X3_LEAN);

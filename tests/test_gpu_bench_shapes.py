@@ -3,7 +3,7 @@
 launch_gemm picks its tile shape from the launch size: the 256 x 256-column `conv_gemm_x3_kernel<...,
 NB = 2, ...>` (gate kernel, backward-data of the dilated conv) only runs when a launch has >= 256 such
 tiles, i.e. B >= 9 at T = 7680, and the streaming `lin128_stream_kernel` (the K = 128 residual
-projection) / `dilconv` window kernels are chosen from the channel counts of configs[1].  Every
+projection) / two-tap kernels are chosen from the channel counts of configs[1].  Every
 oracle-compared case of test_gpu_kernels.py has B <= 3, so until round 3 those instantiations were
 pinned only transitively (batch independence, shard sums).  Here: ResidualBlock.__call__
 (modules.py:30-56) and the ResidualNet chain (modules.py:89-96) at B = 16, T = 7680, 256 channels
@@ -237,25 +237,27 @@ print('HASH', h.hexdigest())
 
 @pytest.mark.parametrize('dil', [1, 64])
 def test_two_tap_kernels_agree_bitwise(gpu, tmp_path, dil):
-    """The three kernels a two-tap contraction can run on -- the 256 x 128-tile loop with two workgroups per CU (the
-    default in the six-product mode), conv_win_x3_kernel (one staged window for both taps) and the tap-interleaved
-    256 x 256-tile conv_gemm_x3_kernel -- keep one K order and one product order: forward and backward-data of the
-    dilated conv at B = 9, T = 7680 must not differ in a single bit whichever the launch picks (the selecting
-    switches are read once per process: one subprocess each)."""
+    """The two kernels a two-tap contraction of a 256-row GEMM can run on -- the 256 x 128-tile loop with two workgroups
+    per CU (the default wherever an operand has two or more pieces) and the tap-interleaved 256 x 256-tile
+    conv_gemm_x3_kernel (VQVAE_X3_LEAN=0, kept as the A/B alternate) -- keep one K order and one product order:
+    forward and backward-data of the dilated conv at B = 9, T = 7680 must not differ in a single bit whichever the
+    launch picks, in the default matmul mode and in 'float32x3' (the selecting switch is read once per process: one
+    subprocess each).  (Round 3's third kernel, one staged window for both taps, measured neutral and was removed.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'win_worker.py'
     script.write_text(_WIN_WORKER)
-    out = []
-    for lean, win in (('1', '1'), ('0', '1'), ('0', '0')):
-        env = dict(os.environ, VQVAE_X3_LEAN=lean, VQVAE_X3_WIN=win)
-        r = subprocess.run([sys.executable, str(script), root, str(dil)], env=env, stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=600)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        out.append([l for l in r.stdout.decode().splitlines() if l.startswith('HASH')][0])
-    assert out[0] == out[1] == out[2]
+    for mode in ('float32x2', 'float32x3'):
+        out = []
+        for lean in ('1', '0'):
+            env = dict(os.environ, VQVAE_X3_LEAN=lean, VQVAE_MATMUL=mode)
+            r = subprocess.run([sys.executable, str(script), root, str(dil)], env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=600)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            out.append([l for l in r.stdout.decode().splitlines() if l.startswith('HASH')][0])
+        assert out[0] == out[1], mode
 
 
 _LIN_WORKER = r"""

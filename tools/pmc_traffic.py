@@ -18,9 +18,7 @@ sys.path.insert(0, ROOT)
 
 
 def mean_of(path, pat, col):
-    """Dispatch-weighted mean of `col` over the kernels matching any of the '|'-separated patterns (the
-    gate launches of a step are served by two kernels: the single-window one for dilations <= 128 and the
-    tap-interleaved one for the rest)."""
+    """Dispatch-weighted mean of `col` over the kernels matching any of the '|'-separated patterns."""
     pats = pat.split('|')
     tot, n = 0.0, 0
     with open(path) as f:

@@ -3,7 +3,7 @@
 #   kernel-trace stats of bench.py for c2 (default), c4, c5 --bf16, and separate --pmc passes
 #   (FETCH_SIZE / WRITE_SIZE / MFMA busy / instruction mix) for the dominant kernel of each.
 # usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
@@ -20,17 +20,20 @@ run_pmc() {     # name, counters, bench args...
   timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pp_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > /tmp/pp_$name.log 2>&1 || echo "pmc pass $name failed"
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pp_$name > $OUT/${name}.csv
 }
-run_stats c2 --steps 10 --warmup 3
-run_stats c2_two_streams --steps 10 --warmup 3 --overlap
-run_stats c2_fp32mfma --steps 10 --warmup 3 --matmul float32
+# (--no-graph: eager launches, so that bench.py's own per-launch events and rocprofv3 time the same dispatches;
+#  --no-fresh-input: one timed region = `steps + warmup` steps in the stats)
+run_stats c2 --steps 10 --warmup 3 --no-graph --no-fresh-input
+run_stats c2_graph --steps 10 --warmup 3 --no-fresh-input
+run_stats c2_x3 --steps 10 --warmup 3 --no-graph --no-fresh-input --matmul float32x3
+run_stats c2_fp32mfma --steps 10 --warmup 3 --no-graph --no-fresh-input --matmul float32
 run_stats c4 --workload c4 --steps 5 --warmup 2
 run_stats c4_N1920 --workload c4 --vq-rows 1920 --steps 20 --warmup 3
 run_stats c5_bf16 --workload c5 --bf16 --steps 5 --warmup 2
 run_stats c5_fp32 --workload c5 --steps 5 --warmup 2
-run_pmc c2_pmc_FETCH_SIZE FETCH_SIZE --steps 2 --warmup 1
-run_pmc c2_pmc_WRITE_SIZE WRITE_SIZE --steps 2 --warmup 1
-run_pmc c2_pmc_MFMA "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" --steps 2 --warmup 1
-run_pmc c2_pmc_INSTS "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" --steps 2 --warmup 1
+run_pmc c2_pmc_FETCH_SIZE FETCH_SIZE --steps 2 --warmup 1 --no-graph --no-fresh-input
+run_pmc c2_pmc_WRITE_SIZE WRITE_SIZE --steps 2 --warmup 1 --no-graph --no-fresh-input
+run_pmc c2_pmc_MFMA "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" --steps 2 --warmup 1 --no-graph --no-fresh-input
+run_pmc c2_pmc_INSTS "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" --steps 2 --warmup 1 --no-graph --no-fresh-input
 run_pmc c4_pmc_FETCH_SIZE FETCH_SIZE --workload c4 --steps 2 --warmup 1
 run_pmc c4_pmc_WRITE_SIZE WRITE_SIZE --workload c4 --steps 2 --warmup 1
 run_pmc c4_pmc_MFMA "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload c4 --steps 2 --warmup 1
