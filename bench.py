@@ -457,7 +457,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     n = world
-    affinity = pin_rank_to_cores(local, n)
+    try:
+        cpus_at_start = set(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus_at_start = None
+    affinity = pin_rank_to_cores(local, n)       # (replaced below by the GPU's NUMA node when sysfs names one)
     if args.scaling == 'strong':
         if 128 % n:
             raise SystemExit('bench.py: --scaling strong splits a global batch of 128: --gpus must divide it')
@@ -476,7 +480,7 @@ def main():
         from vqvae_amd.comm import bind_to_numa_node, gpu_numa_node
         bus = C.create_string_buffer(32)
         if _lib.load().vqvae_device_pci_bus_id(bus, 32) == 0:
-            numa = bind_to_numa_node(gpu_numa_node(bus.value.decode()))
+            numa = bind_to_numa_node(gpu_numa_node(bus.value.decode()), cpus_at_start)
             numa['pci_bus_id'] = bus.value.decode()
     args.overlap_comm = (args.overlap_comm or n > 1) and not args.no_overlap_comm
     if args.bf16:

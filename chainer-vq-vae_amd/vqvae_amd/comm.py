@@ -137,10 +137,11 @@ def gpu_numa_node(pci_bus_id):
         return None
 
 
-def bind_to_numa_node(node):
+def bind_to_numa_node(node, allowed_cpus=None):
     """Prefer ``node`` for this process's future page allocations (set_mempolicy(MPOL_PREFERRED)) and run on its
-    cores: the page-locked input buffers and the Python heap of a rank then live next to its GPU.  Returns a dict
-    describing what was done (for the bench line); never raises."""
+    cores (``allowed_cpus``: the set to choose from, default the current affinity): the page-locked input buffers and
+    the Python heap of a rank then live next to its GPU.  Returns a dict describing what was done (for the bench
+    line); never raises."""
     out = {'numa_node': node, 'mempolicy': None, 'cpus': None}
     if node is None:
         return out
@@ -150,7 +151,7 @@ def bind_to_numa_node(node):
             for part in fh.read().strip().split(','):
                 a, _, b = part.partition('-')
                 cpus.update(range(int(a), int(b or a) + 1))
-        allowed = cpus & set(os.sched_getaffinity(0))
+        allowed = cpus & set(allowed_cpus if allowed_cpus is not None else os.sched_getaffinity(0))
         if allowed:
             os.sched_setaffinity(0, allowed)
             out['cpus'] = [min(allowed), max(allowed), len(allowed)]
