@@ -2522,6 +2522,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
   const int ntiles_all = a.ntile_m * a.ntile_n * a.B;
   const long total = (long)ntiles_all * (128 * 128);
+  float am = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i % (128 * 128));
     const int tile_id = (int)(i / (128 * 128));
@@ -2541,8 +2542,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
     float* yp = od.y + (long)b * od.y_bstride + off;
     if (od.accumulate) v += *yp;
     if (od.relu) v = fmaxf(v, 0.f);
+    am = fmaxf(am, fabsf(v));
     *yp = v;
   }
+  if (a.out[0].amax_out != nullptr) amax_commit(am, a.out[0].amax_out);
 }
 
 // split-K plan for a small-grid, long-K linear GEMM (see GemmArgs::ksplit); 1 = no split
@@ -2592,7 +2595,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   int nk = 0;
   for (int i = 0; i < g.nseg; ++i) nk += cdiv(g.seg[i].cin, BK);
   g.ksplit = 1;
-  if (EPI == EPI_LINEAR && !big && g.partial != nullptr && g.out[0].amax_out == nullptr) {
+  if (EPI == EPI_LINEAR && !big && g.partial != nullptr) {      // (a requested max |y| is then published by the reduce kernel)
     const int sp = plan_ksplit(g.M, g.Tout, g.B, nk);
     if (sp > 1) { g.ksplit = sp; g.ksteps_per_split = cdiv(nk, sp); }
   }
@@ -3000,15 +3003,29 @@ static unsigned* conv_amax_slots(const vqvae_conv1d_desc* d, void* ws) {
   return reinterpret_cast<unsigned*>((char*)ws + vqvae_conv1d_workspace_bytes(d) - 2 * AMAX_SLOTS * sizeof(unsigned));
 }
 
+static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const float* W, const float* b, float* y,
+                           void* ws, size_t ws_bytes, const int32_t* skip_flag, const vqvae_conv1d_amax* cam,
+                           vqvae_stream_t s);
 extern "C" int vqvae_conv1d_fwd(const vqvae_conv1d_desc* d, const float* x, const float* W,
                                 const float* b, float* y, void* ws, size_t ws_bytes,
                                 vqvae_stream_t s) {
-  return vqvae_conv1d_fwd_cond(d, x, W, b, y, ws, ws_bytes, nullptr, s);
+  return conv1d_fwd_impl(d, x, W, b, y, ws, ws_bytes, nullptr, nullptr, s);
 }
-
 extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x, const float* W,
                                      const float* b, float* y, void* ws, size_t ws_bytes,
                                      const int32_t* skip_flag, vqvae_stream_t s) {
+  return conv1d_fwd_impl(d, x, W, b, y, ws, ws_bytes, skip_flag, nullptr, s);
+}
+extern "C" int vqvae_conv1d_fwd_amax(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                                     const float* b, float* y, void* ws, size_t ws_bytes,
+                                     const vqvae_conv1d_amax* amax, vqvae_stream_t s) {
+  return conv1d_fwd_impl(d, x, W, b, y, ws, ws_bytes, nullptr, amax, s);
+}
+extern "C" int vqvae_conv1d_uses_f32x2(const vqvae_conv1d_desc* d) { return (d && conv_f16x2(d)) ? 1 : 0; }
+
+static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const float* W, const float* b, float* y,
+                           void* ws, size_t ws_bytes, const int32_t* skip_flag, const vqvae_conv1d_amax* cam,
+                           vqvae_stream_t s) {
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(x && W && y && ws, "conv1d_fwd: null pointer");
   hipStream_t st = (hipStream_t)s;
@@ -3017,8 +3034,10 @@ extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x,
   float* pk = (float*)ws;
   const bool f16 = conv_f16x2(d) && skip_flag == nullptr && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
   unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
-  if (f16) {
-    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
+  const unsigned* xam = am;          // the operand's maximum: the caller's (it travelled with the tensor) or a scan
+  if (f16 && cam && cam->x) xam = cam->x;
+  else if (f16) {
+    VQ_CHECK_HIP(hipMemsetAsync(am, 0, AMAX_SLOTS * sizeof(unsigned), st));
     if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
   }
   PackArgs pa; pa.njob = 1;
@@ -3033,11 +3052,12 @@ extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x,
     sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
     sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
-    if (f16) { sg.amax = am; sg.wamax = am + AMAX_SLOTS; }
+    if (f16) { sg.amax = xam; sg.wamax = am + AMAX_SLOTS; }
   }
   g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
   g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
   g.out[0].bias = b; g.out[0].relu = d->relu;
+  g.out[0].amax_out = cam ? cam->out : nullptr;
   g.skip_flag = skip_flag;
   {
     const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
@@ -3047,9 +3067,20 @@ extern "C" int vqvae_conv1d_fwd_cond(const vqvae_conv1d_desc* d, const float* x,
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_FWD, st);
 }
 
+static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, const float* gy, float* gx, int accumulate,
+                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s);
 extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const float* gy,
                                      float* gx, int accumulate, void* ws, size_t ws_bytes,
                                      vqvae_stream_t s) {
+  return conv1d_bwd_data_impl(d, W, gy, gx, accumulate, ws, ws_bytes, nullptr, s);
+}
+extern "C" int vqvae_conv1d_bwd_data_amax(const vqvae_conv1d_desc* d, const float* W, const float* gy,
+                                          float* gx, int accumulate, void* ws, size_t ws_bytes,
+                                          const vqvae_conv1d_amax* amax, vqvae_stream_t s) {
+  return conv1d_bwd_data_impl(d, W, gy, gx, accumulate, ws, ws_bytes, amax, s);
+}
+static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, const float* gy, float* gx, int accumulate,
+                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s) {
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(W && gy && gx && ws, "conv1d_bwd_data: null pointer");
   hipStream_t st = (hipStream_t)s;
@@ -3058,8 +3089,10 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
   float* pk = (float*)ws;
   const bool f16 = conv_f16x2(d) && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
   unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
-  if (f16) {
-    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
+  const unsigned* gam = am;
+  if (f16 && cam && cam->gy) gam = cam->gy;
+  else if (f16) {
+    VQ_CHECK_HIP(hipMemsetAsync(am, 0, AMAX_SLOTS * sizeof(unsigned), st));
     if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am, st)) return e;
   }
   PackArgs pa; pa.njob = 1;
@@ -3075,11 +3108,12 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
     // t_out(gy) = (u + pad - j*dil) / stride
     sg.tmul = 1; sg.toff = d->pad - j * d->dil; sg.tdiv = d->stride;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
-    if (f16) { sg.amax = am; sg.wamax = am + AMAX_SLOTS; }
+    if (f16) { sg.amax = gam; sg.wamax = am + AMAX_SLOTS; }
   }
   g.M = d->Cin; g.Tout = d->Tin; g.B = d->B;
   g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;
   g.out[0].accumulate = accumulate;
+  g.out[0].amax_out = cam ? cam->out : nullptr;
   {
     const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
     const size_t need = ksplit_partial_floats(d->Cin, d->Tin, d->B, d->K * cdiv(d->Cout, BK)) * sizeof(float);
@@ -3088,16 +3122,28 @@ extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W,
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_CONV_BWD_DATA, st);
 }
 
+static int conv1d_bwd_weight_impl(const vqvae_conv1d_desc* d, const float* x, const float* gy, float* gW, float* gb,
+                                  int accumulate, void* ws, size_t ws_bytes, const int32_t* skip_flag,
+                                  const vqvae_conv1d_amax* cam, vqvae_stream_t s);
 extern "C" int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                                        float* gW, float* gb, int accumulate, void* ws,
                                        size_t ws_bytes, vqvae_stream_t s) {
-  return vqvae_conv1d_bwd_weight_cond(d, x, gy, gW, gb, accumulate, ws, ws_bytes, nullptr, s);
+  return conv1d_bwd_weight_impl(d, x, gy, gW, gb, accumulate, ws, ws_bytes, nullptr, nullptr, s);
 }
-
 extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                                             float* gW, float* gb, int accumulate, void* ws,
                                             size_t ws_bytes, const int32_t* skip_flag,
                                             vqvae_stream_t s) {
+  return conv1d_bwd_weight_impl(d, x, gy, gW, gb, accumulate, ws, ws_bytes, skip_flag, nullptr, s);
+}
+extern "C" int vqvae_conv1d_bwd_weight_amax(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                                            float* gW, float* gb, int accumulate, void* ws,
+                                            size_t ws_bytes, const vqvae_conv1d_amax* amax, vqvae_stream_t s) {
+  return conv1d_bwd_weight_impl(d, x, gy, gW, gb, accumulate, ws, ws_bytes, nullptr, amax, s);
+}
+static int conv1d_bwd_weight_impl(const vqvae_conv1d_desc* d, const float* x, const float* gy, float* gW, float* gb,
+                                  int accumulate, void* ws, size_t ws_bytes, const int32_t* skip_flag,
+                                  const vqvae_conv1d_amax* cam, vqvae_stream_t s) {
   if (int e = check_conv_desc(d)) return e;
   VQ_REQUIRE(x && gy && gW && ws, "conv1d_bwd_weight: null pointer");
   hipStream_t st = (hipStream_t)s;
@@ -3139,11 +3185,20 @@ extern "C" int vqvae_conv1d_bwd_weight_cond(const vqvae_conv1d_desc* d, const fl
   w.skip_flag = skip_flag;
   if (conv_f16x2(d) && !phases && d->stride == 1 && skip_flag == nullptr && ws_bytes >= vqvae_conv1d_workspace_bytes(d)) {
     unsigned* am = conv_amax_slots(d, ws);
-    VQ_CHECK_HIP(hipMemsetAsync(am, 0, 2 * AMAX_SLOTS * sizeof(unsigned), st));
-    if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
-    if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am + AMAX_SLOTS, st)) return e;
-    w.f16x2 = 1; w.amax_gy = am + AMAX_SLOTS;
-    for (int j = 0; j < d->K; ++j) w.seg[j].amax_x = am;
+    const unsigned* xam = am;
+    const unsigned* gam = am + AMAX_SLOTS;
+    if (cam && cam->x) xam = cam->x;
+    else {
+      VQ_CHECK_HIP(hipMemsetAsync(am, 0, AMAX_SLOTS * sizeof(unsigned), st));
+      if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
+    }
+    if (cam && cam->gy) gam = cam->gy;
+    else {
+      VQ_CHECK_HIP(hipMemsetAsync(am + AMAX_SLOTS, 0, AMAX_SLOTS * sizeof(unsigned), st));
+      if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am + AMAX_SLOTS, st)) return e;
+    }
+    w.f16x2 = 1; w.amax_gy = gam;
+    for (int j = 0; j < d->K; ++j) w.seg[j].amax_x = xam;
   }
   return launch_wgrad(w, p, (float*)ws, VQVAE_PROF_CONV_WGRAD, st);
 }
@@ -3592,7 +3647,7 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
 extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                                        const float* const* Ws, const float* const* bs,
                                        const float* const* z, float* skip, int accumulate,
-                                       void* ws, size_t ws_bytes, vqvae_stream_t s) {
+                                       void* ws, size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_fwd: 1..%d blocks", MAXSEG);
   VQ_REQUIRE(Ws && bs && z && skip && ws, "resstack_skip_fwd: null pointer");
@@ -3629,6 +3684,7 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   g.out[0].y = skip; g.out[0].y_bstride = (long)d->Cs * T; g.out[0].rows = d->Cs;
   g.out[0].bias = bsum;
   g.out[0].accumulate = accumulate;
+  g.out[0].amax_out = skip_amax_out;
   g.z16 = z_bf16(d) ? 1 : 0;
   g.x_nt = X3_SKIP_X_NT;
   return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st);

@@ -42,6 +42,11 @@ class ResblockAmax(C.Structure):
     _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx')]
 
 
+class Conv1dAmax(C.Structure):
+    """vqvae_conv1d_amax"""
+    _fields_ = [(n, P) for n in ('x', 'gy', 'out')]
+
+
 class ResblockGrads(C.Structure):
     _fields_ = [(n, P) for n in ('gWd', 'gbd', 'gWc', 'gbc', 'gWr', 'gbr', 'gWs', 'gbs')]
 
@@ -104,6 +109,11 @@ PROTOTYPES = {
     'vqvae_conv1d_fwd': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, P]),
     'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),
     'vqvae_conv1d_bwd_weight': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P]),
+    'vqvae_conv1d_uses_f32x2': (c_int, [C.POINTER(Conv1dDesc)]),
+    'vqvae_conv1d_fwd_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, C.POINTER(Conv1dAmax), P]),
+    'vqvae_conv1d_bwd_data_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, C.POINTER(Conv1dAmax), P]),
+    'vqvae_conv1d_bwd_weight_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t,
+                                             C.POINTER(Conv1dAmax), P]),
     'vqvae_resblock_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc)]),
     'vqvae_resblock_fwd': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P,
                                    C.POINTER(ResblockCproj), P, P, c_int, P, P, P, c_size_t, P]),
@@ -121,7 +131,7 @@ PROTOTYPES = {
                                           P, P, P, P, P, c_size_t, P, C.POINTER(ResblockAmax), P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
-                                        c_size_t, P]),
+                                        c_size_t, P, P]),
     'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
                                          c_size_t, P]),
     'vqvae_resstack_skip_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, P, PP, PP, PP, c_int, P,

@@ -281,9 +281,12 @@ def memory_stats():
 class DeviceArray(object):
     """A contiguous device buffer with NumPy-like metadata (the ``xp.ndarray``
     of this backend).  Views share the owning block."""
-    __slots__ = ('ptr', 'shape', 'dtype', '_block', '__weakref__')
+    __slots__ = ('ptr', 'shape', 'dtype', '_block', 'amax', '__weakref__')
 
     def __init__(self, shape, dtype=np.float32, _block=None, _ptr=None):
+        # matmul mode 'float32x2': the tensor's absolute maximum (an upper bound will do), when a producer published
+        # it -- a DeviceArray of _lib.AMAX_SLOTS uint32 (see vqvae_absmax); travels with views, dropped by writes
+        self.amax = None
         if isinstance(shape, int):
             shape = (shape,)
         self.shape = tuple(int(s) for s in shape)
@@ -333,7 +336,9 @@ class DeviceArray(object):
             n *= s
         if n != self.size:
             raise ValueError('cannot reshape %s into %s' % (self.shape, tuple(shape)))
-        return DeviceArray(tuple(shape), self.dtype, _block=self._block, _ptr=self.ptr)
+        out = DeviceArray(tuple(shape), self.dtype, _block=self._block, _ptr=self.ptr)
+        out.amax = self.amax
+        return out
 
     def flat_view(self, offset, size, shape=None):
         """View of ``size`` elements starting ``offset`` elements in."""
@@ -348,6 +353,7 @@ class DeviceArray(object):
         if host.size != self.size:
             raise ValueError('size mismatch in DeviceArray.set: %s vs %s' % (host.shape, self.shape))
         _lib.call('vqvae_memcpy_h2d', self.ptr, host.ctypes.data, self.nbytes, stream())
+        self.amax = None
         return self
 
     def get(self):
@@ -364,16 +370,33 @@ class DeviceArray(object):
         if other.nbytes != self.nbytes:
             raise ValueError('size mismatch in copy_from')
         _lib.call('vqvae_memcpy_d2d', self.ptr, other.ptr, self.nbytes, stream())
+        self.amax = getattr(other, 'amax', None)
         return self
 
     def fill_zero(self):
         _lib.call('vqvae_memset', self.ptr, 0, self.nbytes, stream())
+        self.amax = None
         return self
 
     def __float__(self):
         if self.size != 1:
             raise TypeError('only size-1 arrays convert to float')
         return float(self.get().reshape(()))
+
+
+def new_amax():
+    """A zeroed group of absolute-maximum words for a launch's epilogue to raise (vqvae_conv1d_amax.out, ...)."""
+    return zeros((_lib.AMAX_SLOTS,), np.uint32)
+
+
+def absmax(x):
+    """max |x| of a float32 device array as the device words matmul mode 'float32x2' passes around (one pass over x);
+    remembered on the array."""
+    if getattr(x, 'amax', None) is None:
+        a = DeviceArray((_lib.AMAX_SLOTS,), np.uint32)
+        _lib.call('vqvae_absmax', x.ptr, x.size, a.ptr, stream())
+        x.amax = a
+    return x.amax
 
 
 def to_device(host, dtype=None):

@@ -28,6 +28,7 @@ def _ew(op, a, b=None, out=None, alpha=0.0, beta=0.0, like=None):
     if out is None:
         out = DeviceArray(ref.shape, np.float32)
     _lib.call('vqvae_elementwise', op, out.size, _p(a), _p(b), out.ptr, alpha, beta, _S())
+    out.amax = None            # (a maximum published for an earlier content of `out` does not describe this one)
     return out
 
 
@@ -152,11 +153,14 @@ class ReLU(FunctionNode):
     def forward(self, inputs):
         backend.require_device(inputs[0])
         y = _ew(_lib.EW_RELU, inputs[0])
+        y.amax = getattr(inputs[0], 'amax', None)   # max |relu(x)| <= max |x|: an upper bound is all a scale needs
         self._y = y
         return y,
 
     def backward(self, indexes, gys):
-        return _ew(_lib.EW_RELU_BWD, gys[0].data, self._y),
+        gx = _ew(_lib.EW_RELU_BWD, gys[0].data, self._y)
+        gx.amax = getattr(gys[0].data, 'amax', None)
+        return gx,
 
 
 def add(a, b):
@@ -230,8 +234,17 @@ class Conv1dFunction(FunctionNode):
         y = DeviceArray((B, Cout, Tout, 1), np.float32)
         wsb = _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.desc))
         ws = backend.workspace(wsb)
-        _lib.call('vqvae_conv1d_fwd', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
-                  ws.nbytes, _S())
+        # 'float32x2', a launch large enough for the three-product kernels: the operand's maximum travels with it (or
+        # is found once and remembered on it for the backward), the result's is published by the epilogue
+        self._f32x2 = bool(_lib.load().vqvae_conv1d_uses_f32x2(C.byref(self.desc)))
+        if self._f32x2:
+            y.amax = backend.new_amax()
+            am = _lib.Conv1dAmax(backend.absmax(x).ptr, None, y.amax.ptr)
+            _lib.call('vqvae_conv1d_fwd_amax', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
+                      ws.nbytes, C.byref(am), _S())
+        else:
+            _lib.call('vqvae_conv1d_fwd', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
+                      ws.nbytes, _S())
         self.retain_inputs((0, 1))
         self._y = y if self.relu else None
         self._has_b = b is not None
@@ -242,14 +255,23 @@ class Conv1dFunction(FunctionNode):
         x, W = (v.data for v in self.get_retained_inputs())
         gy = gys[0].data
         if self.relu:
+            gy0 = gy
             gy = _ew(_lib.EW_RELU_BWD, gy, self._y)
+            gy.amax = getattr(gy0, 'amax', None)
         wsb = _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.desc))
         ws = backend.workspace(wsb)
+        f32x2 = self._f32x2 and bool(_lib.load().vqvae_conv1d_uses_f32x2(C.byref(self.desc)))
         gx = None
         if 0 in indexes:
             gx = DeviceArray(self._x_shape, np.float32)
-            _lib.call('vqvae_conv1d_bwd_data', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
-                      ws.ptr, ws.nbytes, _S())
+            if f32x2:
+                gx.amax = backend.new_amax()
+                am = _lib.Conv1dAmax(None, backend.absmax(gy).ptr, gx.amax.ptr)
+                _lib.call('vqvae_conv1d_bwd_data_amax', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
+                          ws.ptr, ws.nbytes, C.byref(am), _S())
+            else:
+                _lib.call('vqvae_conv1d_bwd_data', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
+                          ws.ptr, ws.nbytes, _S())
         gW = gb = None
         if 1 in indexes:
             wv = self.inputs[1]
@@ -259,8 +281,13 @@ class Conv1dFunction(FunctionNode):
                 bv = self.inputs[2]
                 buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
                 gb = buf if buf is not None else DeviceArray((self.desc.Cout,), np.float32)
-            _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.desc), x.ptr, gy.ptr, gW.ptr,
-                      _p(gb), 0, ws.ptr, ws.nbytes, _S())
+            if f32x2:
+                am = _lib.Conv1dAmax(backend.absmax(x).ptr, backend.absmax(gy).ptr, None)
+                _lib.call('vqvae_conv1d_bwd_weight_amax', C.byref(self.desc), x.ptr, gy.ptr, gW.ptr,
+                          _p(gb), 0, ws.ptr, ws.nbytes, C.byref(am), _S())
+            else:
+                _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.desc), x.ptr, gy.ptr, gW.ptr,
+                          _p(gb), 0, ws.ptr, ws.nbytes, _S())
         return (gx, gW, gb) if self._has_b else (gx, gW)
 
 

@@ -154,7 +154,10 @@ class ResidualStackFunction(FunctionNode):
             # epilogues raise the words of what they store (atomicMax), only the tensors that arrive from outside
             # are scanned
             self.amax = backend.zeros(((3 * nb + 1) * _lib.AMAX_SLOTS,), np.uint32)
-            _lib.call('vqvae_absmax', x.ptr, x.size, self.amax.ptr, _S())
+            if getattr(x, 'amax', None) is not None:     # it travelled with the tensor
+                _lib.call('vqvae_memcpy_d2d', self.amax.ptr, x.amax.ptr, 4 * _lib.AMAX_SLOTS, _S())
+            else:
+                _lib.call('vqvae_absmax', x.ptr, x.size, self.amax.ptr, _S())
         if self.lat is not None and PACK_ONCE:
             # every block's weight slabs (forward and backward forms), re-laid once for this step
             d0 = _rb_desc(x, cond, inputs[2], inputs[8], self.dilations[0])
@@ -197,6 +200,8 @@ class ResidualStackFunction(FunctionNode):
             h = res
         d = self.descs[0]
         skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
+        if self.amax is not None:
+            skip.amax = backend.new_amax()       # published by the skip sum's epilogue: the next conv's operand scale
         for lo, hi in _groups(nb):
             n = hi - lo
             ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), n))
@@ -204,7 +209,7 @@ class ResidualStackFunction(FunctionNode):
             bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(lo, hi)])
             zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
             _lib.call('vqvae_resstack_skip_fwd', C.byref(d), n, Ws, bs, zs, skip.ptr,
-                      0 if lo == 0 else 1, ws.ptr, ws.nbytes, _S())
+                      0 if lo == 0 else 1, ws.ptr, ws.nbytes, _p(skip.amax), _S())
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
 
@@ -221,7 +226,10 @@ class ResidualStackFunction(FunctionNode):
         nb = len(self.dilations)
         f16 = self.amax is not None
         if f16:
-            _lib.call('vqvae_absmax', g_skip.ptr, g_skip.size, self._slot(3 * nb), _S())
+            if getattr(g_skip, 'amax', None) is not None:
+                _lib.call('vqvae_memcpy_d2d', self._slot(3 * nb), g_skip.amax.ptr, 4 * _lib.AMAX_SLOTS, _S())
+            else:
+                _lib.call('vqvae_absmax', g_skip.ptr, g_skip.size, self._slot(3 * nb), _S())
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb

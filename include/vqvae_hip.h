@@ -148,6 +148,26 @@ int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const floa
 int vqvae_conv1d_bwd_weight(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                             float* gW, float* gb, int accumulate, void* ws,
                             size_t ws_bytes, vqvae_stream_t s);
+/* The same three with the operands' absolute maxima handed in and the result's handed out (matmul mode 3; groups of
+ * VQVAE_AMAX_SLOTS device words as vqvae_absmax writes them): a maximum that travels with its tensor saves the scan
+ * vqvae_conv1d_* would otherwise run over a large operand.  NULL members: scan (inputs) / not wanted (out; zeroed by
+ * the caller, raised with atomicMax by the launch's epilogue, any matmul mode).  vqvae_conv1d_uses_f32x2(d) says
+ * whether the launch is large enough to run the three-product kernels, i.e. whether handing maxima in matters. */
+typedef struct {
+  const uint32_t* x;     /* fwd, bwd_weight: max |x|   */
+  const uint32_t* gy;    /* bwd_data, bwd_weight: max |gy| */
+  uint32_t* out;         /* fwd: max |y|; bwd_data: max |gx| */
+} vqvae_conv1d_amax;
+int vqvae_conv1d_uses_f32x2(const vqvae_conv1d_desc* d);
+int vqvae_conv1d_fwd_amax(const vqvae_conv1d_desc* d, const float* x, const float* W,
+                          const float* b, float* y, void* ws, size_t ws_bytes,
+                          const vqvae_conv1d_amax* amax, vqvae_stream_t s);
+int vqvae_conv1d_bwd_data_amax(const vqvae_conv1d_desc* d, const float* W, const float* gy,
+                               float* gx, int accumulate, void* ws, size_t ws_bytes,
+                               const vqvae_conv1d_amax* amax, vqvae_stream_t s);
+int vqvae_conv1d_bwd_weight_amax(const vqvae_conv1d_desc* d, const float* x, const float* gy,
+                                 float* gW, float* gb, int accumulate, void* ws, size_t ws_bytes,
+                                 const vqvae_conv1d_amax* amax, vqvae_stream_t s);
 /* Device-side conditional forms: the whole launch is a no-op when skip_flag != NULL and
  * *skip_flag != 0 at execution time (skip_flag is a device pointer).  Used to pick between two
  * implementations of one operator by a flag computed on the device, without a host round trip
@@ -273,10 +293,11 @@ int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x, const flo
  *      gcond_bwd: gcond (B,Cc,T) (+)= sum_l Wc_l^T gh_l     -- one GEMM, K = nblocks*Cd
  *      skip_wgrad: gWs_l (+)= g_skip z_l^T, gbs_l (+)= rowsum(g_skip) for every l     */
 size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks);
+/*      skip_amax_out (nullable): max |skip| is raised there (VQVAE_AMAX_SLOTS zeroed words)         */
 int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                             const float* const* Ws, const float* const* bs,
                             const float* const* z, float* skip, int accumulate, void* ws,
-                            size_t ws_bytes, vqvae_stream_t s);
+                            size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s);
 int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* Wc, const float* const* gh, float* gcond,
                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
