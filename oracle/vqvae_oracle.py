@@ -341,6 +341,12 @@ def causal_conv_bwd(x, W, gh, dil, need_gx=True):
     return conv1d_bwd(x, W, g, stride=1, pad=pad, dil=dil, need_gx=need_gx)
 
 
+def gates_saved_as_bf16(Ch, Cr, Cs, T):
+    """The bf16 mode of the configs-sized blocks (BASELINE configs[4]) keeps the saved gate values tanh / sigmoid as
+    bf16 (csrc/conv_gemm.hip z_bf16 / GemmArgs::g16): same predicate, restated."""
+    return _BF16[0] and Ch == 128 and Cr == 256 and Cs % 256 == 0 and T % 64 == 0
+
+
 def resblock_fwd(p, x, cond, dil):
     """ResidualBlock.__call__ (modules.py:30-56), dropout_zero_rate == 0.
     p: conv (W (2*Ch... (Cd,Cr,K), b), condition_proj (W (Cd,Cc,1), b),
@@ -357,6 +363,8 @@ def resblock_fwd(p, x, cond, dil):
     z = ta * sb
     res = conv1d_fwd(z, Wr, br) + x                           # modules.py:52
     skip = conv1d_fwd(z, Ws, bs)                              # modules.py:55
+    if ta.dtype == np.float32 and gates_saved_as_bf16(Ch, Wr.shape[0], Ws.shape[0], x.shape[2]):
+        ta, sb = bf16_round(ta), bf16_round(sb)               # what the backward pass will differentiate
     return res, skip, (x, ta, sb, z)
 
 
