@@ -109,6 +109,8 @@ struct GemmArgs {
   int x_nt;      // the activations of every segment are read once by this launch and by nothing soon after (the skip sum over all blocks' z): non-temporal loads
   int f16x2;     // matmul mode 3: every segment carries its maxima and a format-3 slab -> the float32x2 kernels (NP = 2); otherwise mode 3 runs mode 2's
   int g16;       // matmul mode 1 only: the gate values (EPI_GATE: out[0]; EPI_GATE_BWD: out[0].add) are stored as bf16, the pair (tanh, sigmoid) of a (channel, t) as one dword in tanh's fp32 position
+  int x16;       // matmul mode 1 only: activations STORED as bf16 (conv_gemm_x3_kernel's X16 mask: bit 0 = segment 0 of a two-tap launch / every segment otherwise, bit 1 = the second segment of a two-tap launch)
+  int h16;       // matmul mode 1 only: EPI_GATE_BWD stores gh (out[0].y) as bf16 (same element strides, 2-byte elements)
   int z16;       // matmul mode 1 only: EPI_GATE writes z (out[1]) as bf16; a linear GEMM reads the activations of EVERY segment as bf16 (the z tensors)
 };
 
@@ -227,7 +229,9 @@ __device__ __forceinline__ void buf_st_gate(float v, rsrc_t r, unsigned voff, un
 // (rows m0 + wm*64 + mi*32, columns t0 + wn*64 + ni*32) of batch item b.  SPLITK: this instantiation
 // may have been launched with ksplit > 1 (raw partial tiles out, gemm_splitk_reduce_kernel finishes).
 // DEEP: the linear epilogue requests a whole block's operands up front (needs 64 more registers).
-template <int EPI, int WM, bool SPLITK, bool DEEP = false>
+// ST16: the instantiation may be asked for bf16-stored tensors (GemmArgs::g16 / h16 / z16: matmul mode 1's kernels only --
+// the other modes' kernels do not carry those paths: they cost the float32x2 gate-derivative kernel 24 spilled registers).
+template <int EPI, int WM, bool SPLITK, bool DEEP = false, bool ST16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
                                               const int b, const int wm, const int wn, const int li, const int lk,
                                               const int ksp, const int tile_id, const int ntiles_all) {
@@ -489,13 +493,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         if (tt[ni] >= T) continue;
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
-        if (a.g16) {     // BASELINE configs[4] precision: the saved gate values are bf16 (the backward pass reads exactly these): the pair (tanh, sigmoid) of one (channel, t) as ONE dword in tanh's fp32 position -- one store, and one load in the backward, instead of two
+        if (ST16 && a.g16) {     // BASELINE configs[4] precision: the saved gate values are bf16 (the backward pass reads exactly these): the pair (tanh, sigmoid) of one (channel, t) as ONE dword in tanh's fp32 position -- one store, and one load in the backward, instead of two
           __builtin_amdgcn_raw_buffer_store_b32((int)pack_bf16x2(ta, sb), rG, vT[ni], sT, X3_GATE_ST_AUX);
         } else {
           buf_st_gate(ta, rG, vT[ni], sT);
           buf_st_gate(sb, rG, vT[ni], sT + sGq);
         }
-        if (a.z16) __builtin_amdgcn_raw_buffer_store_b16((short)(pack_bf16x2(ta * sb, 0.f) & 0xffffu), rZ, vT[ni] >> 1, sT >> 1, 0);
+        if (ST16 && a.z16) __builtin_amdgcn_raw_buffer_store_b16((short)(pack_bf16x2(ta * sb, 0.f) & 0xffffu), rZ, vT[ni] >> 1, sT >> 1, 0);
         else buf_st_gate(ta * sb, rZ, vT[ni], sT);
       }
     }
@@ -550,29 +554,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
               }
         }
       };
-      if (a.g16) load_gates(std::true_type{}); else load_gates(std::false_type{});
+      if (ST16 && a.g16) load_gates(std::true_type{}); else load_gates(std::false_type{});
+      auto store_gh = [&](auto h16c) {         // (ONE wave-uniform branch around the whole store loop, as for the loads)
+        constexpr bool H16 = decltype(h16c)::value;
+        // H16 (GemmArgs::h16): gh is read back only as an MFMA operand (backward-data, weight gradient), i.e. rounded
+        // to bf16 -- and by the bias sum and the latent pull-back, which then see the rounded values (the oracle's bf16
+        // mode mirrors that): stored as bf16, same element strides
+        const rsrc_t rGh16 = make_rsrc(reinterpret_cast<const char*>(od.y) + (long)b * od.y_bstride * 2);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int t = t0 + wn * 64 + ni * 32 + li;
-          const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
-          const bool tok = t < T;
-          const unsigned voff = 4u * (unsigned)(mb * T + t);
+          for (int ni = 0; ni < 2; ++ni) {
+            const int t = t0 + wn * 64 + ni * 32 + li;
+            const int mb = m0 + wm * 64 + mi * 32 + 4 * lk;
+            const bool tok = t < T;
+            const unsigned voff = 4u * (unsigned)(mb * T + t);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            if (tok && mb + dr < Ch) {
-              const float gz = acc[mi][ni][r];
-              const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
-              const unsigned so = 4u * (unsigned)(dr * T);
-              const float ga = gz * sv * (1.f - tv * tv), gb = gz * tv * sv * (1.f - sv);
-              am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ga), rGh, voff, so, X3_GBWD_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gb), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
+            for (int r = 0; r < 16; ++r) {
+              const int dr = (r & 3) + 8 * (r >> 2);
+              if (tok && mb + dr < Ch) {
+                const float gz = acc[mi][ni][r];
+                const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
+                const unsigned so = 4u * (unsigned)(dr * T);
+                const float ga = gz * sv * (1.f - tv * tv), gb = gz * tv * sv * (1.f - sv);
+                if constexpr (H16) {
+                  const unsigned pr = pack_bf16x2(ga, gb);
+                  __builtin_amdgcn_raw_buffer_store_b16((short)(pr & 0xffffu), rGh16, voff >> 1, so >> 1, X3_GBWD_ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b16((short)(pr >> 16), rGh16, voff >> 1, (so + sQ) >> 1, X3_GBWD_ST_AUX);
+                } else {
+                  am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ga), rGh, voff, so, X3_GBWD_ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gb), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
+                }
+              }
             }
           }
-        }
+      };
+      if (ST16 && a.h16) store_gh(std::true_type{}); else store_gh(std::false_type{});
     } else {                    // the fp32 MFMA kernel runs four waves per SIMD (128 VGPRs): one sub-tile's gate values at a time
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -975,13 +993,17 @@ __device__ __forceinline__ f32x16 mfma_chain(const uint4 (&a)[NP], const uint4 (
 #ifndef X3_LEAN
 #define X3_LEAN 1             // 256 x 128 tiles, two taps, NP >= 2: the 128-VGPR loop below (two 8-wave workgroups per CU)
 #endif
-// X16 (matmul mode 1, linear GEMMs over the z tensors): the activations of every segment are stored as bf16
-// (GemmArgs::z16): fetched with 2-byte loads and staged without a conversion.
-template <int EPI, int WM, int NB, int NP, bool TAP2 = false, bool X16 = false>
+// X16 (matmul mode 1): activations that are STORED as bf16 (GemmArgs::z16 / x16) are fetched with 2-byte loads and
+// staged without a conversion.  Bit 0: segment 0 of a TAP2 launch / every segment of any other launch; bit 1: the
+// second segment of a TAP2 launch (the two may differ: g_res fp32 | g_skip bf16 in the gate-derivative GEMM).
+template <int EPI, int WM, int NB, int NP, bool TAP2 = false, int X16 = 0>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
-  static_assert(!X16 || (NP == 1 && !TAP2 && EPI == EPI_LINEAR), "bf16-stored activations: mode 1 linear GEMMs only");
-  constexpr unsigned ESZ = X16 ? 2u : 4u;               // bytes per activation element
+  static_assert(X16 == 0 || NP == 1, "bf16-stored activations: mode 1 only");
+  static_assert(X16 >= 0 && X16 <= (TAP2 ? 3 : 1), "X16: one bit per TAP2 segment, one bit otherwise");
+  constexpr bool RAW0 = (X16 & 1) != 0, RAW1 = TAP2 ? (X16 & 2) != 0 : RAW0;
+  constexpr unsigned ESZ = RAW0 ? 2u : 4u, ESZ1 = RAW1 ? 2u : 4u;     // bytes per activation element (segment 0 / TAP2's segment 1)
+  [[maybe_unused]] auto of_seg1 = [](unsigned v) -> unsigned { return ESZ1 == ESZ ? v : (ESZ1 > ESZ ? v << 1 : v >> 1); };   // a byte offset of segment 0 -> the same element of segment 1
   static_assert(NP >= 1 && NP <= 3, "one piece (bf16 operands), two (fp16 hi + lo, scaled) or three (exact bf16 split)");
   constexpr int SCHED = (WM == 4 && NB == 1 && NP == 3) ? 3 : 0;   // MFMA : VALU interleave of the main loop (A/B at configs[1]: 256-row tiles -3 %, 128-row tiles +2 %)
   constexpr int BM = 64 * WM, NT = 128 * WM, BNW = BN * NB;
@@ -1062,13 +1084,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   unsigned sw = 0, sx = 0, sw1 = 0;          // wave-uniform byte offsets of the next step (TAP2: sw1 = tap 1's slab)
   unsigned wl2b = 0, wadvb = 0, xcsb = 0, xadvb = 0;
   constexpr unsigned OOB = 0x80000000u;      // beyond any extent: the load returns 0
-  auto col_offset = [&](const Seg& sg) -> unsigned {       // byte offset of this thread's column in channel s_c of a step
+  auto col_offset = [&](const Seg& sg, const unsigned esz) -> unsigned {       // byte offset of this thread's column in channel s_c of a step
     const int tnum = (t0 + s_n) * sg.tmul + sg.toff;
     bool ok = tnum >= 0;
     int tin = tnum;
     if (sg.tdiv > 1) { ok = ok && (tnum % sg.tdiv == 0); tin = tnum / sg.tdiv; }
     ok = ok && tin < sg.Tin;
-    return ok ? ESZ * (unsigned)(s_c * sg.x_cstride + tin) : OOB;
+    return ok ? esz * (unsigned)(s_c * sg.x_cstride + tin) : OOB;
   };
   auto seg_setup = [&](int s, int skip) {
     const Seg& sg = a.seg[s];
@@ -1079,7 +1101,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(sg.x) + (long)b * sg.x_bstride * ESZ), 0,
                                            (int)(ESZ * (unsigned)sg.cin * (unsigned)sg.x_cstride), 0x00020000);
     va = 16u * (unsigned)(a_hi * sg.ldw + m0 + a_m);
-    vb = col_offset(sg);
+    vb = col_offset(sg, ESZ);
     sw = (unsigned)skip * wadvb; sx = (unsigned)skip * xadvb;
     if constexpr (NP == 2) kcur = seg_kx(s);
   };
@@ -1094,10 +1116,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     seg_setup(s, skip);
     if constexpr (TAP2) {                    // both segments start at channel 0 and advance together
       const Seg& s1 = a.seg[1];
-      vb1 = col_offset(s1);
+      vb1 = col_offset(s1, ESZ1);
       sw1 = (unsigned)(reinterpret_cast<const char*>(s1.w) - reinterpret_cast<const char*>(a.seg[0].w));
-      rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s1.x + (long)b * s1.x_bstride), 0,
-                                              (int)(4u * (unsigned)s1.cin * (unsigned)s1.x_cstride), 0x00020000);
+      rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(s1.x) + (long)b * s1.x_bstride * ESZ1), 0,
+                                              (int)(ESZ1 * (unsigned)s1.cin * (unsigned)s1.x_cstride), 0x00020000);
       if constexpr (NP == 2) k1 = seg_kx(1);
     }
   }
@@ -1115,14 +1137,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
 
   // staging of one K step's activations: split (or round) this thread's CPT channels of its column, one 8- or 16-byte
   // LDS write per piece.  KX: the segment's scale exponent (NP == 2)
-  auto stage_b = [&](const float (&bv)[CPT], const int kx, const int buf) {
+  auto stage_b = [&](auto rawc, const float (&bv)[CPT], const int kx, const int buf) {
+    constexpr bool RAW = decltype(rawc)::value;                // the elements arrived as bf16 bits
     unsigned pc[NP][CPT / 2];                                  // [piece][channel pair]
 #pragma unroll
     for (int e = 0; e < CPT; e += 2) {
       const float v0 = bv[e], v1 = bv[e + 1];                  // out-of-range elements arrived as 0
       if constexpr (NP == 3) split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);
       else if constexpr (NP == 2) split2(v0, v1, kx, pc[0][e / 2], pc[1][e / 2]);
-      else if constexpr (X16) pc[0][e / 2] = __builtin_bit_cast(unsigned, v0) | (__builtin_bit_cast(unsigned, v1) << 16);   // already bf16
+      else if constexpr (RAW) pc[0][e / 2] = __builtin_bit_cast(unsigned, v0) | (__builtin_bit_cast(unsigned, v1) << 16);   // already bf16
       else pc[0][e / 2] = pack_bf16x2(v0, v1);
     }
 #pragma unroll
@@ -1141,28 +1164,28 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // unconditional (a branch around them makes hipcc drain to vmcnt(0)).
   [[maybe_unused]] uint4 pa0, pa1, pa2, qa0, qa1, qa2;      // scalars, not arrays: hipcc leaves uint4[NP] in scratch / LDS here
   [[maybe_unused]] int pkx = 0, qkx = 0;                    // the scale exponent that goes with each set's activations
-#define X3_FETCH(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, kcur, sw, vb, rx, !TAP2, ((EPI == EPI_GATE_BWD && TAP2) ? X3_GBWD_B0_AUX : (a.x_nt ? 2 : 0)))
-#define X3_FETCH1(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, k1, sw + sw1, vb1, rx1, false, 0)
-#define X3_FETCH_(A0, A1, A2, BV, KX, KV, SW, VB, RX, ADV, BAUX)                             \
+#define X3_FETCH(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, kcur, sw, vb, rx, !TAP2, ((EPI == EPI_GATE_BWD && TAP2) ? X3_GBWD_B0_AUX : (a.x_nt ? 2 : 0)), RAW0, sx, xcsb)
+#define X3_FETCH1(A0, A1, A2, BV, KX) X3_FETCH_(A0, A1, A2, BV, KX, k1, sw + sw1, vb1, rx1, false, 0, RAW1, of_seg1(sx), of_seg1(xcsb))
+#define X3_FETCH_(A0, A1, A2, BV, KX, KV, SW, VB, RX, ADV, BAUX, RAW, SX, XCS)               \
   {                                                                                          \
     A0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW), 0));  \
     if constexpr (NP >= 2) A1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + wl2b, 0)); \
     if constexpr (NP == 3) A2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, (SW) + 2u * wl2b, 0)); \
-    if constexpr (X16) {                      /* raw bf16 bits, kept in the low half of a register */ \
+    if constexpr (RAW) {                      /* raw bf16 bits, kept in the low half of a register */ \
       _Pragma("unroll") for (int e = 0; e < CPT; ++e)                                          \
-        BV[e] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(RX, (VB), sx + (unsigned)e * xcsb, 0)); \
+        BV[e] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(RX, (VB), (SX) + (unsigned)e * (XCS), 0)); \
     } else                                                                                     \
-    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = ((BAUX) == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RX, (VB), sx + (unsigned)e * xcsb, 2)) : buf_ld(RX, (VB), sx + (unsigned)e * xcsb)); \
+    _Pragma("unroll") for (int e = 0; e < CPT; ++e) BV[e] = ((BAUX) == 2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RX, (VB), (SX) + (unsigned)e * (XCS), 2)) : buf_ld(RX, (VB), (SX) + (unsigned)e * (XCS))); \
     KX = (KV);                                                                               \
     if (!SCHED && (ADV)) advance();                                                          \
   }
-#define X3_STAGE(A0, A1, A2, BV, KX, BUF)                                                    \
+#define X3_STAGE(A0, A1, A2, BV, KX, BUF, RAW)                                               \
   {                                                                                          \
     uint4* ad = &As[BUF][0][0][0];                                                           \
     ad[tid] = A0;                                                                            \
     if constexpr (NP >= 2) ad[NT + tid] = A1;                                                \
     if constexpr (NP == 3) ad[2 * NT + tid] = A2;                                            \
-    stage_b(BV, KX, BUF);                                                                \
+    stage_b(std::integral_constant<bool, (RAW)>{}, BV, KX, BUF);                             \
   }
   auto mma = [&](auto curc) {
     constexpr int cur = decltype(curc)::value;
@@ -1233,7 +1256,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       uint4* ad = &As[BUF][0][0][0];                                                          \
       ad[tid] = la0; ad[NT + tid] = la1;                                                      \
       if constexpr (NP == 3) ad[2 * NT + tid] = la2;                                          \
-      stage_b(BV, KX, BUF);                                                               \
+      stage_b(std::false_type{}, BV, KX, BUF);                                            \
     }
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
@@ -1281,7 +1304,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
     else X3_FETCH(qa0, qa1, qa2, qb, qkx);
     if (SCHED && !TAP2) advance();
-    X3_STAGE(pa0, pa1, pa2, pb, pkx, 0);
+    X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, RAW0);
     __syncthreads();
     // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1.  (Whole pairs in the loop,
     // an odd last step behind it: with a `break` between the halves hipcc copied the accumulators between register sets
@@ -1289,13 +1312,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     for (int i = 0; i + 1 < nsteps; i += 2) {
       X3_FETCH(pa0, pa1, pa2, pb, pkx);             // step i + 2 (past the end: re-reads the last step, never used)
       mma(I0{});
-      X3_STAGE(qa0, qa1, qa2, qb, qkx, 1);          // step i + 1
+      X3_STAGE(qa0, qa1, qa2, qb, qkx, 1, RAW1);    // step i + 1 (TAP2: the second segment's set)
       if (SCHED && !TAP2) advance();
       __syncthreads();
       if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
       else X3_FETCH(qa0, qa1, qa2, qb, qkx);        // step i + 3
       mma(I1{});
-      X3_STAGE(pa0, pa1, pa2, pb, pkx, 0);          // step i + 2
+      X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, RAW0);    // step i + 2
       if (SCHED && !TAP2) advance();
       __syncthreads();
     }
@@ -1315,10 +1338,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         for (int r = 0; r < 16; ++r) ac[i][j][r] = __builtin_ldexpf(ac[i][j][r], ku);
   };
   if constexpr (NP == 2) unscale(acc);
-  gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD)>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
+  gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD), NP == 1>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
   if constexpr (NB == 2) {
     if constexpr (NP == 2) unscale(acc2);
-    if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
+    if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true, NP == 1>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
   }
 }
 
@@ -1680,6 +1703,7 @@ struct WgradArgs {
   int accumulate;
   const int32_t* skip_flag;       // see GemmArgs::skip_flag
   int x16;                        // matmul mode 1 only: the x operand of every segment (the z tensors) is stored as bf16
+  int g16;                        // matmul mode 1 only: the output-gradient operand (every segment's gy) is stored as bf16
   const unsigned* amax_gy;        // float32x2: absolute maximum of the common gy
   int f16x2;                      // host: run the float32x2 kernel (every segment carries its maxima)
 };
@@ -2124,11 +2148,13 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 #ifndef W3_LEAN
 #define W3_LEAN 1             // 256 x 128 tiles, six products: compiled for 128 VGPRs (two 8-wave workgroups per CU)
 #endif
-template <int WM, int NC, int NP, bool X16 = false>
+// G16 (matmul mode 1): the output-gradient operand (gh of a block, g_skip: T a multiple of 16) is stored as bf16 -- the
+// same 8-byte loads; its bias sums add the stored (rounded) values.
+template <int WM, int NC, int NP, bool X16 = false, bool G16 = false>
 __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2) ? 4 : 2) void wgrad3_kernel(const WgradArgs a) {
   static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
-  static_assert(!X16 || NP == 1, "bf16-stored x: mode 1 only");
-  constexpr unsigned XSZ = X16 ? 2u : 4u;
+  static_assert((!X16 && !G16) || NP == 1, "bf16-stored operands: mode 1 only");
+  constexpr unsigned XSZ = X16 ? 2u : 4u, GSZ = G16 ? 2u : 4u;
   constexpr int NT2 = 128 * WM, BM2 = 64 * WM, BNC = BN * NC;
   constexpr int PA = BM2 + 4, PB = BNC + 4;               // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
   constexpr int NA = BM2 * 4 / NT2, NB = BNC * 4 / NT2;   // float4 row loads per thread: 2 and 1 or 2 (WM=4) / 2 and 2
@@ -2204,7 +2230,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
   bool b_ok[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
-    voa[i] = (m0 + s_row + RSTEP * i) < a.M ? 4u * (unsigned)((m0 + s_row + RSTEP * i) * Tout + 4 * s_chunk) : OOB;
+    voa[i] = (m0 + s_row + RSTEP * i) < a.M ? GSZ * (unsigned)((m0 + s_row + RSTEP * i) * Tout + 4 * s_chunk) : OOB;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     b_ok[i] = (n0 + s_row + RSTEP * i) < sg.cin;
@@ -2221,7 +2247,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
   // (every offset handed to a load is non-negative: the scalar part carries tb + toff only on interior steps)
 #define W3_FETCH(RA, RB, VM, BS, BT)                                                          \
   {                                                                                            \
-    const unsigned soa = 4u * (unsigned)((long)b * a.gy_bstride + tb);                         \
+    const unsigned soa = GSZ * (unsigned)((long)b * a.gy_bstride + tb);                        \
     const bool interior = tb + sg.toff >= 0 && tb + W2K + sg.toff <= sg.Tin && !ragged;        /* wave-uniform */ \
     const unsigned sob = XSZ * (unsigned)((long)b * sg.x_bstride + (interior ? tb + sg.toff : 0)); \
     VM = (!ragged || tb + 4 * s_chunk < Tout) ? 1u : 0u;                                       \
@@ -2236,8 +2262,12 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       BT = tin; BS = tc - tin;                                                                 \
       _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = (any && b_ok[i]) ? vrow[i] + XSZ * (unsigned)tc : OOB; \
     }                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
-      RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
+      if constexpr (G16) {                       /* 4 bf16 = 8 bytes, raw, in .x / .y (host: Tout % 16 == 0) */ \
+        const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); \
+        RA[i] = make_float4(__builtin_bit_cast(float, h_.x), __builtin_bit_cast(float, h_.y), 0.f, 0.f); \
+      } else RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
+    }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       if constexpr (X16) {                       /* 4 bf16 = 8 bytes, raw, in .x / .y (host: toff == 0, Tout % 16 == 0) */ \
         const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rbx, vo_[i], sob, W3_LD_AUX)); \
@@ -2281,8 +2311,15 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
       const float4 v = VM ? RA[i] : zero4;          /* invalid rows arrived as 0; VM: ragged Tout only */ \
+      if constexpr (G16) {                                                                     \
+        put_raw(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);                            \
+        const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y); \
+        if (real_) bsum[i] += (__builtin_bit_cast(float, u0 << 16) + __builtin_bit_cast(float, u0 & 0xffff0000u)) + \
+                              (__builtin_bit_cast(float, u1 << 16) + __builtin_bit_cast(float, u1 & 0xffff0000u)); \
+      } else {                                                                                 \
       put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v, ka);                          \
       if (real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                                         \
+      }                                                                                        \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       float4 v = RB[i];                               /* invalid rows / groups arrived as 0 */ \
@@ -2358,8 +2395,8 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
     // selects that every step paid: 130 VALU + 100 SALU per step beside 12 MFMAs (round 4: the MFMAs halved and this
     // became the loop).  Whole pairs in the loop, an odd last step behind it (single exit, see conv_gemm_x3_kernel).
     if (nsteps > 0) {
-      unsigned base_a = 4u * (unsigned)((long)b * a.gy_bstride), base_b = XSZ * (unsigned)((long)b * sg.x_bstride);
-      const unsigned adv_a = 4u * (unsigned)a.gy_bstride, adv_b = XSZ * (unsigned)sg.x_bstride;
+      unsigned base_a = GSZ * (unsigned)((long)b * a.gy_bstride), base_b = XSZ * (unsigned)((long)b * sg.x_bstride);
+      const unsigned adv_a = GSZ * (unsigned)a.gy_bstride, adv_b = XSZ * (unsigned)sg.x_bstride;
       const int s_toff = sg.toff, s_tin = sg.Tin;
       auto adv = [&]() {
         tb += W2K;
@@ -2369,7 +2406,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
 #define W3L_FETCH()                                                                            \
       pfast = !ragged && tb + s_toff >= 0 && tb + W2K + s_toff <= s_tin;     /* wave-uniform */ \
       if (pfast) {                                                                             \
-        const unsigned soa = base_a + 4u * (unsigned)tb, sob = base_b + XSZ * (unsigned)(tb + s_toff); \
+        const unsigned soa = base_a + GSZ * (unsigned)tb, sob = base_b + XSZ * (unsigned)(tb + s_toff); \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                         \
           pra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[i], soa, W3_LD_AUX)); \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
@@ -2716,15 +2753,21 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   } while (0)
   // the gate-derivative epilogue always runs 128-row tiles (`big` is false): its 256-row variants are
   // not instantiated
-  if constexpr (EPI == EPI_LINEAR) {
-    if (g.z16) {
-      VQ_REQUIRE(mode == 1 && big && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1 and 256-row tiles");
-      for (int i = 0; i < g.nseg; ++i) VQ_REQUIRE(g.seg[i].tmul == 1 && g.seg[i].tdiv == 1, "conv_gemm: bf16-stored activations: stride-1 segments only");
-      if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, true>), dim3((unsigned)nblk2), dim3(512), g);
-      else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, true>), dim3((unsigned)nblk), dim3(512), g);
-      VQ_LAUNCH_CHECK();
-      return 0;
+  // activations stored as bf16 (matmul mode 1): a linear GEMM over z tensors (z16: every segment), or the caller's mask
+  const int xm = (EPI == EPI_LINEAR && g.z16) ? 3 : g.x16;
+  if (xm != 0) {
+    VQ_REQUIRE(mode == 1 && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1");
+    for (int i = 0; i < g.nseg; ++i) VQ_REQUIRE(g.seg[i].tmul == 1 && g.seg[i].tdiv == 1, "conv_gemm: bf16-stored activations: stride-1 segments only");
+    if constexpr (EPI == EPI_LINEAR) {
+      VQ_REQUIRE(big && xm == 3, "conv_gemm: bf16-stored activations of a linear GEMM: every segment, 256-row tiles");
+      if (tap2 && lean) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, true, 3>), dim3((unsigned)nblk), dim3(512), g);
+      else if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, 1>), dim3((unsigned)nblk2), dim3(512), g);
+      else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, 1>), dim3((unsigned)nblk), dim3(512), g);
+    } else {
+      VQ_REQUIRE(false, "conv_gemm: bf16-stored activations are not built for this epilogue");
     }
+    VQ_LAUNCH_CHECK();
+    return 0;
   }
   if constexpr (EPI != EPI_GATE_BWD) {
     if (big && mode != 0) {
@@ -2902,11 +2945,14 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 3>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && mode == 2) {
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 3>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
-  } else if (w.x16) {
+  } else if (w.x16 || w.g16) {
     bool ok16 = fast && mode == 1 && w.M % 256 == 0 && w.Tout % W2K == 0;
-    for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].toff == 0 && w.seg[i].Tin == w.Tout;
-    VQ_REQUIRE(ok16, "wgrad: bf16-stored x operand needs matmul mode 1, unshifted stride-1 segments, 256-row tiles and T %% 16 == 0");
-    hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
+    if (w.x16) for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].toff == 0 && w.seg[i].Tin == w.Tout;
+    VQ_REQUIRE(ok16, "wgrad: bf16-stored operands need matmul mode 1, stride-1 segments (unshifted for a bf16 x), 256-row tiles and T %% 16 == 0");
+    const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
+    if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true, true>), grid, dim3(512), 0, st, w);
+    else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, false, true>), grid, dim3(512), 0, st, w);
+    else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true>), grid, dim3(512), 0, st, w);
   } else if (fast && mode == 1 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && mode == 1) {
@@ -3299,8 +3345,19 @@ static bool gates_bf16(const vqvae_resblock_desc* d) {
   return on && z_bf16(d);
 }
 
+// gh = [ga; gb] (B, Cd, T) stored as bf16 (vqvae_resblock_desc::storage & VQVAE_STORE_GH_BF16): the same blocks, on
+// the caller's request.  VQVAE_H16=0 makes the library report it as unsupported.
+static int bf16_storage_supported(const vqvae_resblock_desc* d) {
+  static const int h16 = getenv("VQVAE_H16") ? atoi(getenv("VQVAE_H16")) : 1;
+  int m = 0;
+  if (h16 && gates_bf16(d) && d->K == 2 && d->Cd == 256) m |= VQVAE_STORE_GH_BF16;
+  return m;
+}
+
 static int check_rb(const vqvae_resblock_desc* d) {
   VQ_REQUIRE(d, "resblock: null desc");
+  VQ_REQUIRE(d->storage == 0 || (d->storage & ~bf16_storage_supported(d)) == 0,
+             "resblock: desc.storage = %d asks for bf16 tensors this shape / matmul mode does not keep (supported: %d)", d->storage, bf16_storage_supported(d));
   VQ_REQUIRE(d->B > 0 && d->T > 0 && d->Cr > 0 && d->Cd > 0 && d->Cs > 0 && d->Cc > 0, "resblock: bad dims");
   VQ_REQUIRE(d->Cd % 64 == 0, "resblock: dilated_channels/2 must be a multiple of 32 (got Cd=%d)", d->Cd);
   VQ_REQUIRE(d->K >= 1 && d->K <= MAXTAPS, "resblock: filter_size %d unsupported", d->K);
@@ -3329,6 +3386,11 @@ static int packed_check(const void* p) {
   VQ_REQUIRE((const char*)p < it->first + it->second.first, "packed slabs %p were not written by vqvae_resstack_pack", p);
   VQ_REQUIRE(it->second.second == g_matmul_dtype, "packed slabs were written in matmul mode %d, used in mode %d", it->second.second, g_matmul_dtype);
   return 0;
+}
+
+extern "C" int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d) {
+  if (!d || d->Cd <= 0) return 0;
+  return bf16_storage_supported(d);
 }
 
 extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
@@ -3514,6 +3576,8 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
   // packed slabs (vqvae_resstack_pack): only the pk_* offsets are read through wpk
   float* wpk = packed ? const_cast<float*>(packed) - L.pk_d : w;
   if (packed) VQ_REQUIRE(!gcond && gh_out, "resblock_bwd_packed: the packed form serves ResidualNet's chain (no per-block condition gradient, gh kept)");
+  const bool h16 = (d->storage & VQVAE_STORE_GH_BF16) != 0;
+  if (h16) VQ_REQUIRE(packed, "resblock_bwd: a bf16-stored gh (desc.storage) is kept by the packed chain form only");
 
   if (!packed) {
   PackArgs pa; pa.njob = 0;
@@ -3545,6 +3609,7 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].add = gates; g.out[0].add_bstride = (long)d->Cd * T;
     g.out[0].amax_out = am ? am->gh : nullptr;
     g.g16 = gates_bf16(d) ? 1 : 0;
+    g.h16 = h16 ? 1 : 0;
     if (int e = launch_gemm<EPI_GATE_BWD>(g, VQVAE_PROF_RESBLOCK_BWD_GZ, st)) return e;
   }
   // K4: gx = g_res + sum_j Wd_j^T gh[t + (K-1-j) dil]
@@ -3564,6 +3629,7 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
     g.out[0].add = g_res; g.out[0].add_bstride = (long)d->Cr * T;
     g.out[0].amax_out = am ? am->gx : nullptr;
+    g.x16 = h16 ? 3 : 0;
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GX, st)) return e;
   }
   // K5: gcond (+)= Wc^T gh
@@ -3739,6 +3805,7 @@ extern "C" int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblock
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_gcond_bwd: 1..%d blocks", MAXSEG);
   VQ_REQUIRE(Wc && gh && gcond && ws, "resstack_gcond_bwd: null pointer");
+  VQ_REQUIRE(!(d->storage & VQVAE_STORE_GH_BF16), "resstack_gcond_bwd: reads fp32 gh (the latent-rate chain pulls a bf16 gh back with vqvae_upsample_linear_bwd_bf16)");
   if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_gcond_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
   const int T = d->T;
@@ -3853,6 +3920,7 @@ extern "C" int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x
   }
   wa.seg[0].gb = gbd;
   wa.accumulate = accumulate;
+  wa.g16 = (d->storage & VQVAE_STORE_GH_BF16) ? 1 : 0;
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 
@@ -3894,6 +3962,7 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
   wa.nseg = n;
   wa.accumulate = accumulate;
+  wa.g16 = (d->storage & VQVAE_STORE_GH_BF16) ? 1 : 0;
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 

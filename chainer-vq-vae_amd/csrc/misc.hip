@@ -207,7 +207,10 @@ __global__ __launch_bounds__(UPB_NT, 8) void upsample_bwd_rows_kernel(
 // combined by three butterfly shuffles: a FIXED-ORDER fp32 tree (4 -> ~17 -> 2), deterministic, within a few
 // ulp of the float64 sum.  LDS is double-buffered by row parity: one barrier per row.  ~30
 // instructions per thread and row against ~150 for the LDS-staged float64 form above.
+// IN16: gy is stored as bf16 (the bf16 mode's gh, vqvae_upsample_linear_bwd_bf16): 8-byte loads of 4 t, widened in
+// registers; gy_bstride counts elements either way.
 constexpr int UPS_NT = 1024, UPS_PITCH = 2048 + 128;
+template <bool IN16>
 __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
     const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
     const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
@@ -243,10 +246,16 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
 #define UPS_FETCH(V, R)                                                                        \
   {                                                                                            \
     const int rr_ = min((R), rows - 1);           /* past the end: re-read the last row, unused */ \
-    const float* g_ = gy + (long)(rr_ / C) * gy_bstride + (long)(rr_ % C) * Tout;              \
+    const long e_ = (long)(rr_ / C) * gy_bstride + (long)(rr_ % C) * Tout;                     \
+    const float* g_ = gy + e_;                                                                 \
+    const unsigned short* h_ = reinterpret_cast<const unsigned short*>(gy) + e_;               \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
       const int q = k * UPS_NT + tid;                                                          \
-      V[k] = q < n4 ? reinterpret_cast<const float4*>(g_)[q] : make_float4(0.f, 0.f, 0.f, 0.f); \
+      if constexpr (IN16) {                                                                    \
+        const uint2 u_ = q < n4 ? reinterpret_cast<const uint2*>(h_)[q] : make_uint2(0u, 0u);  \
+        V[k] = make_float4(__builtin_bit_cast(float, u_.x << 16), __builtin_bit_cast(float, u_.x & 0xffff0000u), \
+                           __builtin_bit_cast(float, u_.y << 16), __builtin_bit_cast(float, u_.y & 0xffff0000u)); \
+      } else V[k] = q < n4 ? reinterpret_cast<const float4*>(g_)[q] : make_float4(0.f, 0.f, 0.f, 0.f); \
     }                                                                                          \
   }
 #define UPS_ROW(V, PAR)                                                                        \
@@ -996,7 +1005,7 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
       ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0) {
     int nb = B * C;
     if (nb > 512) nb = 512;                      // persistent: 2 workgroups per CU
-    hipLaunchKernelGGL(upsample_bwd_seg_kernel, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel<false>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
     VQ_LAUNCH_CHECK();
     return 0;
   }
@@ -1012,6 +1021,23 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
   } else {
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   }
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// gy stored as bf16 (the bf16 mode's gh: vqvae_resblock_desc::storage & VQVAE_STORE_GH_BF16); the decoder's pull-back
+// shape only (the segmented kernel above)
+int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C, int Tin, int Tout,
+                                   const float* w0, const float* w1, const int32_t* lo0,
+                                   const int32_t* hi0, const int32_t* lo1, const int32_t* hi1, float* gx,
+                                   long gx_bstride, vqvae_stream_t s) {
+  VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd_bf16: null pointer");
+  VQ_REQUIRE(Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 &&
+             ((uintptr_t)gy) % 8 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0,
+             "upsample_bwd_bf16: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
+  int nb = B * C;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(upsample_bwd_seg_kernel<true>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
   VQ_LAUNCH_CHECK();
   return 0;
 }

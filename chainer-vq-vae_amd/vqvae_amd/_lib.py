@@ -26,7 +26,7 @@ class Conv1dDesc(C.Structure):
 
 
 class ResblockDesc(C.Structure):
-    _fields_ = [(n, c_int) for n in ('B', 'T', 'Cr', 'Cd', 'Cs', 'Cc', 'K', 'dil')]
+    _fields_ = [(n, c_int) for n in ('B', 'T', 'Cr', 'Cd', 'Cs', 'Cc', 'K', 'dil', 'storage')]
 
 
 class ResblockParams(C.Structure):
@@ -148,6 +148,9 @@ PROTOTYPES = {
     'vqvae_upsample_linear_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_long, P]),
     'vqvae_upsample_linear_bwd': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                           P, c_long, P]),
+    'vqvae_upsample_linear_bwd_bf16': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
+                                               P, c_long, P]),
+    'vqvae_resblock_bf16_storage': (c_int, [C.POINTER(ResblockDesc)]),
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
     'vqvae_onehot': (c_int, [P, c_long, c_int, c_int, c_int, P, P]),
     'vqvae_embed_gather_fwd': (c_int, [P, c_long, c_int, c_int, P, P, c_int, c_int, c_int, P, P]),
@@ -190,6 +193,7 @@ PROTOTYPES = {
 
 # elementwise op codes / profiler tags (mirror the header)
 MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gemm.hip)
+STORE_GH_BF16 = 1                 # vqvae_resblock_desc.storage bits (VQVAE_STORE_*)
 AMAX_SLOTS = 16                   # uint32 words per absolute maximum (vqvae_absmax, vqvae_resblock_amax)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
     EW_MUL_SCALAR_DEV = range(10)

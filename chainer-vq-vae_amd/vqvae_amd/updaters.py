@@ -260,7 +260,7 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         # parameters created during this forward (lazily shaped links, net.py:34-43) join the
         # flat arenas BEFORE the exchange, so their gradients are summed like everyone else's
         adopt = getattr(optimizer, 'adopt_new_params', None)
-        if not optimizer._recording and adopt is not None and adopt() and n > 1:
+        if not getattr(optimizer, '_recording', False) and adopt is not None and adopt() and n > 1:   # (any optimizer with update() / grads serves here: the recording flag is the device Adam's)
             self._check_replicas(optimizer)
         if exchange:
             self.comm.allreduce_grad(optimizer.grads)       # sum over ranks, in place

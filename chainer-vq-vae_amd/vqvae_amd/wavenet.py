@@ -230,6 +230,13 @@ class ResidualStackFunction(FunctionNode):
                 _lib.call('vqvae_memcpy_d2d', self._slot(3 * nb), g_skip.amax.ptr, 4 * _lib.AMAX_SLOTS, _S())
             else:
                 _lib.call('vqvae_absmax', g_skip.ptr, g_skip.size, self._slot(3 * nb), _S())
+        # BASELINE configs[4] (matmul mode 'bfloat16'): the tensors of the backward chain the library can keep in HBM as
+        # bf16 (vqvae_resblock_desc.storage); the buffers below stay fp32-sized, half used
+        store = 0
+        if self.packed is not None and lat is not None:
+            store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))
+        for dd in self.descs:
+            dd.storage = store
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb
@@ -350,7 +357,8 @@ class ResidualStackFunction(FunctionNode):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
-                _lib.call('vqvae_upsample_linear_bwd', gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
+                _lib.call('vqvae_upsample_linear_bwd_bf16' if store & _lib.STORE_GH_BF16 else 'vqvae_upsample_linear_bwd',
+                          gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
                           tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
                           tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, side)
                 gp[2] = gp[3] = None           # condition_proj grads: one latent-rate conv, below

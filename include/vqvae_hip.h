@@ -190,7 +190,20 @@ typedef struct {
   int Cc;      /* condition_dim                                                  */
   int K;       /* filter_size                                                    */
   int dil;     /* dilation                                                       */
+  int storage; /* bit set of VQVAE_STORE_*: tensors of the chain kept in HBM as bf16
+                  (0 = all fp32; matmul mode 1 only -- ask vqvae_resblock_bf16_storage) */
 } vqvae_resblock_desc;
+
+/* BASELINE configs[4] ("bf16"): tensors the bf16 mode may keep in HBM as bf16 -- same element strides,
+ * 2-byte elements, the caller's fp32-sized buffer simply half used.  The caller opts in per tensor through
+ * vqvae_resblock_desc::storage and must pass the same bits to every entry point that produces or reads the
+ * tensor (resblock_bwd_packed produces gh; resstack_dil_wgrad / resblock_wgrad / upsample_linear_bwd_bf16
+ * read it).
+ *   GH: gh = [ga; gb], the gate pre-activation gradient (B, Cd, T).  The GEMMs that read it round it to
+ *       bf16 anyway; its bias sums and the latent pull-back then see the rounded values.              */
+#define VQVAE_STORE_GH_BF16 1
+/* the bits the library supports for this block shape in the current matmul mode (0 outside mode 1)    */
+int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 
 typedef struct {            /* parameters, Chainer layouts (modules.py:13-22)     */
   const float *Wd, *bd;     /* conv            (Cd, Cr, K, 1), (Cd)               */
@@ -358,6 +371,12 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               const int32_t* lo0, const int32_t* hi0,
                               const int32_t* lo1, const int32_t* hi1,
                               float* gx, long gx_bstride, vqvae_stream_t s);
+/* the same with gy stored as bf16 (VQVAE_STORE_GH_BF16; gy_bstride in elements): ratios Tout >= 8 Tin only */
+int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C, int Tin,
+                                   int Tout, const float* w0, const float* w1,
+                                   const int32_t* lo0, const int32_t* hi0,
+                                   const int32_t* lo1, const int32_t* hi1,
+                                   float* gx, long gx_bstride, vqvae_stream_t s);
 
 /* ---- L.EmbedID + broadcast along T (net.py:57-61): y[b,c,t] = E[id[b],c]      */
 int vqvae_embed_broadcast_fwd(const float* E, const int32_t* ids, int B, int G, int T,

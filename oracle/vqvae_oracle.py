@@ -347,6 +347,13 @@ def gates_saved_as_bf16(Ch, Cr, Cs, T):
     return _BF16[0] and Ch == 128 and Cr == 256 and Cs % 256 == 0 and T % 64 == 0
 
 
+def gh_saved_as_bf16(Ch, Cr, Cs, T, K):
+    """... and, on the default (latent-rate condition) path, the gate pre-activation gradient gh = [ga; gb] of every
+    block (vqvae_resblock_desc.storage & VQVAE_STORE_GH_BF16; csrc/conv_gemm.hip bf16_storage_supported): the
+    contractions that read it round it anyway, its bias sums and the condition gradient see the rounded values."""
+    return gates_saved_as_bf16(Ch, Cr, Cs, T) and K == 2
+
+
 def resblock_fwd(p, x, cond, dil):
     """ResidualBlock.__call__ (modules.py:30-56), dropout_zero_rate == 0.
     p: conv (W (2*Ch... (Cd,Cr,K), b), condition_proj (W (Cd,Cc,1), b),
@@ -389,6 +396,8 @@ def resblock_bwd(p, cache, cond, dil, g_res, g_skip, need_gx=True):
     ga = gz * sb * (one - ta * ta)
     gb_ = gz * ta * sb * (one - sb)
     gh = np.concatenate((ga, gb_), axis=1)
+    if gh.dtype == np.float32 and gh_saved_as_bf16(z.shape[1], Wr.shape[0], Ws.shape[0], x.shape[2], Wd.shape[2]):
+        gh = bf16_round(gh)
     gc, gWc, gbc = conv1d_bwd(cond, Wc, gh)
     grads['condition_proj'] = (gWc, gbc)
     gx, gWd, gbd = causal_conv_bwd(x, Wd, gh, dil, need_gx=need_gx)

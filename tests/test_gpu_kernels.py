@@ -855,3 +855,81 @@ def test_conv1d_random_shapes_vs_oracle(gpu, matmul_mode, case):
     assert_close_scaled(vx.grad.get()[..., 0], gx_ref, 1e-4, 'gx')
     assert_close_scaled(vW.grad.get()[..., 0], gW_ref, 1e-4, 'gW')
     assert_close_scaled(vb.grad.get(), gb_ref, 1e-4, 'gb')
+
+
+def _bf16_bits_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_bf16_stored_gh_changes_only_the_rounding_point(gpu, bf16_mode):
+    """BASELINE configs[4] ("bf16"), vqvae_resblock_desc.storage & VQVAE_STORE_GH_BF16: one configs-sized block of the
+    packed chain, backward, with gh kept as fp32 and as bf16.  The stored gh is the fp32 one rounded (RNE), bit for
+    bit; everything that contracts it on the matrix cores -- backward-data (gx), the dilated conv's weight gradient --
+    is bit-identical (those kernels round their operands anyway); the bias gradient and the latent pull-back are
+    those of the rounded values."""
+    from vqvae_amd import _lib, functions as F
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    B, T, Cr, Cd, Cs, Cc, K, dil, Tl = 2, 512, 256, 256, 256, 192, 2, 4, 8
+    Ch = Cd // 2
+    d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, dil)
+    assert lib.vqvae_resblock_bf16_storage(C.byref(d)) & _lib.STORE_GH_BF16
+    rs = np.random.RandomState(77)
+    f = lambda *s, sc=1.0: gpu.to_device((rs.standard_normal(s) * sc).astype(np.float32))
+    Wd, bd = f(Cd, Cr, K, 1, sc=0.04), f(Cd, sc=0.1)
+    Wc, bc = f(Cd, Cc, 1, 1, sc=0.05), f(Cd, sc=0.1)
+    Wr, br = f(Cr, Ch, 1, 1, sc=0.08), f(Cr, sc=0.1)
+    Ws, bs = f(Cs, Ch, 1, 1, sc=0.08), f(Cs, sc=0.1)
+    x, P = f(B, Cr, T), f(B, Cd, Tl, sc=0.3)
+    g_res, g_skip = f(B, Cr, T, sc=1e-3), f(B, Cs, T, sc=1e-3)
+    prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+    per = lib.vqvae_resstack_packed_bytes(C.byref(d))
+    packed = DeviceArray((per // 4,), np.float32)
+    _lib.call('vqvae_resstack_pack', C.byref(d), 1, (_lib.ResblockParams * 1)(prm), (C.c_int * 1)(1), packed.ptr,
+              packed.nbytes, gpu.stream())
+    tb = F.resize_tables(Tl, T)
+    cp = _lib.ResblockCproj(P.ptr, Cd * Tl, Tl, tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
+    ws = DeviceArray((lib.vqvae_resblock_workspace_bytes(C.byref(d)) // 4 + 1,), np.float32)
+    res, gates, z = (DeviceArray(s, np.float32) for s in ((B, Cr, T), (B, Cd, T), (B, Ch, T)))
+    _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), x.ptr, C.byref(cp), res.ptr, gates.ptr, z.ptr,
+              ws.ptr, ws.nbytes, packed.ptr, None, gpu.stream())
+    ws2 = DeviceArray((lib.vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d), 1) // 4 + 1,), np.float32)
+
+    def backward(storage):
+        d.storage = storage
+        gx, gh = DeviceArray((B, Cr, T), np.float32), DeviceArray((B, Cd, T), np.float32)
+        gh.fill_zero()
+        _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), x.ptr, gates.ptr, z.ptr, g_res.ptr,
+                  g_skip.ptr, gx.ptr, gh.ptr, ws.ptr, ws.nbytes, packed.ptr, None, gpu.stream())
+        gW, gb = DeviceArray((Cd, Cr, K), np.float32), DeviceArray((Cd,), np.float32)
+        _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), 1, (C.c_int * 1)(dil), _lib.ptr_array([x]),
+                  _lib.ptr_array([gh]), _lib.ptr_array([gW]), _lib.ptr_array([gb]), 0, ws2.ptr, ws2.nbytes,
+                  None, None, gpu.stream())
+        gP = DeviceArray((B, Cd, Tl), np.float32)
+        _lib.call('vqvae_upsample_linear_bwd_bf16' if storage else 'vqvae_upsample_linear_bwd', gh.ptr, Cd * T, B, Cd,
+                  Tl, T, tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr,
+                  gP.ptr, Cd * Tl, gpu.stream())
+        return gx.get(), gh.get(), gW.get(), gb.get(), gP.get()
+
+    try:
+        gx32, gh32, gW32, gb32, gP32 = backward(0)
+        gx16, gh16raw, gW16, gb16, gP16 = backward(_lib.STORE_GH_BF16)
+    finally:
+        d.storage = 0
+    halves = gh16raw.reshape(-1).view(np.uint16)
+    n = B * Cd * T
+    gh16 = _bf16_bits_to_f32(halves[:n]).reshape(B, Cd, T)
+    assert not halves[n:].any()                                    # the caller's buffer is half used
+    assert np.abs(gh32).max() > 0
+    np.testing.assert_array_equal(gh16, O.bf16_round(gh32))
+    np.testing.assert_array_equal(gx16, gx32)
+    np.testing.assert_array_equal(gW16, gW32)
+    assert_close_scaled(gb16, gh16.sum(axis=(0, 2), dtype=np.float64), 1e-5, 'gbd of the stored gh')
+    assert_close_scaled(gb32, gh32.sum(axis=(0, 2), dtype=np.float64), 1e-5, 'gbd')
+    # the pull-back of the bf16 tensor == the fp32 kernel on the same (rounded) values
+    ghr = gpu.to_device(gh16)
+    gPr = DeviceArray((B, Cd, Tl), np.float32)
+    _lib.call('vqvae_upsample_linear_bwd', ghr.ptr, Cd * T, B, Cd, Tl, T, tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr,
+              tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr, gPr.ptr, Cd * Tl, gpu.stream())
+    np.testing.assert_array_equal(gP16, gPr.get())
+    assert_close_scaled(gP16, gP32, 1e-2, 'pull-back: rounded vs unrounded gh')
