@@ -38,7 +38,7 @@ extern "C" {
 typedef void* vqvae_stream_t;
 
 const char* vqvae_last_error_string(void);
-int vqvae_abi_version(void);
+int vqvae_abi_version(void);      /* 3 since vqvae_resblock_desc grew `storage` (bindings must zero it or set it) */
 
 /* ---- device / memory / stream plumbing (replaces CuPy's allocator + streams,
  *      reached in the reference through model.to_gpu()/converter, updaters.py:8) */
