@@ -212,11 +212,13 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def GATE_BYTES(cfg, B):
-    """Algorithmic HBM bytes of one gate launch: 4 * (N Cr + N 1.5 Cd + K Cr Cd + B Cd T')."""
+def GATE_BYTES(cfg, B, bf16=False):
+    """Algorithmic HBM bytes of one gate launch: 4 * (N Cr + N 1.5 Cd + K Cr Cd + B Cd T'); in
+    the bf16 mode of the configs-sized blocks the gate values and z are kept as bf16: 2 bytes each."""
     N = B * cfg['length']
-    return 4.0 * (N * cfg['residual'] + N * 1.5 * cfg['dilated'] + cfg['filter_size'] * cfg['residual'] * cfg['dilated']
-                  + B * cfg['dilated'] * (cfg['length'] // 64))
+    out_bytes = 2.0 if (bf16 and cfg['dilated'] == 256 and cfg['residual'] == 256 and cfg['length'] % 64 == 0) else 4.0
+    return (4.0 * N * cfg['residual'] + out_bytes * N * 1.5 * cfg['dilated']
+            + 4.0 * (cfg['filter_size'] * cfg['residual'] * cfg['dilated'] + B * cfg['dilated'] * (cfg['length'] // 64)))
 
 
 def measured_traffic(key):
@@ -720,11 +722,11 @@ def main():
                                           '(tools/ubench/mfma_power.hip, f16x2_probe.hip; %.0f nominal)'
                                           % (SUSTAINED_MFMA_TFLOPS_REAL_DATA[mode], X3_PRODUCTS, PEAK_BF16_MFMA_TFLOPS))
                                          if (x3 and not args.bf16) else None,
-                         'hbm': {'achieved_algorithmic': (GATE_BYTES(cfg, B) / (avg_ms * 1e-3) / 1e9) if cnt.value else None,
+                         'hbm': {'achieved_algorithmic': (GATE_BYTES(cfg, B, args.bf16) / (avg_ms * 1e-3) / 1e9) if cnt.value else None,
                                  'peak': 8000.0, 'unit': 'GB/s',
-                                 'frac': (GATE_BYTES(cfg, B) / (avg_ms * 1e-3) / 1e9 / 8000.0) if cnt.value else None,
-                                 'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B),
-                                 'note': 'x read once, gates + z written once, weights, latent-rate condition slice (DESIGN.md section 3)'},
+                                 'frac': (GATE_BYTES(cfg, B, args.bf16) / (avg_ms * 1e-3) / 1e9 / 8000.0) if cnt.value else None,
+                                 'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B, args.bf16),
+                                 'note': 'x read once, gates + z written once (as bf16 with --bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3c)'},
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms, 'avg_launch_ms_measured_over': roofline_pass,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
