@@ -110,6 +110,7 @@ struct GemmArgs {
   int f16x2;     // matmul mode 3: every segment carries its maxima and a format-3 slab -> the float32x2 kernels (NP = 2); otherwise mode 3 runs mode 2's
   int g16;       // matmul mode 1 only: the gate values (EPI_GATE: out[0]; EPI_GATE_BWD: out[0].add) are stored as bf16, the pair (tanh, sigmoid) of a (channel, t) as one dword in tanh's fp32 position
   int x16;       // matmul mode 1 only: activations STORED as bf16 (conv_gemm_x3_kernel's X16 mask: bit 0 = segment 0 of a two-tap launch / every segment otherwise, bit 1 = the second segment of a two-tap launch)
+  int add16, y16; // matmul mode 1 only, the streaming residual 1x1 (lin128_stream_kernel): out[0].add is read / out[0].y is stored as bf16 (the residual stream x_l, vqvae_resblock_desc::storage)
   int h16;       // matmul mode 1 only: EPI_GATE_BWD stores gh (out[0].y) as bf16 (same element strides, 2-byte elements)
   int z16;       // matmul mode 1 only: EPI_GATE writes z (out[1]) as bf16; a linear GEMM reads the activations of EVERY segment as bf16 (the z tensors)
 };
@@ -1374,12 +1375,16 @@ struct Lin128Args {
   // float32x2 (NP = 2): maxima of the weights (as packed) and of z (device pointer or host-known bound); amax_out
   // (nullable, any mode): atomicMax of |y| over the launch
   const unsigned* wamax; const unsigned* z_amax; float z_amax_static; unsigned* amax_out;
+  int add16, y16;                          // template flags' runtime twins (host side only)
 };
 
 // Z16 (matmul mode 1): z is stored as bf16 (same element strides): fetched as 2 x CPC bytes per row and staged as is.
-template <int NP, int NC, bool HAS_ADD, bool Z16 = false>
+// ADD16 / Y16 (matmul mode 1): the residual stream is kept as bf16 -- x_l read, x_{l+1} = bf16((acc + bias) + x_l) stored
+// with 2-byte accesses at the same element strides (the first block of a stack reads an fp32 x: ADD16 off, Y16 on).
+template <int NP, int NC, bool HAS_ADD, bool Z16 = false, bool ADD16 = false, bool Y16 = false>
 __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args a) {
   static_assert(!Z16 || NP == 1, "bf16-stored z: mode 1 only");
+  static_assert((!ADD16 && !Y16) || (NP == 1 && HAS_ADD), "bf16 residual stream: mode 1, with the residual add");
   constexpr int KS = 8, NCB = NC / 32;
   constexpr int CPC = NC / 16;                     // columns per staging thread: 16 column groups x 32 channel quads = 512 threads
   constexpr int STEPW = NP * 2 * NC;               // 16-byte words per K step of the B image
@@ -1464,15 +1469,24 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
   }
   // residual operands of a tile, in the accumulator layout (requested a whole tile ahead)
   const unsigned voff = 4u * (unsigned)(4 * lk * T + li);
+  // bf16 residual stream (ADD16 / Y16): 2-byte accesses would move 128 bytes per wave instruction (measured: +23 us per
+  // launch).  A lane PAIR (columns t, t + 1) shares the dwords of a ROW pair (rows R, R + 1) instead: the even lane
+  // owns (R, t .. t + 1), the odd lane (R + 1, t .. t + 1); what the other lane needs / produces travels by one DPP
+  // swap.  voff16: this lane's dword of the row pair that starts at the descriptor offset of row R.
+  [[maybe_unused]] const unsigned voff16 = 2u * (unsigned)((4 * lk + (li & 1)) * T + (li & ~1));
 #define L128_XLOAD(XV, TILE)                                                                   \
   if constexpr (HAS_ADD) {                                                                     \
     const int tl_ = min((TILE), last);                                                         \
     const int b_ = tl_ / a.tiles_per_b, t_ = (tl_ - b_ * a.tiles_per_b) * NC;                  \
-    const rsrc_t rx_ = make_rsrc(a.add + (long)b_ * a.add_bstride);                           \
+    const rsrc_t rx_ = make_rsrc(reinterpret_cast<const char*>(a.add) + (long)b_ * a.add_bstride * (ADD16 ? 2 : 4)); \
     const unsigned sb_ = 4u * (unsigned)(32 * wave * T + t_);                                  \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                         \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
-        XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff, sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T), L128_X_AUX)); \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+        const unsigned so_ = sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T);    \
+        if constexpr (ADD16) {                    /* one dword per ROW PAIR (see voff16): entries r = 4q, 4q + 2 only */ \
+          if ((r & 1) == 0) XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff16, so_ >> 1, L128_X_AUX)); \
+        } else XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff, so_, L128_X_AUX)); \
+      }                                                                                        \
   }
   // one tile: MFMAs on LDS buffer CUR, next tile's z -> the other buffer, epilogue with XCUR while
   // XNXT (the next tile's residual) and the z tile after the next travel
@@ -1493,12 +1507,37 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     }                                                                                          \
     L128_STAGE(CUR ^ 1);                                                                       \
     {                                                                                          \
-      const rsrc_t ry = make_rsrc(a.y + (long)b * a.y_bstride);                                \
+      const rsrc_t ry = make_rsrc(reinterpret_cast<char*>(a.y) + (long)b * a.y_bstride * (Y16 ? 2 : 4)); \
       const unsigned sbase = 4u * (unsigned)(32 * wave * T + t0);                              \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
         const float4 bq4 = bias_s[8 * wave + 2 * q + lk];         /* rows 32w + 8q + 4lk .. + 3 */ \
         const float bv[4] = {bq4.x, bq4.y, bq4.z, bq4.w};                                      \
-        _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                     \
+        _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) {                                   \
+          if constexpr (ADD16 || Y16) {                                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; j += 2) {         /* rows R = 32w + 8q + 4lk + j and R + 1 */ \
+              const int r = 4 * q + j;                                                         \
+              float va = acc[cb][r] + bv[j], vb = acc[cb][r + 1] + bv[j + 1];                  \
+              if constexpr (ADD16) {                                                           \
+                const unsigned own = __builtin_bit_cast(unsigned, XCUR[cb][r]);                \
+                const unsigned got = (unsigned)__shfl_xor((int)own, 1);                        \
+                /* even lane: own = row R cols (t, t + 1), got = row R + 1 cols (t, t + 1); odd lane (col t + 1): the other way round */ \
+                const unsigned ra_ = (li & 1) ? got : own, rb_ = (li & 1) ? own : got;         \
+                va += __builtin_bit_cast(float, (li & 1) ? (ra_ & 0xffff0000u) : (ra_ << 16)); \
+                vb += __builtin_bit_cast(float, (li & 1) ? (rb_ & 0xffff0000u) : (rb_ << 16)); \
+              } else { va += XCUR[cb][r]; vb += XCUR[cb][r + 1]; }                             \
+              const unsigned so_ = sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T);         \
+              if constexpr (Y16) {                                                             \
+                const unsigned h = pack_bf16x2(va, vb);                    /* lo: row R, hi: row R + 1 (this lane's column) */ \
+                const unsigned send = (li & 1) ? (h & 0xffffu) : (h >> 16); /* what the OTHER lane stores: its row, this column */ \
+                const unsigned got = (unsigned)__shfl_xor((int)send, 1);                       \
+                const unsigned pr = (li & 1) ? (got | (h & 0xffff0000u)) : ((h & 0xffffu) | (got << 16)); \
+                __builtin_amdgcn_raw_buffer_store_b32((int)pr, ry, voff16, so_ >> 1, L128_ST_AUX); \
+              } else {                                                                         \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, va), ry, voff, so_, L128_ST_AUX); \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vb), ry, voff, so_ + 4u * (unsigned)T, L128_ST_AUX); \
+              }                                                                                \
+            }                                                                                  \
+          } else {                                                                             \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
             const int r = 4 * q + j;                                                           \
             float v = (NP == 2 ? __builtin_ldexpf(acc[cb][r], ku) : acc[cb][r]) + bv[j];       \
@@ -1506,6 +1545,8 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
             am = fmaxf(am, fabsf(v));                                                          \
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T), L128_ST_AUX);           \
           }                                                                                    \
+          }                                                                                    \
+        }                                                                                      \
       }                                                                                        \
     }                                                                                          \
     /* the tile after the next goes in flight behind this tile's stores (VMEM retires in order: the  \
@@ -2140,8 +2181,9 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 // tile -- fetched, split and stored once per workgroup, and the same for every column tile of the
 // launch -- serves twice the columns; each wave then owns two 64 x 64 blocks 128 columns apart.
 // NP = bf16 pieces per operand: 3 (mode 2) or 1 (mode 1: operands rounded to bf16, one product).
-// X16 (matmul mode 1): the x operand (the z tensors: unshifted, T a multiple of 16) is stored as bf16 -- 8-byte loads
-// of 4 t, staged as they are.
+// X16 (matmul mode 1): the x operand (the z tensors; the bf16 residual stream x_l, tap-shifted; T a multiple of 16) is
+// stored as bf16 -- 8-byte loads of 4 t at any 2-byte alignment (gfx950 serves them: tools/ubench/misaligned_b64.hip),
+// staged as they are.
 #ifndef W3_LD_AUX
 #define W3_LD_AUX 0           // cache policy of the weight-gradient kernels' operand loads (experiment: non-temporal = 2 costs 1.5 ms per step, the column tiles of a launch share their output-gradient rows through L2)
 #endif
@@ -2323,9 +2365,14 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
       float4 v = RB[i];                               /* invalid rows / groups arrived as 0 */ \
-      if (!X16 && __builtin_amdgcn_ballot_w64(BS != 0) != 0ull) {   /* some group of this wave crosses a row end (edge steps only: wave-uniform branch): element e is loaded[e - BS] */ \
+      if (__builtin_amdgcn_ballot_w64(BS != 0) != 0ull) {   /* some group of this wave crosses a row end (edge steps only: wave-uniform branch): element e is loaded[e - BS] */ \
         asm volatile("");                                                         \
-        const float l[4] = {v.x, v.y, v.z, v.w};                                               \
+        float l[4] = {v.x, v.y, v.z, v.w};                                                     \
+        if constexpr (X16) {                          /* four bf16 in .x / .y: one element per register (raw bits, low half) */ \
+          const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y); \
+          l[0] = __builtin_bit_cast(float, u0 & 0xffffu); l[1] = __builtin_bit_cast(float, u0 >> 16); \
+          l[2] = __builtin_bit_cast(float, u1 & 0xffffu); l[3] = __builtin_bit_cast(float, u1 >> 16); \
+        }                                                                                      \
         float o[4];                                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
           const int src = e - BS, tt = BT + e;                                                 \
@@ -2333,7 +2380,9 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
           pick = src == 1 ? l[1] : pick; pick = src == 2 ? l[2] : pick; pick = src == 3 ? l[3] : pick; \
           o[e] = (src >= 0 && src < 4 && tt >= 0 && tt < sg.Tin) ? pick : 0.f;                 \
         }                                                                                      \
-        v = make_float4(o[0], o[1], o[2], o[3]);                                               \
+        if constexpr (X16) v = make_float4(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[0]) | (__builtin_bit_cast(unsigned, o[1]) << 16)), \
+                                           __builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[2]) | (__builtin_bit_cast(unsigned, o[3]) << 16)), 0.f, 0.f); \
+        else v = make_float4(o[0], o[1], o[2], o[3]);                                          \
       }                                                                                        \
       if constexpr (X16) put_raw(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);          \
       else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v, kb);                     \
@@ -2694,6 +2743,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       la.bias = g.out[0].bias;
       la.T = g.Tout;
       la.wamax = s0.wamax; la.z_amax = s0.amax; la.z_amax_static = s0.amax_static; la.amax_out = g.out[0].amax_out;
+      la.add16 = g.add16; la.y16 = g.y16;
       const int nc = (lin128 == 32 || g.z16) ? 32 : 64;
       la.tiles_per_b = g.Tout / nc; la.ntiles = la.tiles_per_b * g.B;
       static int n_cu = 0;
@@ -2709,6 +2759,11 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       } while (0)
       if (mode == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
       else if (mode == 3) L128_LAUNCH(2, 32);
+      else if (g.add16 || g.y16) {
+        VQ_REQUIRE(g.z16 && la.add && g.y16, "conv_gemm: a bf16 residual stream needs matmul mode 1's bf16 z, the residual add and a bf16 output");
+        if (g.add16) LG_LAUNCH((lin128_stream_kernel<1, 32, true, true, true, true>), dim3(nwg), dim3(512), la);
+        else LG_LAUNCH((lin128_stream_kernel<1, 32, true, true, false, true>), dim3(nwg), dim3(512), la);
+      }
       else if (g.z16) {
         if (la.add) LG_LAUNCH((lin128_stream_kernel<1, 32, true, true>), dim3(nwg), dim3(512), la);
         else LG_LAUNCH((lin128_stream_kernel<1, 32, false, true>), dim3(nwg), dim3(512), la);
@@ -2719,6 +2774,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       return 0;
     }
   }
+  VQ_REQUIRE(!g.add16 && !g.y16, "conv_gemm: a bf16 residual stream is served by the streaming 1x1 kernel only (this launch does not qualify)");
   // 256-column tiles when they still give every CU a workgroup (measured at configs[1]: dilated conv
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
   static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
@@ -2763,6 +2819,9 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       if (tap2 && lean) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, true, 3>), dim3((unsigned)nblk), dim3(512), g);
       else if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, 1>), dim3((unsigned)nblk2), dim3(512), g);
       else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, 1>), dim3((unsigned)nblk), dim3(512), g);
+    } else if constexpr (EPI == EPI_GATE) {
+      VQ_REQUIRE(tap2 && lean && xm == 3, "conv_gemm: gate GEMM over a bf16-stored x: both taps, 256 x 128 tiles");
+      LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE, 4, 1, 1, true, 3>), dim3((unsigned)nblk), dim3(512), g);
     } else {
       VQ_REQUIRE(false, "conv_gemm: bf16-stored activations are not built for this epilogue");
     }
@@ -2947,8 +3006,8 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 3>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
   } else if (w.x16 || w.g16) {
     bool ok16 = fast && mode == 1 && w.M % 256 == 0 && w.Tout % W2K == 0;
-    if (w.x16) for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].toff == 0 && w.seg[i].Tin == w.Tout;
-    VQ_REQUIRE(ok16, "wgrad: bf16-stored operands need matmul mode 1, stride-1 segments (unshifted for a bf16 x), 256-row tiles and T %% 16 == 0");
+    if (w.x16) for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].Tin == w.Tout;
+    VQ_REQUIRE(ok16, "wgrad: bf16-stored operands need matmul mode 1, stride-1 segments, 256-row tiles and T %% 16 == 0");
     const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
     if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true, true>), grid, dim3(512), 0, st, w);
     else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, false, true>), grid, dim3(512), 0, st, w);
@@ -3351,6 +3410,9 @@ static int bf16_storage_supported(const vqvae_resblock_desc* d) {
   static const int h16 = getenv("VQVAE_H16") ? atoi(getenv("VQVAE_H16")) : 1;
   int m = 0;
   if (h16 && gates_bf16(d) && d->K == 2 && d->Cd == 256) m |= VQVAE_STORE_GH_BF16;
+  static const int x16 = getenv("VQVAE_X16") ? atoi(getenv("VQVAE_X16")) : 1;
+  static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
+  if (x16 && lin128 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
   return m;
 }
 
@@ -3422,6 +3484,10 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
   const int Mo = (res ? d->Cr : 0) + (skip ? d->Cs : 0);
   const int ldo = pad128(Mo > 0 ? Mo : 1);
   if (packed) VQ_REQUIRE(cproj && !skip, "resblock_fwd_packed: the packed form serves ResidualNet's chain (latent-rate condition, no per-block skip)");
+  if (d->storage & (VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16)) {
+    VQ_REQUIRE(packed, "resblock_fwd: a bf16 residual stream (desc.storage) is kept by the packed chain form only");
+    VQ_REQUIRE(!(d->storage & VQVAE_STORE_X_BF16) || res == nullptr || (d->storage & VQVAE_STORE_RES_BF16), "resblock_fwd: a bf16 x with an fp32 residual output is not built");
+  }
 
   PackArgs pa; pa.njob = 0;
   if (!packed) {
@@ -3467,6 +3533,7 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[1].y = z; g.out[1].y_bstride = (long)Ch * T;
     g.z16 = z_bf16(d) ? 1 : 0;
     g.g16 = gates_bf16(d) ? 1 : 0;
+    g.x16 = (d->storage & VQVAE_STORE_X_BF16) ? 3 : 0;
     if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
   }
   // K2: [res; skip] = [Wr; Ws] z (+ x) (+= skip)
@@ -3490,6 +3557,9 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
       g.out[o].bias = p->bs; g.out[o].accumulate = skip_accumulate;
     }
     g.z16 = z_bf16(d) ? 1 : 0;
+    g.add16 = (res && (d->storage & VQVAE_STORE_X_BF16)) ? 1 : 0;
+    g.y16 = (res && (d->storage & VQVAE_STORE_RES_BF16)) ? 1 : 0;
+    if (g.add16 || g.y16) VQ_REQUIRE(!skip, "resblock_fwd: a bf16 residual stream (desc.storage) is served by the chain form only (no per-block skip output)");
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st)) return e;
   }
   return 0;
@@ -3963,6 +4033,7 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.nseg = n;
   wa.accumulate = accumulate;
   wa.g16 = (d->storage & VQVAE_STORE_GH_BF16) ? 1 : 0;
+  wa.x16 = (d->storage & VQVAE_STORE_X_BF16) ? 1 : 0;        // every block of this launch (the caller groups them accordingly)
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 

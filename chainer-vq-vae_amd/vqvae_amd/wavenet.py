@@ -174,6 +174,13 @@ class ResidualStackFunction(FunctionNode):
             d = _rb_desc(h, cond, Wd, Ws, dil)
             prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
             last = (i == nb - 1)
+            if self.packed is not None:
+                # BASELINE configs[4] (matmul mode 'bfloat16'): the residual stream between the blocks kept as bf16 where
+                # the library offers it (vqvae_resblock_desc.storage; the buffers stay fp32-sized, half used): every
+                # block but the last stores its residual output that way, every block but the first reads it
+                sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(d))
+                if sup & _lib.STORE_RES_BF16 and sup & _lib.STORE_X_BF16:
+                    d.storage = (0 if last else _lib.STORE_RES_BF16) | (_lib.STORE_X_BF16 if i > 0 else 0)
             res = None if last else DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
             gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
             z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
@@ -234,9 +241,10 @@ class ResidualStackFunction(FunctionNode):
         # bf16 (vqvae_resblock_desc.storage); the buffers below stay fp32-sized, half used
         store = 0
         if self.packed is not None and lat is not None:
-            store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))
+            store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0])) & _lib.STORE_GH_BF16
+        stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16       # the forward's choice for the residual stream stays
         for dd in self.descs:
-            dd.storage = store
+            dd.storage = (dd.storage & stream16) | store
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb
@@ -276,15 +284,22 @@ class ResidualStackFunction(FunctionNode):
             del dil_pending[:]
             if overlap:
                 backend.wait_event(side, backend.Event().record(_S()))    # their gh are complete
-            dils = (C.c_int * len(blocks))(*[self.dilations[i] for i in blocks])
-            xam = (C.c_void_p * len(blocks))(*[self._slot(i) for i in blocks]) if f16 else None
-            gam = (C.c_void_p * len(blocks))(*[self._slot(nb + i) for i in blocks]) if f16 else None
-            _lib.call('vqvae_resstack_dil_wgrad', C.byref(d0), len(blocks), dils,
-                      _lib.ptr_array([self.saved[i][0] for i in blocks]),
-                      _lib.ptr_array([ghs[i] for i in blocks]),
-                      _lib.ptr_array([gdil[i][0] for i in blocks]),
-                      _lib.ptr_array([gdil[i][1] for i in blocks]), 0, ws_side.ptr, ws_side.nbytes,
-                      xam, gam, side)
+            # one launch per kind of x: the blocks whose input is the bf16 residual stream, and the rest (block 0)
+            for x16 in (_lib.STORE_X_BF16, 0):
+                sel = [i for i in blocks if (self.descs[i].storage & _lib.STORE_X_BF16) == x16]
+                if not sel:
+                    continue
+                dg = _lib.ResblockDesc.from_buffer_copy(d0)
+                dg.storage = store | x16
+                dils = (C.c_int * len(sel))(*[self.dilations[i] for i in sel])
+                xam = (C.c_void_p * len(sel))(*[self._slot(i) for i in sel]) if f16 else None
+                gam = (C.c_void_p * len(sel))(*[self._slot(nb + i) for i in sel]) if f16 else None
+                _lib.call('vqvae_resstack_dil_wgrad', C.byref(dg), len(sel), dils,
+                          _lib.ptr_array([self.saved[i][0] for i in sel]),
+                          _lib.ptr_array([ghs[i] for i in sel]),
+                          _lib.ptr_array([gdil[i][0] for i in sel]),
+                          _lib.ptr_array([gdil[i][1] for i in sel]), 0, ws_side.ptr, ws_side.nbytes,
+                          xam, gam, side)
 
         # skip-conv weight gradients need only g_skip and the saved z_l: start them right away
         gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]

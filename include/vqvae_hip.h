@@ -202,6 +202,13 @@ typedef struct {
  *   GH: gh = [ga; gb], the gate pre-activation gradient (B, Cd, T).  The GEMMs that read it round it to
  *       bf16 anyway; its bias sums and the latent pull-back then see the rounded values.              */
 #define VQVAE_STORE_GH_BF16 1
+/*   X / RES: the residual stream.  RES: this block's residual output x_{l+1} = bf16((Wr z + br) + x_l) is stored as
+ *       bf16; X: this block's input x_l is (i.e. it is the RES output of the block before it).  The first block of a
+ *       stack reads the caller's fp32 x (RES only), the last one has no residual output (X only).  The rounding is
+ *       part of the result (the oracle's bf16 mode mirrors it); readers: the gate GEMM, the residual add, the dilated
+ *       conv's weight gradient (resstack_dil_wgrad: every block of ONE launch shares the flag).                    */
+#define VQVAE_STORE_X_BF16 2
+#define VQVAE_STORE_RES_BF16 4
 /* the bits the library supports for this block shape in the current matmul mode (0 outside mode 1)    */
 int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 

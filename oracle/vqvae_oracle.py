@@ -85,8 +85,15 @@ class MuLaw(object):
 _BF16 = [False]
 
 
-def set_bf16(on):
+# ... and, on the product's default path (ResidualNet's packed chain at the configs' block sizes), keeps the residual
+# stream x_l and the gate pre-activation gradients gh_l in HBM as bf16 (vqvae_resblock_desc.storage): `storage=False`
+# restates the mode WITHOUT those two roundings (the full-rate-condition path, which does not store them that way)
+_STORE16 = [True]
+
+
+def set_bf16(on, storage=True):
     _BF16[0] = bool(on)
+    _STORE16[0] = bool(storage)
 
 
 def bf16_round(a):
@@ -369,6 +376,9 @@ def resblock_fwd(p, x, cond, dil):
     sb = sigmoid(h[:, Ch:])
     z = ta * sb
     res = conv1d_fwd(z, Wr, br) + x                           # modules.py:52
+    if res.dtype == np.float32 and _STORE16[0] and gh_saved_as_bf16(Ch, Wr.shape[0], Ws.shape[0], x.shape[2], Wd.shape[2]) \
+            and x.shape[2] % 128 == 0:
+        res = bf16_round(res)                                 # the residual stream between the blocks is kept as bf16 (VQVAE_STORE_RES_BF16)
     skip = conv1d_fwd(z, Ws, bs)                              # modules.py:55
     if ta.dtype == np.float32 and gates_saved_as_bf16(Ch, Wr.shape[0], Ws.shape[0], x.shape[2]):
         ta, sb = bf16_round(ta), bf16_round(sb)               # what the backward pass will differentiate
@@ -396,7 +406,7 @@ def resblock_bwd(p, cache, cond, dil, g_res, g_skip, need_gx=True):
     ga = gz * sb * (one - ta * ta)
     gb_ = gz * ta * sb * (one - sb)
     gh = np.concatenate((ga, gb_), axis=1)
-    if gh.dtype == np.float32 and gh_saved_as_bf16(z.shape[1], Wr.shape[0], Ws.shape[0], x.shape[2], Wd.shape[2]):
+    if gh.dtype == np.float32 and _STORE16[0] and gh_saved_as_bf16(z.shape[1], Wr.shape[0], Ws.shape[0], x.shape[2], Wd.shape[2]):
         gh = bf16_round(gh)
     gc, gWc, gbc = conv1d_bwd(cond, Wc, gh)
     grads['condition_proj'] = (gWc, gbc)

@@ -933,3 +933,85 @@ def test_bf16_stored_gh_changes_only_the_rounding_point(gpu, bf16_mode):
               tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr, gPr.ptr, Cd * Tl, gpu.stream())
     np.testing.assert_array_equal(gP16, gPr.get())
     assert_close_scaled(gP16, gP32, 1e-2, 'pull-back: rounded vs unrounded gh')
+
+
+def test_bf16_residual_stream_changes_only_the_rounding_point(gpu, bf16_mode):
+    """vqvae_resblock_desc.storage & (VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16): one configs-sized block of the packed
+    chain, forward, on an input whose values are bf16-representable, read as fp32 and as bf16: the gate values and z
+    are bit-identical, the stored residual output is the fp32 one rounded (RNE) -- also in the first block's form (fp32
+    x in, bf16 out) -- and the dilated conv's weight gradient over the bf16 x (tap shifts 1, 2, 4, 64: 8-byte loads at
+    every 2-byte alignment, row ends included) equals the one over the same values in fp32, bit for bit."""
+    from vqvae_amd import _lib, functions as F
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    B, T, Cr, Cd, Cs, Cc, K, Tl = 2, 512, 256, 256, 256, 192, 2, 8
+    Ch = Cd // 2
+    X, R = _lib.STORE_X_BF16, _lib.STORE_RES_BF16
+    d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, 4)
+    assert lib.vqvae_resblock_bf16_storage(C.byref(d)) & (X | R) == (X | R)
+    rs = np.random.RandomState(78)
+    f = lambda *s, sc=1.0: gpu.to_device((rs.standard_normal(s) * sc).astype(np.float32))
+    Wd, bd = f(Cd, Cr, K, 1, sc=0.04), f(Cd, sc=0.1)
+    Wc, bc = f(Cd, Cc, 1, 1, sc=0.05), f(Cd, sc=0.1)
+    Wr, br = f(Cr, Ch, 1, 1, sc=0.08), f(Cr, sc=0.1)
+    Ws, bs = f(Cs, Ch, 1, 1, sc=0.08), f(Cs, sc=0.1)
+    xr = O.bf16_round(rs.standard_normal((B, Cr, T)).astype(np.float32))
+    x32 = gpu.to_device(xr)
+    x16 = DeviceArray((B, Cr, T), np.float32)             # the caller's buffer stays fp32-sized, half used
+    x16.fill_zero()
+    half = gpu.to_device(np.ascontiguousarray((xr.view(np.uint32) >> 16).astype(np.uint16)).reshape(-1).view(np.float32))
+    _lib.call('vqvae_memcpy_d2d', x16.ptr, half.ptr, B * Cr * T * 2, gpu.stream())
+    P = f(B, Cd, Tl, sc=0.3)
+    prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+    packed = DeviceArray((lib.vqvae_resstack_packed_bytes(C.byref(d)) // 4,), np.float32)
+    _lib.call('vqvae_resstack_pack', C.byref(d), 1, (_lib.ResblockParams * 1)(prm), (C.c_int * 1)(1), packed.ptr,
+              packed.nbytes, gpu.stream())
+    tb = F.resize_tables(Tl, T)
+    cp = _lib.ResblockCproj(P.ptr, Cd * Tl, Tl, tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
+    ws = DeviceArray((lib.vqvae_resblock_workspace_bytes(C.byref(d)) // 4 + 1,), np.float32)
+
+    def forward(storage, x):
+        d.storage = storage
+        res, gates, z = (DeviceArray(s, np.float32) for s in ((B, Cr, T), (B, Cd, T), (B, Ch, T)))
+        for a in (res, gates, z):
+            a.fill_zero()
+        _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), x.ptr, C.byref(cp), res.ptr, gates.ptr, z.ptr,
+                  ws.ptr, ws.nbytes, packed.ptr, None, gpu.stream())
+        return res.get(), gates.get(), z.get()
+
+    try:
+        resA, gatesA, zA = forward(0, x32)
+        resB, gatesB, zB = forward(X | R, x16)
+        resC, gatesC, zC = forward(R, x32)
+    finally:
+        d.storage = 0
+    n = B * Cr * T
+    for res_, gates_, z_ in ((resB, gatesB, zB), (resC, gatesC, zC)):
+        np.testing.assert_array_equal(gates_, gatesA)
+        np.testing.assert_array_equal(z_, zA)
+        halves = res_.reshape(-1).view(np.uint16)
+        assert not halves[n:].any()
+        np.testing.assert_array_equal(_bf16_bits_to_f32(halves[:n]).reshape(B, Cr, T), O.bf16_round(resA))
+    assert np.abs(resA).max() > 0
+
+    gh = f(B, Cd, T, sc=1e-3)
+    ws2 = DeviceArray((lib.vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d), 2) // 4 + 1,), np.float32)
+
+    def wgrad(storage, x, dils):
+        d.storage = storage
+        nbk = len(dils)
+        gW = [DeviceArray((Cd, Cr, K), np.float32) for _ in dils]
+        gb = [DeviceArray((Cd,), np.float32) for _ in dils]
+        _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), nbk, (C.c_int * nbk)(*dils), _lib.ptr_array([x] * nbk),
+                  _lib.ptr_array([gh] * nbk), _lib.ptr_array(gW), _lib.ptr_array(gb), 0, ws2.ptr, ws2.nbytes,
+                  None, None, gpu.stream())
+        return [a.get() for a in gW] + [a.get() for a in gb]
+
+    try:
+        for dils in ((1, 2), (4, 64)):
+            a, b = wgrad(0, x32, dils), wgrad(X, x16, dils)
+            assert np.abs(a[0]).max() > 0
+            for u, v in zip(a, b):
+                np.testing.assert_array_equal(u, v)
+    finally:
+        d.storage = 0

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-bash tools/kstats.sh --no-graph --no-fresh-input 2>&1 | head -22 | cut -c1-150
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step', d['ms_per_step'], 'with input', d['ms_per_step_with_input'])"
+timeout 1500 python -m pytest tests -m gpu -x -q -k "bf16 or config4" 2>&1 | tail -5
+for g in 1 0; do echo "== VQVAE_X16=$g"; VQVAE_X16=$g bash tools/kstats.sh --workload c5 --bf16 --no-graph --no-fresh-input 2>&1 | sed -n 1,9p | cut -c1-150; done
