@@ -214,10 +214,11 @@ def kernel_source_hash():
 
 def GATE_BYTES(cfg, B, bf16=False):
     """Algorithmic HBM bytes of one gate launch: 4 * (N Cr + N 1.5 Cd + K Cr Cd + B Cd T'); in
-    the bf16 mode of the configs-sized blocks the gate values and z are kept as bf16: 2 bytes each."""
+    the bf16 mode of the configs-sized blocks the gate values, z and the residual stream x are kept as bf16: 2 bytes each."""
     N = B * cfg['length']
     out_bytes = 2.0 if (bf16 and cfg['dilated'] == 256 and cfg['residual'] == 256 and cfg['length'] % 64 == 0) else 4.0
-    return (4.0 * N * cfg['residual'] + out_bytes * N * 1.5 * cfg['dilated']
+    x_bytes = 2.0 if (out_bytes == 2.0 and cfg['length'] % 128 == 0) else 4.0      # the bf16 residual stream (every block but the first)
+    return (x_bytes * N * cfg['residual'] + out_bytes * N * 1.5 * cfg['dilated']
             + 4.0 * (cfg['filter_size'] * cfg['residual'] * cfg['dilated'] + B * cfg['dilated'] * (cfg['length'] // 64)))
 
 
@@ -726,7 +727,7 @@ def main():
                                  'peak': 8000.0, 'unit': 'GB/s',
                                  'frac': (GATE_BYTES(cfg, B, args.bf16) / (avg_ms * 1e-3) / 1e9 / 8000.0) if cnt.value else None,
                                  'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B, args.bf16),
-                                 'note': 'x read once, gates + z written once (as bf16 with --bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3c)'},
+                                 'note': 'x read once, gates + z written once (all three as bf16 with --bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3c)'},
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms, 'avg_launch_ms_measured_over': roofline_pass,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
