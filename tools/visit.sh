@@ -1,3 +1,11 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q -k "bf16 or config4" 2>&1 | tail -5
-for g in 1 0; do echo "== VQVAE_X16=$g"; VQVAE_X16=$g bash tools/kstats.sh --workload c5 --bf16 --no-graph --no-fresh-input 2>&1 | sed -n 1,9p | cut -c1-150; done
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+timeout 300 rocprofv3 --memory-copy-trace --hip-runtime-trace --stats --output-format csv -d /tmp/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-graph --no-fresh-input --workload c5 --bf16 > /tmp/b.log 2>&1
+ls /tmp/prof/*/ 2>/dev/null | head; f=$(find /tmp/prof -name "*memory_copy_stats.csv" | head -1); cat $f | head
+g=$(find /tmp/prof -name "*hip_api_stats.csv" | head -1); head -12 $g | cut -c1-120
+t=$(find /tmp/prof -name "*memory_copy_trace.csv" | head -1); python - "$t" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+print(len(rows), rows[0].keys() if rows else None)
+c = collections.Counter((r.get('Direction'), r.get('Bytes') or r.get('Size')) for r in rows)
+for k, v in c.most_common(15): print(v, k)
+PY
