@@ -3412,7 +3412,11 @@ static int bf16_storage_supported(const vqvae_resblock_desc* d) {
   if (h16 && gates_bf16(d) && d->K == 2 && d->Cd == 256) m |= VQVAE_STORE_GH_BF16;
   static const int x16 = getenv("VQVAE_X16") ? atoi(getenv("VQVAE_X16")) : 1;
   static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
-  if (x16 && lin128 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
+  // (the gate GEMM reads a bf16 x in its 256 x 128-tile two-tap form only: not offered when an A/B switch turns that form off)
+  static const int lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
+  static const int tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
+  static const int nb3 = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
+  if (x16 && lin128 && lean && tap2 && nb3 != 3 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
   return m;
 }
 
