@@ -257,6 +257,69 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
     // sub-tile q" lets the next operands travel while the previous results drain; the plain
     // load/store/load/store order exposed one load AND one store latency per sub-tile, which is
     // what bounded the K = 128 projections (315 MB of traffic per launch, 8 GFLOP).
+    if constexpr (ST16) {
+      // matmul mode 1, the residual GRADIENT stream kept as bf16 (GemmArgs::add16 / y16: the backward-data GEMM of the
+      // packed chain; whole tiles, one output range, no bias / relu / accumulate -- the host guarantees all of it):
+      // y = bf16(acc + add).  2-byte elements at the fp32 element strides; a lane pair (columns t, t + 1) shares the dwords
+      // of a row pair and swaps halves by DPP, as in lin128_stream_kernel.  Same one-sub-tile look-ahead as below.
+      if (a.add16 || a.y16) {
+        const OutR& od = a.out[0];
+        auto run16 = [&](auto add16c, auto y16c) {
+          constexpr bool ADD16 = decltype(add16c)::value, Y16 = decltype(y16c)::value;
+          const rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(od.add) + (long)b * od.add_bstride * (ADD16 ? 2 : 4));
+          const rsrc_t ry = make_rsrc(reinterpret_cast<char*>(od.y) + (long)b * od.y_bstride * (Y16 ? 2 : 4));
+          float pv[2][16];
+#pragma unroll
+          for (int q = 0; q <= 4; ++q) {
+            if (q < 4) {
+              const int mi = q >> 1, ni = q & 1;
+              const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+              const unsigned voff16 = 2u * (unsigned)((4 * lk + (li & 1)) * T + wn * 64 + ni * 32 + (li & ~1));
+              const unsigned sbase = 4u * (unsigned)((m0 + wm * 64 + mi * 32) * T + t0);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const unsigned so = sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T);
+                if (od.add == nullptr) pv[q & 1][r] = 0.f;
+                else if constexpr (ADD16) { if ((r & 1) == 0) pv[q & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff16, so >> 1, X3_LIN_ADD_AUX)); }
+                else pv[q & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, X3_LIN_ADD_AUX));
+              }
+            }
+            if (q > 0) {
+              const int p = q - 1, mi = p >> 1, ni = p & 1;
+              const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+              const unsigned voff16 = 2u * (unsigned)((4 * lk + (li & 1)) * T + wn * 64 + ni * 32 + (li & ~1));
+              const unsigned sbase = 4u * (unsigned)((m0 + wm * 64 + mi * 32) * T + t0);
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {            // rows R = ... + (r & 3) + 8 (r >> 2) and R + 1
+                const unsigned so = sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T);
+                float va = acc[mi][ni][r], vb = acc[mi][ni][r + 1];
+                if (ADD16 && od.add != nullptr) {
+                  const unsigned own = __builtin_bit_cast(unsigned, pv[p & 1][r]);
+                  const unsigned got = (unsigned)__shfl_xor((int)own, 1);
+                  const unsigned ra_ = (li & 1) ? got : own, rb_ = (li & 1) ? own : got;     // (row R, row R + 1) x columns (t, t + 1) of the pair
+                  va += __builtin_bit_cast(float, (li & 1) ? (ra_ & 0xffff0000u) : (ra_ << 16));
+                  vb += __builtin_bit_cast(float, (li & 1) ? (rb_ & 0xffff0000u) : (rb_ << 16));
+                } else { va += pv[p & 1][r]; vb += pv[p & 1][r + 1]; }
+                if constexpr (Y16) {
+                  const unsigned h = pack_bf16x2(va, vb);
+                  const unsigned send = (li & 1) ? (h & 0xffffu) : (h >> 16);
+                  const unsigned got = (unsigned)__shfl_xor((int)send, 1);
+                  const unsigned pr = (li & 1) ? (got | (h & 0xffff0000u)) : ((h & 0xffffu) | (got << 16));
+                  __builtin_amdgcn_raw_buffer_store_b32((int)pr, ry, voff16, so >> 1, X3_LIN_ST_AUX);
+                } else {
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, va), ry, voff, so, X3_LIN_ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vb), ry, voff, so + 4u * (unsigned)T, X3_LIN_ST_AUX);
+                }
+              }
+            }
+          }
+        };
+        if (a.add16 && a.y16) run16(std::true_type{}, std::true_type{});
+        else if (a.y16) run16(std::false_type{}, std::true_type{});
+        else run16(std::true_type{}, std::false_type{});
+        return;
+      }
+    }
     bool fast = (t0 + BN <= T);
     {
 #pragma unroll
@@ -2774,7 +2837,10 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       return 0;
     }
   }
-  VQ_REQUIRE(!g.add16 && !g.y16, "conv_gemm: a bf16 residual stream is served by the streaming 1x1 kernel only (this launch does not qualify)");
+  if (g.add16 || g.y16)
+    VQ_REQUIRE(EPI == EPI_LINEAR && mode == 1 && big && g.Tout % BN == 0 && g.M % 256 == 0 && g.out[1].y == nullptr && !g.out[0].bias &&
+               !g.out[0].relu && !g.out[0].accumulate && g.ksplit == 1,
+               "conv_gemm: a bf16 residual / gradient stream needs matmul mode 1, whole 256-row tiles and a plain (acc + add) epilogue");
   // 256-column tiles when they still give every CU a workgroup (measured at configs[1]: dilated conv
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
   static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
@@ -2819,6 +2885,9 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       if (tap2 && lean) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, true, 3>), dim3((unsigned)nblk), dim3(512), g);
       else if (wide) LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 2, 1, false, 1>), dim3((unsigned)nblk2), dim3(512), g);
       else LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 1, false, 1>), dim3((unsigned)nblk), dim3(512), g);
+    } else if constexpr (EPI == EPI_GATE_BWD) {
+      VQ_REQUIRE(tap2 && xm == 1, "conv_gemm: gate-derivative GEMM with a bf16-stored g_res: [g_res | g_skip] of one shape");
+      LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 1, true, 1>), dim3((unsigned)grid), dim3(256), g);
     } else if constexpr (EPI == EPI_GATE) {
       VQ_REQUIRE(tap2 && lean && xm == 3, "conv_gemm: gate GEMM over a bf16-stored x: both taps, 256 x 128 tiles");
       LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE, 4, 1, 1, true, 3>), dim3((unsigned)nblk), dim3(512), g);
@@ -3417,6 +3486,8 @@ static int bf16_storage_supported(const vqvae_resblock_desc* d) {
   static const int tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
   static const int nb3 = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
   if (x16 && lin128 && lean && tap2 && nb3 != 3 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
+  static const int r16 = getenv("VQVAE_R16") ? atoi(getenv("VQVAE_R16")) : 1;
+  if (r16 && tap2 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->Cs == d->Cr && d->T % 128 == 0) m |= VQVAE_STORE_GX_BF16 | VQVAE_STORE_GRES_BF16;
   return m;
 }
 
@@ -3651,7 +3722,9 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
   float* wpk = packed ? const_cast<float*>(packed) - L.pk_d : w;
   if (packed) VQ_REQUIRE(!gcond && gh_out, "resblock_bwd_packed: the packed form serves ResidualNet's chain (no per-block condition gradient, gh kept)");
   const bool h16 = (d->storage & VQVAE_STORE_GH_BF16) != 0;
-  if (h16) VQ_REQUIRE(packed, "resblock_bwd: a bf16-stored gh (desc.storage) is kept by the packed chain form only");
+  const bool gres16 = g_res && (d->storage & VQVAE_STORE_GRES_BF16), gx16 = gx && (d->storage & VQVAE_STORE_GX_BF16);
+  if (h16 || (d->storage & (VQVAE_STORE_GRES_BF16 | VQVAE_STORE_GX_BF16)))
+    VQ_REQUIRE(packed, "resblock_bwd: bf16-stored gh / gradient stream (desc.storage) are kept by the packed chain form only");
 
   if (!packed) {
   PackArgs pa; pa.njob = 0;
@@ -3684,6 +3757,7 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].amax_out = am ? am->gh : nullptr;
     g.g16 = gates_bf16(d) ? 1 : 0;
     g.h16 = h16 ? 1 : 0;
+    g.x16 = gres16 ? 1 : 0;                       // segment 0 = g_res
     if (int e = launch_gemm<EPI_GATE_BWD>(g, VQVAE_PROF_RESBLOCK_BWD_GZ, st)) return e;
   }
   // K4: gx = g_res + sum_j Wd_j^T gh[t + (K-1-j) dil]
@@ -3704,6 +3778,7 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].add = g_res; g.out[0].add_bstride = (long)d->Cr * T;
     g.out[0].amax_out = am ? am->gx : nullptr;
     g.x16 = h16 ? 3 : 0;
+    g.add16 = gres16 ? 1 : 0; g.y16 = gx16 ? 1 : 0;
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GX, st)) return e;
   }
   // K5: gcond (+)= Wc^T gh
@@ -3969,6 +4044,7 @@ extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.nseg = n;
   wa.accumulate = accumulate;
   wa.x16 = z_bf16(d) ? 1 : 0;
+  wa.g16 = (d->storage & VQVAE_STORE_GRES_BF16) ? 1 : 0;      // every g_res of this launch
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 

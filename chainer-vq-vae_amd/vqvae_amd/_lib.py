@@ -194,6 +194,7 @@ PROTOTYPES = {
 # elementwise op codes / profiler tags (mirror the header)
 MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gemm.hip)
 STORE_X_BF16, STORE_RES_BF16 = 2, 4
+STORE_GX_BF16, STORE_GRES_BF16 = 8, 16
 STORE_GH_BF16 = 1                 # vqvae_resblock_desc.storage bits (VQVAE_STORE_*)
 AMAX_SLOTS = 16                   # uint32 words per absolute maximum (vqvae_absmax, vqvae_resblock_amax)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \

@@ -243,8 +243,14 @@ class ResidualStackFunction(FunctionNode):
         if self.packed is not None and lat is not None:
             store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0])) & _lib.STORE_GH_BF16
         stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16       # the forward's choice for the residual stream stays
-        for dd in self.descs:
-            dd.storage = (dd.storage & stream16) | store
+        gstream = 0                                              # ... and its counterpart, the gradient stream g_res_l = gx_{l+1}
+        if self.packed is not None and lat is not None:
+            sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))
+            if sup & _lib.STORE_GX_BF16 and sup & _lib.STORE_GRES_BF16:
+                gstream = _lib.STORE_GX_BF16 | _lib.STORE_GRES_BF16
+        for l, dd in enumerate(self.descs):
+            gs = (gstream & _lib.STORE_GX_BF16 if l >= 1 else 0) | (gstream & _lib.STORE_GRES_BF16 if l <= nb - 2 else 0)
+            dd.storage = (dd.storage & stream16) | store | gs
         grads = [None] * len(ins)
         g_res = None
         ghs = [None] * nb

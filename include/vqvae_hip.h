@@ -209,6 +209,12 @@ typedef struct {
  *       conv's weight gradient (resstack_dil_wgrad: every block of ONE launch shares the flag).                    */
 #define VQVAE_STORE_X_BF16 2
 #define VQVAE_STORE_RES_BF16 4
+/*   GX / GRES: the residual GRADIENT stream, the backward's counterpart.  GX: this block's gx = bf16(g_res + Wd^T gh)
+ *       is stored as bf16; GRES: this block's g_res is (it is the GX output of the block above).  The block nearest the
+ *       output has no g_res (GX only), the first block's gx leaves the stack as fp32 (GRES only).  Readers: the
+ *       gate-derivative GEMM, the backward-data epilogue's add, resstack_res_wgrad (one flag per launch).          */
+#define VQVAE_STORE_GX_BF16 8
+#define VQVAE_STORE_GRES_BF16 16
 /* the bits the library supports for this block shape in the current matmul mode (0 outside mode 1)    */
 int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 

@@ -458,6 +458,11 @@ def wavenet_bwd(p, cache, cond, gy, n_loop, n_layer):
     for i in range(len(dils) - 1, -1, -1):
         g_res, gc, bg = resblock_bwd(p['blocks'][i], caches[i], cond, dils[i],
                                      g_res, g_skip, need_gx=True)
+        blk = p['blocks'][i]
+        if i >= 1 and g_res.dtype == np.float32 and _STORE16[0] and blk['skip'][0].shape[0] == blk['res'][0].shape[0] and \
+                g_res.shape[2] % 128 == 0 and gh_saved_as_bf16(blk['conv'][0].shape[0] // 2, blk['res'][0].shape[0],
+                                                              blk['skip'][0].shape[0], g_res.shape[2], blk['conv'][0].shape[2]):
+            g_res = bf16_round(g_res)      # the residual gradient stream between the blocks is kept as bf16 (VQVAE_STORE_GX_BF16)
         gcond += gc
         bgrads[i] = bg
     grads['blocks'] = bgrads

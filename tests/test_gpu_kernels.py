@@ -1015,3 +1015,85 @@ def test_bf16_residual_stream_changes_only_the_rounding_point(gpu, bf16_mode):
                 np.testing.assert_array_equal(u, v)
     finally:
         d.storage = 0
+
+
+def test_bf16_gradient_stream_changes_only_the_rounding_point(gpu, bf16_mode):
+    """vqvae_resblock_desc.storage & (VQVAE_STORE_GRES_BF16 | VQVAE_STORE_GX_BF16): one configs-sized block of the packed
+    chain, backward, on a g_res whose values are bf16-representable, read as fp32 and as bf16: gh is bit-identical, the
+    stored gx is the fp32 one rounded -- also in the first block's form (bf16 g_res in, fp32 gx out: bit-identical) and in
+    the last block's (no g_res, bf16 gx out) -- and the res conv's weight and bias gradients over the bf16 g_res equal
+    those over the same values in fp32, bit for bit."""
+    from vqvae_amd import _lib, functions as F
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    B, T, Cr, Cd, Cs, Cc, K, dil, Tl = 2, 512, 256, 256, 256, 192, 2, 8, 8
+    Ch = Cd // 2
+    GH, GRES, GX = _lib.STORE_GH_BF16, _lib.STORE_GRES_BF16, _lib.STORE_GX_BF16
+    d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, dil)
+    assert lib.vqvae_resblock_bf16_storage(C.byref(d)) & (GH | GRES | GX) == (GH | GRES | GX)
+    rs = np.random.RandomState(79)
+    f = lambda *s, sc=1.0: gpu.to_device((rs.standard_normal(s) * sc).astype(np.float32))
+    Wd, bd = f(Cd, Cr, K, 1, sc=0.04), f(Cd, sc=0.1)
+    Wc, bc = f(Cd, Cc, 1, 1, sc=0.05), f(Cd, sc=0.1)
+    Wr, br = f(Cr, Ch, 1, 1, sc=0.08), f(Cr, sc=0.1)
+    Ws, bs = f(Cs, Ch, 1, 1, sc=0.08), f(Cs, sc=0.1)
+    x, P = f(B, Cr, T), f(B, Cd, Tl, sc=0.3)
+    gr = O.bf16_round((rs.standard_normal((B, Cr, T)) * 1e-3).astype(np.float32))
+    g_res32 = gpu.to_device(gr)
+    g_res16 = DeviceArray((B, Cr, T), np.float32)
+    g_res16.fill_zero()
+    half = gpu.to_device(np.ascontiguousarray((gr.view(np.uint32) >> 16).astype(np.uint16)).reshape(-1).view(np.float32))
+    _lib.call('vqvae_memcpy_d2d', g_res16.ptr, half.ptr, B * Cr * T * 2, gpu.stream())
+    g_skip = f(B, Cs, T, sc=1e-3)
+    prm = _lib.ResblockParams(Wd.ptr, bd.ptr, Wc.ptr, bc.ptr, Wr.ptr, br.ptr, Ws.ptr, bs.ptr)
+    packed = DeviceArray((lib.vqvae_resstack_packed_bytes(C.byref(d)) // 4,), np.float32)
+    _lib.call('vqvae_resstack_pack', C.byref(d), 1, (_lib.ResblockParams * 1)(prm), (C.c_int * 1)(1), packed.ptr,
+              packed.nbytes, gpu.stream())
+    tb = F.resize_tables(Tl, T)
+    cp = _lib.ResblockCproj(P.ptr, Cd * Tl, Tl, tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
+    ws = DeviceArray((lib.vqvae_resblock_workspace_bytes(C.byref(d)) // 4 + 1,), np.float32)
+    res, gates, z = (DeviceArray(s, np.float32) for s in ((B, Cr, T), (B, Cd, T), (B, Ch, T)))
+    _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), x.ptr, C.byref(cp), res.ptr, gates.ptr, z.ptr,
+              ws.ptr, ws.nbytes, packed.ptr, None, gpu.stream())
+    wsr = DeviceArray((lib.vqvae_resstack_workspace_bytes(C.byref(d), 1) // 4 + 1,), np.float32)
+
+    def backward(storage, g_res):
+        d.storage = storage
+        gx, gh = DeviceArray((B, Cr, T), np.float32), DeviceArray((B, Cd, T), np.float32)
+        gx.fill_zero()
+        _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), x.ptr, gates.ptr, z.ptr,
+                  g_res.ptr if g_res is not None else None, g_skip.ptr, gx.ptr, gh.ptr, ws.ptr, ws.nbytes, packed.ptr,
+                  None, gpu.stream())
+        out = [gx.get(), gh.get()]
+        if g_res is not None:
+            gW, gb = DeviceArray((Cr, Ch), np.float32), DeviceArray((Cr,), np.float32)
+            _lib.call('vqvae_resstack_res_wgrad', C.byref(d), 1, _lib.ptr_array([g_res]), _lib.ptr_array([z]),
+                      _lib.ptr_array([gW]), _lib.ptr_array([gb]), 0, wsr.ptr, wsr.nbytes, None, gpu.stream())
+            out += [gW.get(), gb.get()]
+        return out
+
+    def decode(a):
+        halves = a.reshape(-1).view(np.uint16)
+        n = B * Cr * T
+        assert not halves[n:].any()
+        return _bf16_bits_to_f32(halves[:n]).reshape(B, Cr, T)
+
+    try:
+        gxA, ghA, gWA, gbA = backward(GH, g_res32)
+        gxB, ghB, gWB, gbB = backward(GH | GRES | GX, g_res16)
+        gxC, ghC, gWC, gbC = backward(GH | GRES, g_res16)
+        gxD, ghD = backward(GH, None)
+        gxE, ghE = backward(GH | GX, None)
+    finally:
+        d.storage = 0
+    assert np.abs(gxA).max() > 0 and np.abs(gxA - gr).max() > 0
+    def _dec(a):                                   # gh is stored as bf16 (GH): the first half of the fp32-sized buffer
+        return _bf16_bits_to_f32(a.reshape(-1).view(np.uint16)[:B * Cd * T]).reshape(B, Cd, T)
+    for gh_, gW_, gb_ in ((ghB, gWB, gbB), (ghC, gWC, gbC)):
+        np.testing.assert_array_equal(_dec(gh_), _dec(ghA))
+        np.testing.assert_array_equal(gW_, gWA)
+        np.testing.assert_array_equal(gb_, gbA)
+    np.testing.assert_array_equal(decode(gxB), O.bf16_round(gxA))
+    np.testing.assert_array_equal(gxC, gxA)
+    np.testing.assert_array_equal(_dec(ghE), _dec(ghD))
+    np.testing.assert_array_equal(decode(gxE), O.bf16_round(gxD))

@@ -1,4 +1,3 @@
-cd $GRAFT_REPO_ROOT
-for v in VQVAE_X3_LEAN=0 VQVAE_X3_TAP2=0 VQVAE_X3_NB=3 X=1; do
-  echo "== $v: $(env $v timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_model.py -m gpu -x -q -k 'config4 or bf16' 2>&1 | tail -1)"
-done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q -k "bf16 or config4" 2>&1 | tail -8
+for g in 1 0; do echo "== VQVAE_R16=$g"; VQVAE_R16=$g bash tools/kstats.sh --workload c5 --bf16 --no-graph --no-fresh-input 2>&1 | sed -n 1,9p | cut -c1-150; done
