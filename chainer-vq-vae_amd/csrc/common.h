@@ -55,5 +55,6 @@ struct ProfScope {
 // before and after the kernel on the stream -- those cost ~5.6 us of idle queue each, 0.22 ms per step when the 20 gate
 // launches of the bench are timed (tools/phase_trace.py).  prof_attach returns false when the tag is not enabled.
 bool prof_attach(int tag, hipEvent_t* start, hipEvent_t* stop);
+bool prof_enabled(int tag);
 
 }  // namespace vq

@@ -2783,11 +2783,11 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   const long grid = nblk * g.ksplit;
   // timing (vqvae_prof_*): the GEMM kernel of this call is timed by its own dispatch's events (a split-K reduce behind it is not)
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
-  const bool attach = prof_attach(tag, &pe0, &pe1);
+  const bool attach = prof_enabled(tag);     // (the pair is registered in front of the launch itself: every check below may still return)
   ProfScope ps(attach ? 0 : tag, st);
 #define LG_LAUNCH(KERNEL, GRID, BLOCK, ARG)                                                                    \
   do {                                                                                                          \
-    if (attach) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, pe0, pe1, 0, ARG);                            \
+    if (attach && prof_attach(tag, &pe0, &pe1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, pe0, pe1, 0, ARG); \
     else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, st, ARG);                                                   \
   } while (0)
   // the K = 128 -> 256-row projection with residual add (the ResidualBlock `res` conv): streaming kernel

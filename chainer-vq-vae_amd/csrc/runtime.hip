@@ -43,6 +43,10 @@ void prof_begin(int tag, hipStream_t s) {
   g_prof_open[tag] = e;
 }
 
+bool prof_enabled(int tag) { return tag > 0 && tag < VQVAE_PROF_NTAGS && (g_prof_mask & (1u << tag)) != 0; }
+
+// (call it immediately in front of the launch the events go to: a pair registered for a launch that then never happens
+// would hold two never-recorded -- or, recycled from an earlier profile, stale -- events)
 bool prof_attach(int tag, hipEvent_t* start, hipEvent_t* stop) {
   if (tag <= 0 || tag >= VQVAE_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return false;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -196,6 +200,7 @@ int vqvae_prof_read(int tag, double* total_ms, int* launches) {
     if (p.tag != tag) continue;
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { tot += ms; ++n; }
+    else (void)hipGetLastError();            // (a pair that was never recorded: not this profile's, and not the next launch's error either)
   }
   *total_ms = tot;
   *launches = n;
