@@ -672,6 +672,9 @@ def main():
                               'the same %d steps with the input leg inside the step: each minibatch starts in host memory '
                               '(8 distinct host minibatches, cycled), page-locked double buffer -> copy stream -> mu-law '
                               'binning on the device (0.5 MB of waveform per step instead of the 125.8 MB one-hot)' % args.steps),
+            'backward': ('loss1 + loss3 back-propagated in one sweep (the encoder walked once with g1 + g3 at z), then vq.cleargrads() and '
+                         'loss2: the gradients of updaters.py:14-18, encoder to fp32 rounding, the rest bit for bit (DESIGN.md section 1)'
+                         if V.updaters.MERGED_BACKWARD else "the reference's three sweeps (updaters.py:14-18)"),
             'comm_ms_per_step': comm_ms_step_max if timed_comm else None,
             'multi_rank_diagnostics': None if not timed_comm else {
                 'allreduce_ms_per_step_max_over_ranks': comm_ms_step_max,

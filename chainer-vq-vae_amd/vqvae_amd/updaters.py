@@ -3,6 +3,7 @@ updaters.py (5-19, 22-77) on minimal StandardUpdater / ParallelUpdater bases
 that provide the attributes the reference's ``update_core`` bodies use
 (``_iterators``, ``converter``, ``_optimizers``, ``loss_func``, ``device``,
 ``get_optimizer``, ``get_iterator``)."""
+import os
 import numpy as np
 
 from . import backend, core
@@ -155,12 +156,34 @@ class StandardUpdater(object):
         self.iteration += 1
 
 
-def three_loss_backward(model, losses):
+# The reference back-propagates its three losses in three sweeps (updaters.py:14-18).  The reconstruction loss and
+# the commitment loss both reach the encoder through ONE variable, its output z (loss1 through the quantiser's
+# straight-through identity, loss3 = beta * mean((z - e.data)^2) directly), and back-propagation is linear: one sweep from
+# loss1 + loss3 hands the encoder g1 + g3 and walks it ONCE -- the same gradients (summation order aside: the two
+# contributions are added at z instead of in every encoder parameter), minus one encoder backward per step (6 backward-data
+# GEMMs, 6 weight gradients and their ~50 small launches: ~0.5 ms of 17 at configs[1]).  The codebook still receives the
+# codebook loss only.  VQVAE_SEQUENTIAL_BACKWARD=1 (or merged=False) runs the reference's three sweeps.
+MERGED_BACKWARD = os.environ.get('VQVAE_SEQUENTIAL_BACKWARD', '0') in ('0', '')
+
+
+def _merged_sweep(losses, merged=None):
+    """Whether loss1 and loss3 are back-propagated in one sweep: the switch, and both must be this package's Variables
+    (anything else that merely has .backward() -- a test double, a foreign autograd -- gets the reference's three sweeps)."""
+    want = MERGED_BACKWARD if merged is None else merged
+    return bool(want) and isinstance(losses[0], core.Variable) and isinstance(losses[2], core.Variable)
+
+
+def three_loss_backward(model, losses, merged=None):
     """The gradient routing of the reference's updaters (updaters.py:14-18, 58-69):
     clear everything, back-propagate the reconstruction loss, throw away what it put on the
     codebook, then add the codebook loss (-> vq.W only) and the commitment loss (-> encoder)."""
     loss1, loss2, loss3 = losses
     model.cleargrads()
+    if _merged_sweep(losses, merged):
+        (loss1 + loss3).backward()      # decoder, condition embed, encoder (g1 + g3 at z); the codebook's share is discarded next
+        model.vq.cleargrads()
+        loss2.backward()
+        return
     loss1.backward()
     model.vq.cleargrads()
     loss2.backward()
@@ -203,21 +226,24 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         self.overlap_comm = overlap_comm
         self._buckets = None
 
-    def _grad_buckets(self, optimizer, model):
+    def _grad_buckets(self, optimizer, model, merged=False):
         """(early, late): contiguous [offset, size) runs of the gradient arena.  `late` = what
         loss2 / loss3 still write after loss1's backward -- the parameters of ``model.vq`` and
         ``model.encoder`` (updaters.py:16-18), found BY IDENTITY in the optimizer's layout, whatever the
         links are called and wherever the VAE sits inside ``optimizer.target`` -- `early` = the rest.
         A model without those two links, or one whose late set comes out empty, has no early bucket at
         all (raises): exchanging a gradient before its last writer has run would be silently wrong."""
-        key = core.param_epoch('layout')
+        key = (core.param_epoch('layout'), bool(merged))
         if self._buckets is None or self._buckets[0] != key:
             enc, vq = getattr(model, 'encoder', None), getattr(model, 'vq', None)
             if enc is None or vq is None:
                 raise RuntimeError('overlap_comm needs a model with .encoder and .vq links (the parameters the '
                                    'codebook / commitment losses still write after the reconstruction loss); got %s'
                                    % type(model).__name__)
-            late_ids = {id(p) for link in (enc, vq) for p in link.params() if p.data is not None}
+            # (merged sweeps, see three_loss_backward: the first sweep already finishes the encoder; only the codebook
+            # is still written by the second)
+            late_links = (vq,) if merged else (enc, vq)
+            late_ids = {id(p) for link in late_links for p in link.params() if p.data is not None}
             by_name = {n: p for n, p in optimizer.target.namedparams()}
             early, late = [], []
             n_late = 0
@@ -292,19 +318,24 @@ class VQVAE_ParallelUpdater(StandardUpdater):
     def _update_overlapped(self, optimizer, model):
         """three_loss_backward with the exchange of the early bucket on the side stream."""
         loss1, loss2, loss3 = self.last_losses
+        merged = _merged_sweep(self.last_losses)
         model.cleargrads()
-        loss1.backward()
+        if merged:
+            (loss1 + loss3).backward()
+        else:
+            loss1.backward()
         model.vq.cleargrads()
         adopt = getattr(optimizer, 'adopt_new_params', None)
         if adopt is not None and adopt() and self.comm.size > 1:
             self._check_replicas(optimizer)
-        early, late = self._grad_buckets(optimizer, self.loss_func_model(model))
+        early, late = self._grad_buckets(optimizer, self.loss_func_model(model), merged)
         main, side = backend.stream(), backend.side_stream()
         backend.wait_event(side, backend.Event().record(main))      # loss1's gradients are complete
         for off, size in early:
             self.comm.allreduce_grad(optimizer.grads.flat_view(off, size), stream=side)
         loss2.backward()
-        loss3.backward()
+        if not merged:
+            loss3.backward()
         for off, size in late:
             self.comm.allreduce_grad(optimizer.grads.flat_view(off, size))
         backend.wait_event(main, backend.Event().record(side))      # join before the optimizer reads the arena

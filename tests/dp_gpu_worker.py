@@ -98,7 +98,9 @@ def run_rank(rank, n, directory, overlap=False):
     upd = V.VQVAE_ParallelUpdater(_Iter(_examples()), opt, comm=comm, device=0, overlap_comm=overlap)
     for _ in range(STEPS):
         upd.update()
-    assert comm.calls == STEPS * (len(upd._grad_buckets(opt, model)[0]) + len(upd._grad_buckets(opt, model)[1]) if overlap else 1)
+    from vqvae_amd.updaters import MERGED_BACKWARD
+    bk = upd._grad_buckets(opt, model, MERGED_BACKWARD)
+    assert comm.calls == STEPS * (len(bk[0]) + len(bk[1]) if overlap else 1)
     upd._check_replicas(opt)        # the parameter-checksum path (runs when lazily shaped parameters are adopted under N > 1)
     np.save(os.path.join(directory, 'params_rank%d.npy' % rank), opt.params.get())
     np.save(os.path.join(directory, 'losses_rank%d.npy' % rank),

@@ -438,3 +438,44 @@ def test_graphed_step_equals_eager_step(gpu, index_input):
     np.testing.assert_array_equal(pa, pb)
     np.testing.assert_array_equal(ma, mb)
     np.testing.assert_array_equal(va, vb)
+
+
+@pytest.mark.gpu
+def test_one_sweep_for_loss1_and_loss3_gives_the_three_sweep_gradients(gpu):
+    """updaters.three_loss_backward: the reconstruction loss and the commitment loss reach the encoder through one
+    variable (its output z), so the default back-propagates loss1 + loss3 in ONE sweep (the encoder is walked once
+    with g1 + g3) instead of the reference's separate sweeps (updaters.py:14-18).  Same gradients: the decoder's,
+    the condition embed's and the codebook's bit for bit (nothing about their sweeps changes), the encoder's to fp32
+    rounding (g1 + g3 are added at z instead of in every parameter); and the whole step still matches the oracle's
+    three sweeps."""
+    import vqvae_amd as V
+    from vqvae_amd import updaters
+    cfg = dict(H.SMALL)
+    batch = O.synth_batch(3, length=512, n_speaker=cfg['n_speaker'], seed=91)
+
+    def grads(merged):
+        P, model = H.build_model(cfg, seed=6)
+        model.to_gpu()
+        ex = [(batch[0][i][..., None], batch[1][i][..., None], batch[2][i], batch[3][i][..., None]) for i in range(3)]
+        arrays = V.concat_examples(ex, device=0)
+        losses = model(*arrays)
+        model(*arrays) if False else None
+        updaters.three_loss_backward(model, losses, merged=merged)
+        return P, {n: p.grad.get().copy() for n, p in model.namedparams() if p.grad is not None}, [float(l.data.get()) for l in losses]
+
+    P, ga, la = grads(True)
+    _, gb, lb = grads(False)
+    assert la == lb and set(ga) == set(gb) and len(ga) > 40
+    n_enc = 0
+    for name in ga:
+        a, b = ga[name], gb[name]
+        if name.startswith('/encoder'):
+            n_enc += 1
+            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), name
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    assert n_enc >= 10
+    losses, cache, G = O.train_step(P, {}, batch, cfg['n_loop'], cfg['n_layer'])
+    for name, arr in G.items():
+        got = ga[H._dev_name(name, False)].reshape(arr.shape)
+        assert np.abs(got - arr).max() <= 1e-5 * max(np.abs(arr).max(), 1e-30) + 1e-9, name
