@@ -173,21 +173,42 @@ def _merged_sweep(losses, merged=None):
     return bool(want) and isinstance(losses[0], core.Variable) and isinstance(losses[2], core.Variable)
 
 
+class _codebook_share_discarded(object):
+    """The reconstruction loss's sweep also reaches the codebook (through e = vq(z)), and the very next statement of the
+    reference throws that gradient away (``model.vq.cleargrads()``, updaters.py:16).  While this context is open the
+    codebook parameters do not ask for a gradient, so the sweep does not compute what is discarded (the fp64 scatter of
+    utils.py:227-228: ~70 us per step at the configs); the result of the three-loss routine is unchanged."""
+
+    def __init__(self, model):
+        vq = getattr(model, 'vq', None)
+        self.params = [p for p in vq.params()] if isinstance(vq, core.Link) else []
+
+    def __enter__(self):
+        self.old = [p.requires_grad for p in self.params]
+        for p in self.params:
+            p.requires_grad = False
+
+    def __exit__(self, *exc):
+        for p, r in zip(self.params, self.old):
+            p.requires_grad = r
+        return False
+
+
 def three_loss_backward(model, losses, merged=None):
     """The gradient routing of the reference's updaters (updaters.py:14-18, 58-69):
     clear everything, back-propagate the reconstruction loss, throw away what it put on the
     codebook, then add the codebook loss (-> vq.W only) and the commitment loss (-> encoder)."""
     loss1, loss2, loss3 = losses
     model.cleargrads()
-    if _merged_sweep(losses, merged):
-        (loss1 + loss3).backward()      # decoder, condition embed, encoder (g1 + g3 at z); the codebook's share is discarded next
-        model.vq.cleargrads()
-        loss2.backward()
-        return
-    loss1.backward()
+    with _codebook_share_discarded(model):
+        if _merged_sweep(losses, merged):
+            (loss1 + loss3).backward()  # decoder, condition embed, encoder (g1 + g3 at z)
+        else:
+            loss1.backward()
     model.vq.cleargrads()
     loss2.backward()
-    loss3.backward()
+    if not _merged_sweep(losses, merged):
+        loss3.backward()
 
 
 class VQVAE_StandardUpdater(StandardUpdater):
@@ -320,10 +341,11 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         loss1, loss2, loss3 = self.last_losses
         merged = _merged_sweep(self.last_losses)
         model.cleargrads()
-        if merged:
-            (loss1 + loss3).backward()
-        else:
-            loss1.backward()
+        with _codebook_share_discarded(model):
+            if merged:
+                (loss1 + loss3).backward()
+            else:
+                loss1.backward()
         model.vq.cleargrads()
         adopt = getattr(optimizer, 'adopt_new_params', None)
         if adopt is not None and adopt() and self.comm.size > 1:
