@@ -41,8 +41,14 @@ class GraphedStep(object):
         self.key, self.stage, self.arena, self.graph, self.losses, self.keep = key, stage, arena, graph, losses, keep
 
     def load(self, in_arrays):
+        # raw copies: the staging arrays never carry an absolute maximum (the recording scans them itself, so every
+        # replay derives its float32x2 scales from the data it was handed -- ADVICE r4)
+        from . import _lib
         for dst, src in zip(self.stage, in_arrays):
-            dst.copy_from(src)
+            if src.nbytes != dst.nbytes:
+                raise ValueError('size mismatch in GraphedStep.load')
+            _lib.call('vqvae_memcpy_d2d', dst.ptr, src.ptr, dst.nbytes, backend.stream())
+            dst.amax = None
 
     def launch(self):
         from . import _lib
@@ -59,11 +65,13 @@ class GraphedStep(object):
 
 
 def _like(a):
-    """A fresh device array of ``a``'s shape, dtype and class (IndexInput keeps its quantize)."""
+    """A fresh device array of ``a``'s shape, dtype and class (IndexInput keeps its quantize).  NOT its absolute
+    maximum: a staging array that inherited one would make the recording skip its scan and bake the pointer to THAT
+    batch's maximum into the graph -- every replay would then scale new data by a stale maximum."""
     out = a.__class__.__new__(a.__class__)
     backend.DeviceArray.__init__(out, a.shape, a.dtype)
     for slot in getattr(a.__class__, '__slots__', ()):
-        if slot not in ('ptr', 'shape', 'dtype', '_block', '__weakref__') and hasattr(a, slot):
+        if slot not in ('ptr', 'shape', 'dtype', '_block', 'amax', '__weakref__') and hasattr(a, slot):
             setattr(out, slot, getattr(a, slot))
     return out
 

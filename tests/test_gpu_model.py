@@ -441,6 +441,63 @@ def test_graphed_step_equals_eager_step(gpu, index_input):
 
 
 @pytest.mark.gpu
+def test_graphed_step_rescans_the_maximum_of_every_replayed_batch(gpu):
+    """a recording made from a batch that already carried a cached absolute maximum (float32x2, every conv on
+    the three-product kernels) must not bake that batch's maximum into the graph.  The staging arrays start without one,
+    so the scan is part of the recording; replaying a batch whose peak is 4x larger then gives the eager step's bits
+    (with a stale scale its fp16 high pieces would overflow to inf)."""
+    import vqvae_amd as V
+    from vqvae_amd import backend
+    from vqvae_amd.inputs import DeviceInputPipeline
+    from vqvae_amd.optimizers import Adam
+    if backend._lib.load().vqvae_get_matmul_dtype() != 3:
+        pytest.skip('float32x2 only')
+    cfg = dict(H.SMALL)
+    L = 512
+    gains = [0.2, 0.2, 0.2, 0.9, 0.2, 0.9]
+    data = []
+    for s, g in enumerate(gains):
+        x_enc, _, spk, _ = O.synth_batch(3, length=L, n_speaker=cfg['n_speaker'], seed=500 + s)
+        raw = np.ascontiguousarray(x_enc[:, 0, :], np.float32)
+        raw = raw / np.abs(raw).max() * g
+        data.append((raw, np.asarray(spk, np.int32)))
+    backend.set_f32x2_min_gflop(0)
+    try:
+        def run(graph):
+            _, model = H.build_model(cfg, seed=4)
+            model.to_gpu()
+            opt = Adam(2e-4)
+            opt.setup(model)
+            pipe = DeviceInputPipeline(256)
+
+            class It(object):
+                i = 0
+
+                def next(self):
+                    It.i += 1
+                    arrays = pipe(*data[It.i - 1])
+                    backend.absmax(arrays[0])          # the batch arrives with its maximum already cached
+                    return arrays
+            upd = V.VQVAE_StandardUpdater(It(), opt, converter=lambda b, dev: b, device=0, graph=graph)
+            losses = []
+            for _ in gains:
+                upd.update()
+                losses.append([l.data.get().copy() for l in upd.last_losses])
+            if graph:
+                assert upd._graphed is not None and all(a.amax is None for a in upd._graphed.stage)
+            return losses, opt.params.get()
+        la, pa = run(True)
+        lb, pb = run(False)
+    finally:
+        backend.set_f32x2_min_gflop(8)
+    for a, b in zip(la, lb):
+        for u, v in zip(a, b):
+            assert np.isfinite(u).all()
+            np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(pa, pb)
+
+
+@pytest.mark.gpu
 def test_one_sweep_for_loss1_and_loss3_gives_the_three_sweep_gradients(gpu):
     """updaters.three_loss_backward: the reconstruction loss and the commitment loss reach the encoder through one
     variable (its output z), so the default back-propagates loss1 + loss3 in ONE sweep (the encoder is walked once
@@ -459,7 +516,6 @@ def test_one_sweep_for_loss1_and_loss3_gives_the_three_sweep_gradients(gpu):
         ex = [(batch[0][i][..., None], batch[1][i][..., None], batch[2][i], batch[3][i][..., None]) for i in range(3)]
         arrays = V.concat_examples(ex, device=0)
         losses = model(*arrays)
-        model(*arrays) if False else None
         updaters.three_loss_backward(model, losses, merged=merged)
         return P, {n: p.grad.get().copy() for n, p in model.namedparams() if p.grad is not None}, [float(l.data.get()) for l in losses]
 
