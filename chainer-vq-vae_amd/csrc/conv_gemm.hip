@@ -51,6 +51,19 @@ static int g_matmul_dtype = 2;
 static int g_wgrad_impl = 0;      // 0: auto; 1: force the generic wgrad_kernel (tests / A-B timing)
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;   // wgrad tiles; conv_gemm derives BM/NT from WM
+
+// Dev aid (-DVQ_PHASE_TIMING, tools/experiments/phases.py; never in the product build): s_memtime stamps at the phase
+// boundaries of the two-tap float32x2 kernels, summed per epilogue kind over one workgroup thread -- how round 5 found
+// the gate epilogue's 40 k cycles of dependent condition loads.  [EPI][0..3] = sums of prologue / K loop / condition step /
+// epilogue ticks, [4] = workgroups, [5] / [6] (gate) = epilogue phase 1 (loads) / phase 2 issue.
+#ifdef VQ_PHASE_TIMING
+__device__ unsigned long long g_phase[3][8];
+#define VQ_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#define VQ_PHASE_ADD(EP_, I_, V_) do { if (threadIdx.x == 0) atomicAdd(&g_phase[EP_][I_], (unsigned long long)(V_)); } while (0)
+#else
+#define VQ_STAMP(v)
+#define VQ_PHASE_ADD(EP_, I_, V_)
+#endif
 constexpr int MAXSEG = 24;   // a whole ResidualNet's blocks can feed one contraction
 constexpr int MAXTAPS = 4;
 
@@ -84,6 +97,10 @@ enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_GATE_BWD = 2 };
 struct Lerp {           // epilogue add of an up-sampled latent-rate tensor (align-corners lerp)
   const float* P; long p_bstride; int Tl;
   const int* v0; const float* w0; const float* w1;
+  // fold != 0 (the two-tap 256 x 128-tile gate kernels, modes 2 / 3): the lerp runs on the matrix pipe as ONE more K step
+  // instead of 128 dependent loads per lane in the epilogue -- see "the condition as a K step" in conv_gemm_x3_kernel;
+  // amax: max |P| (float32x2: it joins the launch's product scale)
+  int fold; const unsigned* amax;
 };
 
 struct GemmArgs {
@@ -113,6 +130,16 @@ struct GemmArgs {
   int add16, y16; // matmul mode 1 only, the streaming residual 1x1 (lin128_stream_kernel): out[0].add is read / out[0].y is stored as bf16 (the residual stream x_l, vqvae_resblock_desc::storage)
   int h16;       // matmul mode 1 only: EPI_GATE_BWD stores gh (out[0].y) as bf16 (same element strides, 2-byte elements)
   int z16;       // matmul mode 1 only: EPI_GATE writes z (out[1]) as bf16; a linear GEMM reads the activations of EVERY segment as bf16 (the z tensors)
+  // matmul mode 3 (float32x2 launches), PRE-SPLIT storage (see presplit_pair): x16 = the same segment mask, here "stored
+  // as fp16 hi | lo dwords" (same addresses as fp32; the segment's `amax` words are the scale words its producer wrote);
+  // h16 = EPI_GATE_BWD stores gh that way under the bound sum_seg bound_l1[seg] * max|x_seg|, published to scale_out
+  const float* bound_l1; unsigned* scale_out;
+  // ... and the streaming residual 1x1 (lin128_stream_kernel): add16 / y16 = x_l read / x_{l+1} stored pre-split; add_scale =
+  // the scale words of x_l, add_amax = its ACTUAL maximum, bound_l1[0] = max_r (sum_c |Wr[r][c]| + |br[r]|)
+  const unsigned* add_scale; const unsigned* add_amax;
+  // ... whose scale also leaves room for the NEXT block's condition step (see "the condition as a K step"): the exponent
+  // of x_{l+1}'s scale is at least e(max |P|) - e(max |Wd_{l+1}|) - 1 (floor_p / floor_w: those maxima; NULL = no floor)
+  const unsigned* floor_w; const unsigned* floor_p;
 };
 
 // Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error
@@ -224,6 +251,8 @@ __device__ __forceinline__ void buf_st_gate(float v, rsrc_t r, unsigned voff, un
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, X3_GATE_ST_AUX);
 }
 
+__device__ __forceinline__ void presplit_pair(float x0, float x1, int k, unsigned& d0, unsigned& d1);   // (float32x2 pre-split storage: defined beside split2)
+
 // WM = wavefronts along M: block tile (64*WM) x 128 with 128*WM threads.  WM = 4 (256 rows)
 // halves the activation-tile loads per FLOP and is used whenever M >= 256.
 // Epilogue of the conv GEMM kernels: acc[mi][ni] is the wave's 2 x 2 block of 32 x 32 accumulator tiles
@@ -232,10 +261,12 @@ __device__ __forceinline__ void buf_st_gate(float v, rsrc_t r, unsigned voff, un
 // DEEP: the linear epilogue requests a whole block's operands up front (needs 64 more registers).
 // ST16: the instantiation may be asked for bf16-stored tensors (GemmArgs::g16 / h16 / z16: matmul mode 1's kernels only --
 // the other modes' kernels do not carry those paths: they cost the float32x2 gate-derivative kernel 24 spilled registers).
-template <int EPI, int WM, bool SPLITK, bool DEEP = false, bool ST16 = false>
+// OUT = 1 (EPI_GATE_BWD, float32x2): gh is stored PRE-SPLIT under 2^kout (presplit_pair; `am` still collects the actual maximum).
+template <int EPI, int WM, bool SPLITK, bool DEEP = false, bool ST16 = false, int OUT = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], const int m0, const int t0,
                                               const int b, const int wm, const int wn, const int li, const int lk,
-                                              const int ksp, const int tile_id, const int ntiles_all) {
+                                              const int ksp, const int tile_id, const int ntiles_all, [[maybe_unused]] const int kout = 0,
+                                              [[maybe_unused]] const bool folded = false) {      // folded (EPI_GATE): the K loop added the condition term
   // ---- epilogue ----------------------------------------------------------
   // C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int T = a.Tout;
@@ -501,23 +532,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
     // Phase 1 -- pre-activations completed in place in the accumulators: biases and the lerp of the
     // latent-rate condition projection.  No store has been issued yet, so all of these loads overlap
     // (a load behind a may-alias store would wait for the store's acknowledgement: one in-order counter).
+    const float* Pb = (a.lerp.P && !folded) ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;      // (folded: the K loop added it)
     int tt[2], vv[2];
     float w0v[2], w1v[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       tt[ni] = t0 + wn * 64 + ni * 32 + li;
       const bool tok = tt[ni] < T;
-      vv[ni] = (tok && a.lerp.P) ? a.lerp.v0[tt[ni]] : 0;
-      w0v[ni] = (tok && a.lerp.P) ? a.lerp.w0[tt[ni]] : 0.f;
-      w1v[ni] = (tok && a.lerp.P) ? a.lerp.w1[tt[ni]] : 0.f;
+      vv[ni] = (tok && Pb) ? a.lerp.v0[tt[ni]] : 0;
+      w0v[ni] = (tok && Pb) ? a.lerp.w0[tt[ni]] : 0.f;
+      w1v[ni] = (tok && Pb) ? a.lerp.w1[tt[ni]] : 0.f;
     }
-    const float* Pb = a.lerp.P ? a.lerp.P + (long)b * a.lerp.p_bstride : nullptr;
     const rsrc_t rP = make_rsrc(Pb);
     const int chl = 32 * g + 4 * lk;            // this lane's first channel; row r adds (r&3) + 8*(r>>2)
     unsigned vP[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) vP[ni] = 4u * (unsigned)(chl * a.lerp.Tl + vv[ni]);
     const unsigned sPq = 4u * (unsigned)(Ch * a.lerp.Tl);
+    if (Pb || og.bias || og.bias2)       // (wave-uniform; nothing to add when the K loop folded the condition and P carries the biases)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dr = (r & 3) + 8 * (r >> 2);
@@ -538,6 +570,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         acc[1][ni][r] = (acc[1][ni][r] + bb) + pb;
       }
     }
+#ifdef VQ_PHASE_TIMING
+    VQ_STAMP(te0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VQ_STAMP(te1);
+    VQ_PHASE_ADD(1, 5, te1 - te0);
+#endif
     // Phase 2 -- gate and the three stores per element
     const rsrc_t rG = make_rsrc(og.y + (long)b * og.y_bstride);
     // z is read only through GEMM staging; in matmul mode 1 that staging rounds it to bf16 anyway, so it is
@@ -645,6 +683,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
                   const unsigned pr = pack_bf16x2(ga, gb);
                   __builtin_amdgcn_raw_buffer_store_b16((short)(pr & 0xffffu), rGh16, voff >> 1, so >> 1, X3_GBWD_ST_AUX);
                   __builtin_amdgcn_raw_buffer_store_b16((short)(pr >> 16), rGh16, voff >> 1, (so + sQ) >> 1, X3_GBWD_ST_AUX);
+                } else if constexpr (OUT == 1) {
+                  am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
+                  unsigned da, db;
+                  presplit_pair(ga, gb, kout, da, db);
+                  __builtin_amdgcn_raw_buffer_store_b32((int)da, rGh, voff, so, X3_GBWD_ST_AUX);
+                  __builtin_amdgcn_raw_buffer_store_b32((int)db, rGh, voff, so + sQ, X3_GBWD_ST_AUX);
                 } else {
                   am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
                   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ga), rGh, voff, so, X3_GBWD_ST_AUX);
@@ -1019,6 +1063,46 @@ __device__ __forceinline__ void split2(float x0, float x1, int k, unsigned& h, u
   lv[0] = (_Float16)(y0 - (float)hb[0]); lv[1] = (_Float16)(y1 - (float)hb[1]);
   l = __builtin_bit_cast(unsigned, lv);
 }
+// ---------------------------------------------------------------------------
+// `float32x2`, PRE-SPLIT storage (vqvae_resblock_desc::storage & VQVAE_STORE_*_F16X2).
+//
+// A tensor of ResidualNet's chain that is read back only as a float32x2 MFMA operand -- the residual stream x_l (gate
+// GEMM, dilated weight gradient) and gh_l (backward-data GEMM, dilated weight gradient) -- reaches THREE consumers, each
+// of which split every element it staged (split2: 4 VALU per element, a third of the K loops' instruction stream once
+// the MFMAs were halved).  Its producer now writes it split, ONCE: one dword per element at the fp32 element's
+// address = fp16 hi | fp16 lo << 16 of x * 2^k, so every consumer keeps its addressing and stages two elements with
+// two v_perm_b32 (presplit_stage).  k must be known BEFORE the producer runs, so it comes from a rigorous a-priori
+// BOUND on the tensor's absolute maximum instead of the maximum itself:
+//     |x_{l+1}| = |x_l + Wr z + br| <= max|x_l| + max_r (sum_c |Wr[r][c]| + |br[r]|)          (|z| = |tanh * sigmoid| <= 1)
+//     |gh_l| <= |gz| = |Wr^T g_res + Ws^T g_skip| <= max_c sum_r |Wr[r][c]| * max|g_res| + max_c sum_s |Ws[s][c]| * max|g_skip|
+// (the maxima on the right are the ACTUAL ones, published by the producers' epilogues as before; the weight norms are
+// found once per step by wl1_kernel).  The producer writes the bound into the tensor's SCALE words -- the group of
+// AMAX_SLOTS words its consumers are handed in place of the maximum -- so consumers derive the very k it used.  A bound
+// that is 2^m above the true maximum costs m of the 2^-39 absolute precision bits (an element within 2^-(15-m) of
+// the maximum still carries a full fp32 significand): see DESIGN.md 3a for the numbers (m = 1-2 for x, 4-6 for gh).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void presplit_pair(float x0, float x1, int k, unsigned& d0, unsigned& d1) {   // the stored dwords of two elements
+  unsigned h, l;
+  split2(x0, x1, k, h, l);
+  d0 = __builtin_amdgcn_perm(l, h, 0x05040100u);        // hi(x0) | lo(x0) << 16
+  d1 = __builtin_amdgcn_perm(l, h, 0x07060302u);        // hi(x1) | lo(x1) << 16
+}
+__device__ __forceinline__ void presplit_stage(float d0, float d1, unsigned& h, unsigned& l) {            // two stored elements -> the fp16 pair of each piece
+  h = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, d1), __builtin_bit_cast(unsigned, d0), 0x05040100u);
+  l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, d1), __builtin_bit_cast(unsigned, d0), 0x07060302u);
+}
+__device__ __forceinline__ float presplit_scaled(float d) {       // hi + lo = x * 2^k (exact in fp32: 22 significant bits)
+  const f16x2 v = __builtin_bit_cast(f16x2, d);
+  return (float)v[0] + (float)v[1];
+}
+__device__ __forceinline__ float presplit_value(float d, int kinv) { return __builtin_ldexpf(presplit_scaled(d), kinv); }
+// a bound enters the scale words with a margin for the roundings of what it bounds (fp32 accumulation over <= 2560
+// terms: relative 2^-12 at worst) and never as zero (an all-zero tensor keeps a finite scale)
+__device__ __forceinline__ float bound_margin(float b) { return fmaxf(b * 1.001f, 1e-30f); }
+__device__ __forceinline__ void scale_publish(unsigned* scale_out, float bound) {     // word 0; the caller zeroed the group
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = __builtin_bit_cast(unsigned, bound);
+}
+
 // one 32 x 32 x 16 MFMA on 16-byte fragment words: fp16 (NP == 2) or bf16 operands
 template <int NP>
 __device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
@@ -1060,12 +1144,17 @@ __device__ __forceinline__ f32x16 mfma_chain(const uint4 (&a)[NP], const uint4 (
 // X16 (matmul mode 1): activations that are STORED as bf16 (GemmArgs::z16 / x16) are fetched with 2-byte loads and
 // staged without a conversion.  Bit 0: segment 0 of a TAP2 launch / every segment of any other launch; bit 1: the
 // second segment of a TAP2 launch (the two may differ: g_res fp32 | g_skip bf16 in the gate-derivative GEMM).
-template <int EPI, int WM, int NB, int NP, bool TAP2 = false, int X16 = 0>
+// (matmul mode 3, NP = 2: the same X16 mask marks PRE-SPLIT segments -- fp16 hi | lo dwords at the fp32 addresses, staged
+// with two v_perm_b32 per element pair instead of split2; OUT = 1: EPI_GATE_BWD stores gh that way.)
+template <int EPI, int WM, int NB, int NP, bool TAP2 = false, int X16 = 0, int OUT = 0>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
-  static_assert(X16 == 0 || NP == 1, "bf16-stored activations: mode 1 only");
+  static_assert(X16 == 0 || NP == 1 || NP == 2, "bf16-stored activations: mode 1; pre-split activations: mode 3");
+  static_assert(OUT == 0 || (NP == 2 && EPI == EPI_GATE_BWD), "pre-split output: the float32x2 gate-derivative GEMM");
   static_assert(X16 >= 0 && X16 <= (TAP2 ? 3 : 1), "X16: one bit per TAP2 segment, one bit otherwise");
-  constexpr bool RAW0 = (X16 & 1) != 0, RAW1 = TAP2 ? (X16 & 2) != 0 : RAW0;
+  constexpr bool SEL0 = (X16 & 1) != 0, SEL1 = TAP2 ? (X16 & 2) != 0 : SEL0;
+  constexpr bool RAW0 = SEL0 && NP == 1, RAW1 = SEL1 && NP == 1;      // stored as bf16 (2-byte elements, staged as they are)
+  constexpr bool PRE0 = SEL0 && NP == 2, PRE1 = SEL1 && NP == 2;      // stored pre-split (4-byte elements, staged by presplit_stage)
   constexpr unsigned ESZ = RAW0 ? 2u : 4u, ESZ1 = RAW1 ? 2u : 4u;     // bytes per activation element (segment 0 / TAP2's segment 1)
   [[maybe_unused]] auto of_seg1 = [](unsigned v) -> unsigned { return ESZ1 == ESZ ? v : (ESZ1 > ESZ ? v << 1 : v >> 1); };   // a byte offset of segment 0 -> the same element of segment 1
   static_assert(NP >= 1 && NP <= 3, "one piece (bf16 operands), two (fp16 hi + lo, scaled) or three (exact bf16 split)");
@@ -1074,9 +1163,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   constexpr int NQ = NT / BNW;            // staging threads per tile column
   constexpr int CPT = BK / NQ;            // channels per staging thread and K step: 8 or 4
   constexpr bool SPLITK = (EPI == EPI_LINEAR && WM == 2);
-  __shared__ uint4 As[2][NP][2][BM];
-  __shared__ uint4 Bs[2][NP][2][BNW];
+  // (the two-piece gate kernel of the 256 x 128-tile two-tap loop keeps a THIRD image: the condition step's operands, staged in
+  // the prologue -- see "the condition as a K step"; 73 KB per workgroup, still two per CU)
+  constexpr int NBUF = (EPI == EPI_GATE && NB == 1 && NP == 2 && TAP2 && WM == 4 && X3_LEAN) ? 3 : 2;
+  __shared__ uint4 As[NBUF][NP][2][BM];
+  __shared__ uint4 Bs[NBUF][NP][2][BNW];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
+  VQ_STAMP(tp0);
 
   const int nblk = gridDim.x;
   int logical;
@@ -1127,7 +1220,34 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       const int eb = amax_expo(sg.amax ? amax_load(sg.amax) : __builtin_bit_cast(unsigned, sg.amax_static));
       em = max(em, amax_expo(amax_load(sg.wamax)) + eb);
     }
+    // the condition step's products P * c, c <= 1, join the scale -- unless the activations are PRE-SPLIT: their scale,
+    // hence the launch's, was fixed by their producer (which saw max |P| too: lin128_stream_kernel's floor)
+    if (EPI == EPI_GATE && a.lerp.fold && !PRE0) em = max(em, amax_expo(amax_load(a.lerp.amax)));
     emax = em;
+  }
+  // the condition as a K step (see behind the two-tap loop): P is scaled by 2^kp, its lerp coefficients by 2^kc, kp + kc = the
+  // launch's product scale 28 - emax.  A pre-split x pins emax; should max |P| then need kc > 15 (the coefficients would leave
+  // fp16's range: lin128_stream_kernel's floor on x's scale rules it out inside ResidualNet's chain) the epilogue lerps as before.
+  [[maybe_unused]] bool fold = EPI == EPI_GATE && a.lerp.fold != 0;
+  [[maybe_unused]] int kp = 0, kc = 0;
+  if constexpr (NP == 2 && EPI == EPI_GATE) {
+    if (fold) {
+      const int ep = amax_expo(amax_load(a.lerp.amax));
+      kp = 14 - ep; kc = 14 - emax + ep;
+      if (kc > 15) fold = false;
+    }
+  }
+  // pre-split output (OUT): the power of two gh is stored under, from the a-priori bound sum_seg l1[seg] * max|x_seg|
+  [[maybe_unused]] int kout = 0;
+  if constexpr (OUT == 1) {
+    float bound = 0.f;
+    for (int s = 0; s < a.nseg; ++s) {
+      const Seg& sg = a.seg[s];
+      bound += a.bound_l1[s] * __builtin_bit_cast(float, sg.amax ? amax_load(sg.amax) : __builtin_bit_cast(unsigned, sg.amax_static));
+    }
+    bound = bound_margin(bound);
+    kout = 14 - amax_expo(__builtin_bit_cast(unsigned, bound));
+    scale_publish(a.scale_out, bound);
   }
   [[maybe_unused]] int kcur = 0, k1 = 0;    // scale exponent of the segment the fetch cursor is in (TAP2: of segment 0 / segment 1)
 
@@ -1202,12 +1322,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // staging of one K step's activations: split (or round) this thread's CPT channels of its column, one 8- or 16-byte
   // LDS write per piece.  KX: the segment's scale exponent (NP == 2)
   auto stage_b = [&](auto rawc, const float (&bv)[CPT], const int kx, const int buf) {
-    constexpr bool RAW = decltype(rawc)::value;                // the elements arrived as bf16 bits
+    constexpr bool RAW = decltype(rawc)::value;                // the elements arrived as bf16 bits (NP == 1) / as pre-split dwords (NP == 2)
     unsigned pc[NP][CPT / 2];                                  // [piece][channel pair]
 #pragma unroll
     for (int e = 0; e < CPT; e += 2) {
       const float v0 = bv[e], v1 = bv[e + 1];                  // out-of-range elements arrived as 0
       if constexpr (NP == 3) split3(v0, v1, pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);
+      else if constexpr (NP == 2 && RAW) presplit_stage(v0, v1, pc[0][e / 2], pc[1][e / 2]);
       else if constexpr (NP == 2) split2(v0, v1, kx, pc[0][e / 2], pc[1][e / 2]);
       else if constexpr (RAW) pc[0][e / 2] = __builtin_bit_cast(unsigned, v0) | (__builtin_bit_cast(unsigned, v1) << 16);   // already bf16
       else pc[0][e / 2] = pack_bf16x2(v0, v1);
@@ -1296,6 +1417,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // weights (L2-resident) are fetched ONE step ahead into a single register set, only the activations two;
   // the A fragments of one 32-row block at a time.
   constexpr bool LEAN = (NB == 1 && NP >= 2 && TAP2 && WM == 4 && X3_LEAN);
+  VQ_STAMP(tp1);
   if constexpr (LEAN) {
     unsigned swA = 0, sxB = 0;                 // the two cursors: weights of the next A fetch, activations of the next B fetch
     int leftA = nsteps, leftB = nsteps;
@@ -1315,12 +1437,12 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         BV[e] = (TAP1) ? buf_ld(rx1, vb1, sxB + (unsigned)e * xcsb) : buf_ld(rx, vb, sxB + (unsigned)e * xcsb); \
       if (TAP1) { leftB -= 2; sxB += leftB > 0 ? xadvb : 0u; }                                \
     }
-#define LN_STAGE(BV, KX, BUF)                                                                 \
+#define LN_STAGE(BV, KX, BUF, PRE)                                                            \
     {                                                                                         \
       uint4* ad = &As[BUF][0][0][0];                                                          \
       ad[tid] = la0; ad[NT + tid] = la1;                                                      \
       if constexpr (NP == 3) ad[2 * NT + tid] = la2;                                          \
-      stage_b(std::false_type{}, BV, KX, BUF);                                            \
+      stage_b(std::integral_constant<bool, (PRE)>{}, BV, KX, BUF);                            \
     }
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
@@ -1338,28 +1460,95 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(af, bf[j], acc[i][j]);     // same product order as the loop below
       }
     };
+    // the condition step's operand images (see "the condition as a K step" behind the loop)
+    [[maybe_unused]] auto stage_cond = [&](auto bufc) {
+      constexpr int cbuf = decltype(bufc)::value;
+        const int vb = a.lerp.v0[t0];
+        // A: row a_m of the tile, k slots 0..7 = P[ch][vb .. vb + 7] (slot 7 never has a coefficient), slots 8..15 = 0
+        uint4 wa[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) wa[p] = make_uint4(0u, 0u, 0u, 0u);
+        if (a_hi == 0) {
+          const int m = m0 + a_m, Chh = a.M >> 1;
+          const int ch = ((m >> 5) & 1) * Chh + 32 * (m >> 6) + (m & 31);
+          const float* pr = a.lerp.P + (long)b * a.lerp.p_bstride + (long)ch * a.lerp.Tl;
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = pr[min(vb + j, a.lerp.Tl - 1)];
+          unsigned pc[NP][4];
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            if constexpr (NP == 3) split3(pv[e], pv[e + 1], pc[0][e / 2], pc[1][e / 2], pc[2][e / 2]);
+            else split2(pv[e], pv[e + 1], kp, pc[0][e / 2], pc[1][e / 2]);
+          }
+#pragma unroll
+          for (int p = 0; p < NP; ++p) wa[p] = make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);
+        }
+        // B: column s_n, k slots 4 (tid / 128) .. + 3
+        float cv[CPT];
+        {
+          const int t = min(t0 + s_n, a.Tout - 1);
+          const int dv = a.lerp.v0[t] - vb;
+          const float c0 = a.lerp.w0[t], c1 = a.lerp.w1[t];
+#pragma unroll
+          for (int e = 0; e < CPT; ++e) {
+            const int j = s_c + e;
+            cv[e] = j == dv ? c0 : (j == dv + 1 ? c1 : 0.f);
+          }
+        }
+        uint4* ad = &As[cbuf][0][0][0];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) ad[p * NT + tid] = wa[p];
+        stage_b(std::false_type{}, cv, kc, cbuf);
+    };
     if (nsteps > 0) {
       LN_FETCH_B(pb, false);                   // step 0
       LN_FETCH_A(false);                       // step 0
       LN_FETCH_B(qb, true);                    // step 1
-      LN_STAGE(pb, kcur, 0);
+      if constexpr (EPI == EPI_GATE && NBUF == 3) {
+        if (fold) stage_cond(std::integral_constant<int, 2>{});     // its loads travel with the first steps'; read after the loop: the loop's barriers order the writes
+      }
+      LN_STAGE(pb, kcur, 0, PRE0);
       __syncthreads();
       for (int i = 0; i < nsteps; i += 2) {    // nsteps is even: two taps per channel group
         LN_FETCH_A(true);                      // weights of step i + 1
         LN_FETCH_B(pb, false);                 // activations of step i + 2
         lmma(std::integral_constant<int, 0>{});
-        LN_STAGE(qb, k1, 1);                   // step i + 1
+        LN_STAGE(qb, k1, 1, PRE1);             // step i + 1
         __syncthreads();
         LN_FETCH_A(false);                     // weights of step i + 2
         LN_FETCH_B(qb, true);                  // activations of step i + 3
         lmma(std::integral_constant<int, 1>{});
-        LN_STAGE(pb, kcur, 0);                 // step i + 2
+        LN_STAGE(pb, kcur, 0, PRE0);           // step i + 2
         __syncthreads();
       }
     }
 #undef LN_FETCH_A
 #undef LN_FETCH_B
 #undef LN_STAGE
+    // ---- the condition as a K step.  h += upsample(P)[t] = w0[t] P[v0[t]] + w1[t] P[v0[t] + 1] (net.py:54-55 after the
+    // latent-rate projection, align-corners lerp) is itself a small matrix product: the 128 columns of a tile touch at
+    // most 7 consecutive latent positions vb .. vb + 6 (the host guarantees Tout >= 26 Tl), so
+    //     cond[m, t] = sum_{j < 8} P[ch(m), vb + j] * c_j[t],   c_j[t] = w0[t] (j = v0[t] - vb), w1[t] (j = v0[t] - vb + 1), 0 otherwise
+    // is ONE more step of this very contraction (12 MFMAs per wave, +3 %).  The epilogue used to fetch 4 values of P per
+    // output element through 128 dependent L2 loads per lane: 40 k of the gate workgroup's 130 k cycles (measured with
+    // s_memtime stamps, round 5) -- now the epilogue starts with finished pre-activations.  P carries both biases
+    // (vqvae_resblock_cproj::P_has_bd).  float32x2: P is scaled by 2^(14 - e_P), c by 2^(14 - emax + e_P) <= 2^14 (emax
+    // includes e_P, see above): same product scale as every other step.
+    VQ_STAMP(tpc);
+    VQ_PHASE_ADD(EPI, 1, tpc - tp1);
+    if constexpr (EPI == EPI_GATE) {
+      if (fold) {
+        if constexpr (NBUF == 3) lmma(std::integral_constant<int, 2>{});        // staged in the prologue (stage_cond), ordered by the loop's barriers
+        else {
+          stage_cond(std::integral_constant<int, 1>{});      // every wave has finished with image 1 (the loop's last barrier)
+          __syncthreads();
+          lmma(std::integral_constant<int, 1>{});
+        }
+      }
+    }
+    VQ_STAMP(tpd);
+    VQ_PHASE_ADD(EPI, 2, tpd - tpc);
   } else
   if (nsteps > 0) {
     float pb[CPT], qb[CPT];
@@ -1368,7 +1557,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
     else X3_FETCH(qa0, qa1, qa2, qb, qkx);
     if (SCHED && !TAP2) advance();
-    X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, RAW0);
+    X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, SEL0);
     __syncthreads();
     // top of a pair (i even): LDS buffer 0 holds step i, set Q holds (in flight) step i + 1.  (Whole pairs in the loop,
     // an odd last step behind it: with a `break` between the halves hipcc copied the accumulators between register sets
@@ -1376,13 +1565,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     for (int i = 0; i + 1 < nsteps; i += 2) {
       X3_FETCH(pa0, pa1, pa2, pb, pkx);             // step i + 2 (past the end: re-reads the last step, never used)
       mma(I0{});
-      X3_STAGE(qa0, qa1, qa2, qb, qkx, 1, RAW1);    // step i + 1 (TAP2: the second segment's set)
+      X3_STAGE(qa0, qa1, qa2, qb, qkx, 1, SEL1);    // step i + 1 (TAP2: the second segment's set)
       if (SCHED && !TAP2) advance();
       __syncthreads();
       if constexpr (TAP2) { X3_FETCH1(qa0, qa1, qa2, qb, qkx); advance2(); }
       else X3_FETCH(qa0, qa1, qa2, qb, qkx);        // step i + 3
       mma(I1{});
-      X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, RAW0);    // step i + 2
+      X3_STAGE(pa0, pa1, pa2, pb, pkx, 0, SEL0);    // step i + 2
       if (SCHED && !TAP2) advance();
       __syncthreads();
     }
@@ -1401,8 +1590,19 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac[i][j][r] = __builtin_ldexpf(ac[i][j][r], ku);
   };
+  VQ_STAMP(tp2);
   if constexpr (NP == 2) unscale(acc);
-  gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD), NP == 1>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
+  gemm_epilogue<EPI, WM, SPLITK, ((WM == 4 && !(NB == 1 && TAP2 && X3_LEAN)) || EPI == EPI_GATE_BWD), NP == 1, OUT>(a, acc, m0, t0, b, wm, wn, li, lk, ksp, tile_id, ntiles_all, kout, fold && NB == 1 && NP >= 2 && TAP2 && WM == 4 && X3_LEAN);   // two workgroups per CU: no room for the deep epilogue's 64 registers, and no need
+#ifdef VQ_PHASE_TIMING
+  if (NP == 2 && TAP2 && NB == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VQ_STAMP(tp3);
+    VQ_PHASE_ADD(EPI, 0, tp1 - tp0);
+    if (!LEAN) VQ_PHASE_ADD(EPI, 1, tp2 - tp1);
+    VQ_PHASE_ADD(EPI, 3, tp3 - tp2);
+    VQ_PHASE_ADD(EPI, 4, 1);
+  }
+#endif
   if constexpr (NB == 2) {
     if constexpr (NP == 2) unscale(acc2);
     if (t0 + BN < a.Tout) gemm_epilogue<EPI, WM, false, true, NP == 1>(a, acc2, m0, t0 + BN, b, wm, wn, li, lk, 0, tile_id, ntiles_all);
@@ -1439,6 +1639,11 @@ struct Lin128Args {
   // (nullable, any mode): atomicMax of |y| over the launch
   const unsigned* wamax; const unsigned* z_amax; float z_amax_static; unsigned* amax_out;
   int add16, y16;                          // template flags' runtime twins (host side only)
+  // float32x2, PRE-SPLIT residual stream (presplit_pair): ADD16 -- `add` holds x_l as hi | lo dwords split under the
+  // bound in its scale words add_scale; Y16 -- y = x_{l+1} is stored that way under the bound max|x_l| + *l1
+  // (add_amax: the ACTUAL max |x_l|; l1: max_r (sum_c |Wr[r][c]| + |br[r]|), wl1_kernel), published to scale_out
+  const unsigned* add_scale; const unsigned* add_amax; const float* l1; unsigned* scale_out;
+  const unsigned* floor_w; const unsigned* floor_p;      // see GemmArgs
 };
 
 // Z16 (matmul mode 1): z is stored as bf16 (same element strides): fetched as 2 x CPC bytes per row and staged as is.
@@ -1447,7 +1652,9 @@ struct Lin128Args {
 template <int NP, int NC, bool HAS_ADD, bool Z16 = false, bool ADD16 = false, bool Y16 = false>
 __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args a) {
   static_assert(!Z16 || NP == 1, "bf16-stored z: mode 1 only");
-  static_assert((!ADD16 && !Y16) || (NP == 1 && HAS_ADD), "bf16 residual stream: mode 1, with the residual add");
+  static_assert((!ADD16 && !Y16) || ((NP == 1 || NP == 2) && HAS_ADD), "bf16 (mode 1) / pre-split (mode 3) residual stream: with the residual add");
+  constexpr bool ADDPRE = ADD16 && NP == 2, YPRE = Y16 && NP == 2;     // pre-split x_l in / x_{l+1} out: 4-byte elements at the fp32 addresses
+  constexpr bool ADDB16 = ADD16 && NP == 1, YB16 = Y16 && NP == 1;     // the bf16 stream of mode 1: 2-byte elements
   constexpr int KS = 8, NCB = NC / 32;
   constexpr int CPC = NC / 16;                     // columns per staging thread: 16 column groups x 32 channel quads = 512 threads
   constexpr int STEPW = NP * 2 * NC;               // 16-byte words per K step of the B image
@@ -1467,6 +1674,17 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
   if constexpr (NP == 2) {
     const int ew = amax_expo(amax_load(a.wamax)), ez = amax_expo(a.z_amax ? amax_load(a.z_amax) : __builtin_bit_cast(unsigned, a.z_amax_static));
     kz = 14 - ez; ku = ew + ez - 28;
+  }
+  [[maybe_unused]] int kadd = 0, kout = 0;         // pre-split stream: x_l comes back by 2^kadd, x_{l+1} is stored under 2^kout
+  if constexpr (ADDPRE) kadd = amax_expo(amax_load(a.add_scale)) - 14;
+  if constexpr (YPRE) {
+    float bound = bound_margin(__builtin_bit_cast(float, amax_load(a.add_amax)) + a.l1[0]);
+    if (a.floor_p != nullptr) {
+      const int ef = amax_expo(amax_load(a.floor_p)) - amax_expo(amax_load(a.floor_w)) - 1;
+      bound = fmaxf(bound, __builtin_ldexpf(1.f, min(max(ef, -100), 100)));
+    }
+    kout = 14 - amax_expo(__builtin_bit_cast(unsigned, bound));
+    scale_publish(a.scale_out, bound);
   }
   float am = 0.f;
 
@@ -1541,12 +1759,12 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
   if constexpr (HAS_ADD) {                                                                     \
     const int tl_ = min((TILE), last);                                                         \
     const int b_ = tl_ / a.tiles_per_b, t_ = (tl_ - b_ * a.tiles_per_b) * NC;                  \
-    const rsrc_t rx_ = make_rsrc(reinterpret_cast<const char*>(a.add) + (long)b_ * a.add_bstride * (ADD16 ? 2 : 4)); \
+    const rsrc_t rx_ = make_rsrc(reinterpret_cast<const char*>(a.add) + (long)b_ * a.add_bstride * (ADDB16 ? 2 : 4)); \
     const unsigned sb_ = 4u * (unsigned)(32 * wave * T + t_);                                  \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                         \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
         const unsigned so_ = sb_ + 4u * (unsigned)(cb * 32 + ((r & 3) + 8 * (r >> 2)) * T);    \
-        if constexpr (ADD16) {                    /* one dword per ROW PAIR (see voff16): entries r = 4q, 4q + 2 only */ \
+        if constexpr (ADDB16) {                   /* one dword per ROW PAIR (see voff16): entries r = 4q, 4q + 2 only */ \
           if ((r & 1) == 0) XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff16, so_ >> 1, L128_X_AUX)); \
         } else XV[cb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx_, voff, so_, L128_X_AUX)); \
       }                                                                                        \
@@ -1570,12 +1788,31 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
     }                                                                                          \
     L128_STAGE(CUR ^ 1);                                                                       \
     {                                                                                          \
-      const rsrc_t ry = make_rsrc(reinterpret_cast<char*>(a.y) + (long)b * a.y_bstride * (Y16 ? 2 : 4)); \
+      const rsrc_t ry = make_rsrc(reinterpret_cast<char*>(a.y) + (long)b * a.y_bstride * (YB16 ? 2 : 4)); \
       const unsigned sbase = 4u * (unsigned)(32 * wave * T + t0);                              \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
         const float4 bq4 = bias_s[8 * wave + 2 * q + lk];         /* rows 32w + 8q + 4lk .. + 3 */ \
         const float bv[4] = {bq4.x, bq4.y, bq4.z, bq4.w};                                      \
         _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) {                                   \
+          if constexpr (ADDPRE || YPRE) {             /* float32x2, pre-split stream: the fp32 path's addresses, dwords re-coded */ \
+            _Pragma("unroll") for (int j = 0; j < 4; j += 2) {                                 \
+              const int r = 4 * q + j;                                                         \
+              float va = __builtin_ldexpf(acc[cb][r], ku) + bv[j], vb = __builtin_ldexpf(acc[cb][r + 1], ku) + bv[j + 1]; \
+              if constexpr (ADDPRE) { va += presplit_value(XCUR[cb][r], kadd); vb += presplit_value(XCUR[cb][r + 1], kadd); } \
+              else { va += XCUR[cb][r]; vb += XCUR[cb][r + 1]; }                               \
+              am = fmaxf(am, fmaxf(fabsf(va), fabsf(vb)));                                     \
+              const unsigned so_ = sbase + 4u * (unsigned)(cb * 32 + (j + 8 * q) * T);         \
+              if constexpr (YPRE) {                                                            \
+                unsigned da_, db_;                                                             \
+                presplit_pair(va, vb, kout, da_, db_);                                         \
+                __builtin_amdgcn_raw_buffer_store_b32((int)da_, ry, voff, so_, L128_ST_AUX);   \
+                __builtin_amdgcn_raw_buffer_store_b32((int)db_, ry, voff, so_ + 4u * (unsigned)T, L128_ST_AUX); \
+              } else {                                                                         \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, va), ry, voff, so_, L128_ST_AUX); \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vb), ry, voff, so_ + 4u * (unsigned)T, L128_ST_AUX); \
+              }                                                                                \
+            }                                                                                  \
+          } else                                                                               \
           if constexpr (ADD16 || Y16) {                                                        \
             _Pragma("unroll") for (int j = 0; j < 4; j += 2) {         /* rows R = 32w + 8q + 4lk + j and R + 1 */ \
               const int r = 4 * q + j;                                                         \
@@ -2258,8 +2495,11 @@ __global__ __launch_bounds__(128 * WM, 4) void wgrad2_kernel(const WgradArgs a) 
 template <int WM, int NC, int NP, bool X16 = false, bool G16 = false>
 __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2) ? 4 : 2) void wgrad3_kernel(const WgradArgs a) {
   static_assert(NC == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
-  static_assert((!X16 && !G16) || NP == 1, "bf16-stored operands: mode 1 only");
-  constexpr unsigned XSZ = X16 ? 2u : 4u, GSZ = G16 ? 2u : 4u;
+  static_assert((!X16 && !G16) || NP == 1 || NP == 2, "bf16-stored operands: mode 1; pre-split operands: mode 3");
+  // (matmul mode 3, NP = 2: X16 / G16 mark PRE-SPLIT operands -- fp16 hi | lo dwords at the fp32 addresses, see presplit_pair:
+  // the same loads and re-alignment as fp32, staged with v_perm_b32 instead of split2; their `amax` words are scale words)
+  constexpr bool XB16 = X16 && NP == 1, GB16 = G16 && NP == 1, XPRE = X16 && NP == 2, GPRE = G16 && NP == 2;
+  constexpr unsigned XSZ = XB16 ? 2u : 4u, GSZ = GB16 ? 2u : 4u;
   constexpr int NT2 = 128 * WM, BM2 = 64 * WM, BNC = BN * NC;
   constexpr int PA = BM2 + 4, PB = BNC + 4;               // rows of a (piece, k-half) plane; +4: the two k-halves land on different banks
   constexpr int NA = BM2 * 4 / NT2, NB = BNC * 4 / NT2;   // float4 row loads per thread: 2 and 1 or 2 (WM=4) / 2 and 2
@@ -2368,13 +2608,13 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       _Pragma("unroll") for (int i = 0; i < NB; ++i) vo_[i] = (any && b_ok[i]) ? vrow[i] + XSZ * (unsigned)tc : OOB; \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
-      if constexpr (G16) {                       /* 4 bf16 = 8 bytes, raw, in .x / .y (host: Tout % 16 == 0) */ \
+      if constexpr (GB16) {                      /* 4 bf16 = 8 bytes, raw, in .x / .y (host: Tout % 16 == 0) */ \
         const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); \
         RA[i] = make_float4(__builtin_bit_cast(float, h_.x), __builtin_bit_cast(float, h_.y), 0.f, 0.f); \
       } else RA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, VM ? voa[i] : OOB, soa, W3_LD_AUX)); /* a group beyond Tout (ragged last step) must not be fetched: it may lie beyond the tensor */ \
     }                                                                                          \
     _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                           \
-      if constexpr (X16) {                       /* 4 bf16 = 8 bytes, raw, in .x / .y (host: toff == 0, Tout % 16 == 0) */ \
+      if constexpr (XB16) {                      /* 4 bf16 = 8 bytes, raw, in .x / .y (host: toff == 0, Tout % 16 == 0) */ \
         const uint2 h_ = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rbx, vo_[i], sob, W3_LD_AUX)); \
         RB[i] = make_float4(__builtin_bit_cast(float, h_.x), __builtin_bit_cast(float, h_.y), 0.f, 0.f); \
       } else RB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rbx, vo_[i], sob, W3_LD_AUX)); \
@@ -2386,6 +2626,14 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
   };
   // staging: this thread's 4 consecutive t of a row are half (s_chunk & 1) of the 8-k group
   // (s_chunk >> 1) of that row; split into the three bf16 pieces and written as 8 bytes per piece
+  [[maybe_unused]] auto put_pre = [&](uint4* plane0, int prow, const float4 v) {      // four pre-split elements: the pieces are there, two v_perm_b32 per pair
+    uint2* d = reinterpret_cast<uint2*>(plane0) + (s_chunk & 1);
+    unsigned h0, l0, h1, l1;
+    presplit_stage(v.x, v.y, h0, l0);
+    presplit_stage(v.z, v.w, h1, l1);
+    d[2 * (0 * 2 * prow)] = make_uint2(h0, h1);
+    d[2 * (1 * 2 * prow)] = make_uint2(l0, l1);
+  };
   auto put = [&](uint4* plane0, int prow, const float4 v, [[maybe_unused]] const int kx) {     // plane0 = &X[stage][0][s_chunk >> 1][row]
     uint2* d = reinterpret_cast<uint2*>(plane0) + (s_chunk & 1);
     if constexpr (NP == 2) {
@@ -2416,7 +2664,11 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                           \
       const float4 v = VM ? RA[i] : zero4;          /* invalid rows arrived as 0; VM: ragged Tout only */ \
-      if constexpr (G16) {                                                                     \
+      if constexpr (GPRE) {                                                                    \
+        put_pre(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                        \
+        if (real_) bsum[i] += (presplit_scaled(v.x) + presplit_scaled(v.y)) + (presplit_scaled(v.z) + presplit_scaled(v.w)); \
+      } else                                                                                   \
+      if constexpr (GB16) {                                                                    \
         put_raw(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);                            \
         const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y); \
         if (real_) bsum[i] += (__builtin_bit_cast(float, u0 << 16) + __builtin_bit_cast(float, u0 & 0xffff0000u)) + \
@@ -2431,7 +2683,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       if (__builtin_amdgcn_ballot_w64(BS != 0) != 0ull) {   /* some group of this wave crosses a row end (edge steps only: wave-uniform branch): element e is loaded[e - BS] */ \
         asm volatile("");                                                         \
         float l[4] = {v.x, v.y, v.z, v.w};                                                     \
-        if constexpr (X16) {                          /* four bf16 in .x / .y: one element per register (raw bits, low half) */ \
+        if constexpr (XB16) {                         /* four bf16 in .x / .y: one element per register (raw bits, low half) */ \
           const unsigned u0 = __builtin_bit_cast(unsigned, v.x), u1 = __builtin_bit_cast(unsigned, v.y); \
           l[0] = __builtin_bit_cast(float, u0 & 0xffffu); l[1] = __builtin_bit_cast(float, u0 >> 16); \
           l[2] = __builtin_bit_cast(float, u1 & 0xffffu); l[3] = __builtin_bit_cast(float, u1 >> 16); \
@@ -2443,11 +2695,12 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
           pick = src == 1 ? l[1] : pick; pick = src == 2 ? l[2] : pick; pick = src == 3 ? l[3] : pick; \
           o[e] = (src >= 0 && src < 4 && tt >= 0 && tt < sg.Tin) ? pick : 0.f;                 \
         }                                                                                      \
-        if constexpr (X16) v = make_float4(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[0]) | (__builtin_bit_cast(unsigned, o[1]) << 16)), \
+        if constexpr (XB16) v = make_float4(__builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[0]) | (__builtin_bit_cast(unsigned, o[1]) << 16)), \
                                            __builtin_bit_cast(float, __builtin_bit_cast(unsigned, o[2]) | (__builtin_bit_cast(unsigned, o[3]) << 16)), 0.f, 0.f); \
         else v = make_float4(o[0], o[1], o[2], o[3]);                                          \
       }                                                                                        \
-      if constexpr (X16) put_raw(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);          \
+      if constexpr (XB16) put_raw(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], v);         \
+      else if constexpr (XPRE) put_pre(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v); \
       else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, v, kb);                     \
     }                                                                                          \
   }
@@ -2529,11 +2782,18 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
         const bool real_ = (REAL);                                                             \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                       \
           const float4 v = pra[i];                                                             \
+          if constexpr (GPRE) {                                                                \
+            put_pre(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v);                    \
+            if (do_bias && real_) bsum[i] += (presplit_scaled(v.x) + presplit_scaled(v.y)) + (presplit_scaled(v.z) + presplit_scaled(v.w)); \
+          } else {                                                                             \
           put(&As[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PA, v, ka);                      \
           if (do_bias && real_) bsum[i] += (v.x + v.y) + (v.z + v.w);                          \
+          }                                                                                    \
         }                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
-          put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, prb[i], kb);                 \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                       \
+          if constexpr (XPRE) put_pre(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, prb[i]); \
+          else put(&Bs[STAGE][0][s_chunk >> 1][s_row + i * RSTEP], PB, prb[i], kb);            \
+        }                                                                                      \
       } else W3_STAGE(pra, prb, pvm, pbs, pbt, STAGE, REAL)
       W3L_FETCH();
       W3L_STAGE(0, true);
@@ -2607,6 +2867,7 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       float v = bsum[i];
       v += __shfl_xor(v, 1, 4);
       v += __shfl_xor(v, 2, 4);
+      if constexpr (GPRE) v = __builtin_ldexpf(v, -ka);       // the sums ran over hi + lo = gy * 2^ka
       const int row = m0 + s_row + RSTEP * i;              // global row
       if (s_chunk == 0 && row < a.ntile_m * BM)
         a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
@@ -2680,6 +2941,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// wl1_kernel -- the weight norms behind the a-priori bounds of the pre-split tensors (see presplit_pair), three
+// workgroups per ResidualBlock, once per step beside pack_kernel:
+//   out[0] = max_r (sum_c |Wr[r][c]| + |br[r]|)   bounds |Wr z + br| for |z| <= 1                (x_{l+1}'s bound)
+//   out[1] = max_c sum_r |Wr[r][c]|,  out[2] = max_c sum_s |Ws[s][c]|   bound |Wr^T g|, |Ws^T g| per unit max |g|  (gh_l's bound)
+// Wr (Cr, Ch), Ws (Cs, Ch) row-major (Chainer (Cout, Cin, 1, 1)).  fp32 sums of <= 256 magnitudes: relative error
+// 2^-16, inside bound_margin's 2^-10.
+// ---------------------------------------------------------------------------
+struct L1Job { const float* Wr; const float* br; const float* Ws; float* out; };
+struct L1Args { L1Job job[MAXSEG]; int Cr, Cs, Ch; };
+// grid (blocks of the stack, 3): y = 0 the row norms of Wr (a wave per row: lanes across the contiguous c axis), y = 1 / 2 the
+// column norms of Wr / Ws (a thread per column, coalesced across c, the rows split over the workgroup's thread groups)
+__global__ __launch_bounds__(256) void wl1_kernel(const L1Args a) {
+  __shared__ float red[256];
+  const L1Job& j = a.job[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, Ch = a.Ch;
+  float m = 0.f;
+  if (blockIdx.y == 0) {
+    if (j.Wr)
+      for (int r = wave; r < a.Cr; r += 4) {
+        float sum = 0.f;
+        for (int c = lane; c < Ch; c += 64) sum += fabsf(j.Wr[(long)r * Ch + c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        m = fmaxf(m, sum + (j.br ? fabsf(j.br[r]) : 0.f));
+      }
+  } else {
+    const float* W = blockIdx.y == 1 ? j.Wr : j.Ws;
+    const int R = blockIdx.y == 1 ? a.Cr : a.Cs;
+    const int ngrp = 256 / Ch;                       // thread groups that share the columns (host: Ch <= 256)
+    const int c = tid % Ch, grp = tid / Ch;
+    float sum = 0.f;
+    if (W && grp < ngrp)
+      for (int r = grp; r < R; r += ngrp) sum += fabsf(W[(long)r * Ch + c]);
+    red[tid] = sum;
+    __syncthreads();
+    if (tid < Ch) { float t = 0.f; for (int g = 0; g < ngrp; ++g) t += red[g * Ch + tid]; m = t; }
+  }
+  m = wave_max(m);
+  __syncthreads();
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) j.out[blockIdx.y] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // ---------------------------------------------------------------------------
@@ -2807,6 +3113,8 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       la.T = g.Tout;
       la.wamax = s0.wamax; la.z_amax = s0.amax; la.z_amax_static = s0.amax_static; la.amax_out = g.out[0].amax_out;
       la.add16 = g.add16; la.y16 = g.y16;
+      la.add_scale = g.add_scale; la.add_amax = g.add_amax; la.l1 = g.bound_l1; la.scale_out = g.scale_out;
+      la.floor_w = g.floor_w; la.floor_p = g.floor_p;
       const int nc = (lin128 == 32 || g.z16) ? 32 : 64;
       la.tiles_per_b = g.Tout / nc; la.ntiles = la.tiles_per_b * g.B;
       static int n_cu = 0;
@@ -2821,6 +3129,12 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
         else LG_LAUNCH((lin128_stream_kernel<NPv, NCv, false>), dim3(nwg), dim3(512), la);           \
       } while (0)
       if (mode == 2) { if (nc == 32) L128_LAUNCH(3, 32); else L128_LAUNCH(3, 64); }
+      else if (mode == 3 && (g.add16 || g.y16)) {
+        VQ_REQUIRE(la.add && g.y16 && g.add_amax && g.bound_l1 && g.scale_out && (!g.add16 || g.add_scale),
+                   "conv_gemm: a pre-split residual stream needs the residual add, a pre-split output and its bound's inputs");
+        if (g.add16) LG_LAUNCH((lin128_stream_kernel<2, 32, true, false, true, true>), dim3(nwg), dim3(512), la);
+        else LG_LAUNCH((lin128_stream_kernel<2, 32, true, false, false, true>), dim3(nwg), dim3(512), la);
+      }
       else if (mode == 3) L128_LAUNCH(2, 32);
       else if (g.add16 || g.y16) {
         VQ_REQUIRE(g.z16 && la.add && g.y16, "conv_gemm: a bf16 residual stream needs matmul mode 1's bf16 z, the residual add and a bf16 output");
@@ -2837,6 +3151,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       return 0;
     }
   }
+  VQ_REQUIRE(mode == 3 || g_matmul_dtype != 3 || (!g.x16 && !g.h16 && !g.add16 && !g.y16), "conv_gemm: pre-split tensors need a float32x2 launch (every segment with its maxima)");
   if (g.add16 || g.y16)
     VQ_REQUIRE(EPI == EPI_LINEAR && mode == 1 && big && g.Tout % BN == 0 && g.M % 256 == 0 && g.out[1].y == nullptr && !g.out[0].bias &&
                !g.out[0].relu && !g.out[0].accumulate && g.ksplit == 1,
@@ -2861,6 +3176,11 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   static const int x3_lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
   const bool lean = x3_lean && X3_LEAN && tap2 && big && mode != 0 && EPI != EPI_GATE_BWD && x3_nb != 3;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
   const bool wide = mode != 0 && big && !lean && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
+  if constexpr (EPI == EPI_GATE) {       // the latent-rate condition as one more K step: the 256 x 128-tile two-tap loop, modes 2 / 3 (see the kernel)
+    static const int kstep = getenv("VQVAE_COND_KSTEP") ? atoi(getenv("VQVAE_COND_KSTEP")) : 1;
+    g.lerp.fold = (g.lerp.fold && kstep && g.lerp.P && lean && (mode == 2 || (mode == 3 && g.lerp.amax)) && g.Tout % BN == 0 &&
+                   (long)g.Tout >= 26L * g.lerp.Tl) ? 1 : 0;
+  }
   if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
 #define X3_LAUNCH(WMv, NBv, NPv, blocks, threads)                                                                    \
   do {                                                                                                                \
@@ -2877,6 +3197,24 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // not instantiated
   // activations stored as bf16 (matmul mode 1): a linear GEMM over z tensors (z16: every segment), or the caller's mask
   const int xm = (EPI == EPI_LINEAR && g.z16) ? 3 : g.x16;
+  if (mode == 3 && (xm != 0 || g.h16)) {       // float32x2 with pre-split tensors (see presplit_pair)
+    VQ_REQUIRE(g.ksplit == 1, "conv_gemm: pre-split tensors: no split-K");
+    if constexpr (EPI == EPI_GATE) {
+      VQ_REQUIRE(tap2 && lean && xm == 3 && g.seg[0].amax == g.seg[1].amax && g.seg[0].wamax == g.seg[1].wamax,
+                 "conv_gemm: gate GEMM over a pre-split x: both taps of one tensor, 256 x 128 tiles");
+      LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE, 4, 1, 2, true, 3>), dim3((unsigned)nblk), dim3(512), g);
+    } else if constexpr (EPI == EPI_LINEAR) {
+      VQ_REQUIRE(tap2 && lean && xm == 3 && g.seg[0].amax == g.seg[1].amax && g.seg[0].wamax == g.seg[1].wamax && !g.add16 && !g.y16,
+                 "conv_gemm: backward-data GEMM over a pre-split gh: both taps of one tensor, 256 x 128 tiles");
+      LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 2, true, 3>), dim3((unsigned)nblk), dim3(512), g);
+    } else {
+      VQ_REQUIRE(xm == 0 && g.h16 && g.bound_l1 && g.scale_out, "conv_gemm: gate-derivative GEMM storing a pre-split gh needs its bound's inputs (fp32 operands)");
+      if (tap2) LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, true, 0, 1>), dim3((unsigned)grid), dim3(256), g);
+      else LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, false, 0, 1>), dim3((unsigned)grid), dim3(256), g);
+    }
+    VQ_LAUNCH_CHECK();
+    return 0;
+  }
   if (xm != 0) {
     VQ_REQUIRE(mode == 1 && g.ksplit == 1, "conv_gemm: bf16-stored activations need matmul mode 1");
     for (int i = 0; i < g.nseg; ++i) VQ_REQUIRE(g.seg[i].tmul == 1 && g.seg[i].tdiv == 1, "conv_gemm: bf16-stored activations: stride-1 segments only");
@@ -3061,7 +3399,13 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
   ProfScope ps(tag, st);
   static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
   const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
-  if (fast && mode == 3 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
+  if (g_matmul_dtype == 3 && (w.x16 || w.g16)) {        // pre-split operands (see presplit_pair): their `amax` words are scale words
+    VQ_REQUIRE(fast && mode == 3 && w.M % 256 == 0, "wgrad: pre-split operands need a float32x2 launch on 256-row tiles");
+    const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
+    if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, true>), grid, dim3(512), 0, st, w);
+    else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, false, true>), grid, dim3(512), 0, st, w);
+    else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, false>), grid, dim3(512), 0, st, w);
+  } else if (fast && mode == 3 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 2, 2>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
   } else if (fast && mode == 3 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
@@ -3110,6 +3454,14 @@ extern "C" int vqvae_set_matmul_dtype(int dtype) {
   return 0;
 }
 extern "C" int vqvae_get_matmul_dtype(void) { return vq::g_matmul_dtype; }
+#ifdef VQ_PHASE_TIMING
+extern "C" int vqvae_debug_phases(unsigned long long* out, int reset) {       // dev aid, see g_phase
+  VQ_CHECK_HIP(hipDeviceSynchronize());
+  VQ_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(vq::g_phase), sizeof(unsigned long long) * 24));
+  if (reset) { unsigned long long z[24] = {0}; VQ_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vq::g_phase), z, sizeof(z))); }
+  return 0;
+}
+#endif
 extern "C" int vqvae_set_wgrad_impl(int impl) {
   VQ_REQUIRE(impl == 0 || impl == 1, "set_wgrad_impl: 0 (auto) or 1 (generic kernel)");
   vq::g_wgrad_impl = impl;
@@ -3418,7 +3770,8 @@ struct RbLayout {
   WgradPlan p_h, p_r, p_s;
 };
 
-enum { HDR_D = 0, HDR_O = AMAX_SLOTS, HDR_GZ_R = 2 * AMAX_SLOTS, HDR_GZ_S = 3 * AMAX_SLOTS, HDR_BD = 4 * AMAX_SLOTS, HDR_N = 5 };   // word offsets into RbLayout::hdr
+enum { HDR_D = 0, HDR_O = AMAX_SLOTS, HDR_GZ_R = 2 * AMAX_SLOTS, HDR_GZ_S = 3 * AMAX_SLOTS, HDR_BD = 4 * AMAX_SLOTS, HDR_N = 5,   // word offsets into RbLayout::hdr
+       HDR_L1 = HDR_N * AMAX_SLOTS, HDR_L1_WORDS = 16 };       // wl1_kernel's three floats (pre-split bounds), behind the maxima
 
 static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   RbLayout L;
@@ -3433,7 +3786,7 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
   L.pk_gz_s = take((size_t)slab_rows(d->Cs) * pad128(Ch));             // bwd gz from g_skip
   L.pk_bd = take((size_t)d->K * slab_rows(d->Cd) * pad128(d->Cr));     // bwd-data dilated conv
   L.pk_bc = take((size_t)slab_rows(d->Cd) * pad128(d->Cc));            // bwd-data cond proj
-  L.hdr = take(HDR_N * AMAX_SLOTS);                                    // float32x2: max |W| of each format-3 slab (HDR_* x AMAX_SLOTS words)
+  L.hdr = take(HDR_N * AMAX_SLOTS + HDR_L1_WORDS);                     // float32x2: max |W| of each format-3 slab (HDR_* x AMAX_SLOTS words), then wl1_kernel's norms
   int cins[MAXSEG];
   for (int j = 0; j < d->K; ++j) cins[j] = d->Cr;
   cins[d->K] = d->Cc;
@@ -3491,10 +3844,31 @@ static int bf16_storage_supported(const vqvae_resblock_desc* d) {
   return m;
 }
 
+// matmul mode 3 (float32x2): the tensors of the packed chain that can be kept PRE-SPLIT (see presplit_pair) -- the
+// configs-sized blocks whose two-tap GEMMs run the 256 x 128-tile loop and whose residual 1x1 runs the streaming kernel.
+// VQVAE_PRESPLIT=0 makes the library report none.
+static int g_presplit = -1;          // < 0: not set (VQVAE_PRESPLIT, else 3); bit 0: gh, bit 1: the residual stream
+static int f16x2_storage_supported(const vqvae_resblock_desc* d) {
+  if (g_presplit < 0) g_presplit = getenv("VQVAE_PRESPLIT") ? atoi(getenv("VQVAE_PRESPLIT")) : 3;
+  const int on = g_presplit;
+  static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
+  static const int lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
+  static const int tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
+  static const int nb3 = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
+  static const int w3nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
+  if (!on || g_matmul_dtype != 3 || g_wgrad_impl == 1 || !lean || !tap2 || nb3 == 3 || w3nc != 1) return 0;
+  if (!(d->K == 2 && d->Cd == 256 && d->Cr == 256 && d->T % 128 == 0 && d->dil < d->T &&
+        (long)d->B * d->Cd * d->T * 4 < (1L << 31))) return 0;
+  int m = 0;
+  if (on & 1) m |= VQVAE_STORE_GH_F16X2;
+  if ((on & 2) && lin128) m |= VQVAE_STORE_X_F16X2 | VQVAE_STORE_RES_F16X2;
+  return m;
+}
+
 static int check_rb(const vqvae_resblock_desc* d) {
   VQ_REQUIRE(d, "resblock: null desc");
-  VQ_REQUIRE(d->storage == 0 || (d->storage & ~bf16_storage_supported(d)) == 0,
-             "resblock: desc.storage = %d asks for bf16 tensors this shape / matmul mode does not keep (supported: %d)", d->storage, bf16_storage_supported(d));
+  VQ_REQUIRE(d->storage == 0 || (d->storage & ~(bf16_storage_supported(d) | f16x2_storage_supported(d))) == 0,
+             "resblock: desc.storage = %d asks for bf16 / pre-split tensors this shape / matmul mode does not keep (supported: %d)", d->storage, bf16_storage_supported(d) | f16x2_storage_supported(d));
   VQ_REQUIRE(d->B > 0 && d->T > 0 && d->Cr > 0 && d->Cd > 0 && d->Cs > 0 && d->Cc > 0, "resblock: bad dims");
   VQ_REQUIRE(d->Cd % 64 == 0, "resblock: dilated_channels/2 must be a multiple of 32 (got Cd=%d)", d->Cd);
   VQ_REQUIRE(d->K >= 1 && d->K <= MAXTAPS, "resblock: filter_size %d unsupported", d->K);
@@ -3529,6 +3903,15 @@ extern "C" int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d) {
   if (!d || d->Cd <= 0) return 0;
   return bf16_storage_supported(d);
 }
+extern "C" int vqvae_set_presplit(int mask) {
+  VQ_REQUIRE(mask >= 0 && mask <= 3, "set_presplit: bit 0 = gh, bit 1 = the residual stream");
+  g_presplit = mask;
+  return 0;
+}
+extern "C" int vqvae_resblock_f16x2_storage(const vqvae_resblock_desc* d) {
+  if (!d || d->Cd <= 0) return 0;
+  return f16x2_storage_supported(d);
+}
 
 extern "C" size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d) {
   if (!d || d->Cd <= 0) return 0;
@@ -3559,6 +3942,12 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
   const int Mo = (res ? d->Cr : 0) + (skip ? d->Cs : 0);
   const int ldo = pad128(Mo > 0 ? Mo : 1);
   if (packed) VQ_REQUIRE(cproj && !skip, "resblock_fwd_packed: the packed form serves ResidualNet's chain (latent-rate condition, no per-block skip)");
+  const bool xpre = (d->storage & VQVAE_STORE_X_F16X2) != 0, rpre = res && (d->storage & VQVAE_STORE_RES_F16X2);
+  if (d->storage & (VQVAE_STORE_X_F16X2 | VQVAE_STORE_RES_F16X2)) {
+    VQ_REQUIRE(f16, "resblock_fwd: a pre-split residual stream (desc.storage) is kept by the packed float32x2 chain only");
+    VQ_REQUIRE(!xpre || res == nullptr || rpre, "resblock_fwd: a pre-split x with an fp32 residual output is not built");
+    VQ_REQUIRE(!rpre || (am->x_max && am->res_scale), "resblock_fwd: a pre-split residual output needs amax->x_max and amax->res_scale");
+  }
   if (d->storage & (VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16)) {
     VQ_REQUIRE(packed, "resblock_fwd: a bf16 residual stream (desc.storage) is kept by the packed chain form only");
     VQ_REQUIRE(!(d->storage & VQVAE_STORE_X_BF16) || res == nullptr || (d->storage & VQVAE_STORE_RES_BF16), "resblock_fwd: a bf16 x with an fp32 residual output is not built");
@@ -3596,19 +3985,21 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     if (cproj) {      // condition projection (incl. its bias) arrives pre-computed at latent rate
       g.lerp.P = cproj->P; g.lerp.p_bstride = cproj->P_bstride; g.lerp.Tl = cproj->Tl;
       g.lerp.v0 = cproj->v0; g.lerp.w0 = cproj->w0; g.lerp.w1 = cproj->w1;
+      g.lerp.fold = 1; g.lerp.amax = cproj->P_amax;       // a request: launch_gemm decides (kernel form, shape)
     } else {
       Seg& sc = g.seg[d->K];
       sc.x = cond; sc.x_bstride = (long)d->Cc * T; sc.x_cstride = T; sc.cin = d->Cc; sc.Tin = T;
       sc.tmul = 1; sc.toff = 0; sc.tdiv = 1; sc.w = w + L.pk_c; sc.ldw = ldd;
     }
     g.M = d->Cd; g.Tout = T; g.B = d->B;
-    g.out[0].y = gates; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].bias = p->bd;
+    g.out[0].y = gates; g.out[0].y_bstride = (long)d->Cd * T; g.out[0].bias = (cproj && cproj->P_has_bd) ? nullptr : p->bd;
     g.out[0].bias2 = cproj ? nullptr : p->bc;
     g.out[0].rows = d->Cd;
     g.out[1].y = z; g.out[1].y_bstride = (long)Ch * T;
     g.z16 = z_bf16(d) ? 1 : 0;
     g.g16 = gates_bf16(d) ? 1 : 0;
     g.x16 = (d->storage & VQVAE_STORE_X_BF16) ? 3 : 0;
+    if (xpre) g.x16 = 3;                         // both taps read the pre-split x_l; amax->x holds its scale words
     if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
   }
   // K2: [res; skip] = [Wr; Ws] z (+ x) (+= skip)
@@ -3634,6 +4025,15 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.z16 = z_bf16(d) ? 1 : 0;
     g.add16 = (res && (d->storage & VQVAE_STORE_X_BF16)) ? 1 : 0;
     g.y16 = (res && (d->storage & VQVAE_STORE_RES_BF16)) ? 1 : 0;
+    if (rpre) {
+      g.add16 = xpre ? 1 : 0; g.y16 = 1;
+      g.add_scale = am->x; g.add_amax = am->x_max; g.scale_out = am->res_scale;
+      g.bound_l1 = w + L.hdr + HDR_L1;
+      if (cproj && cproj->P_amax) {          // the next block's gate GEMM adds its condition as a K step: leave it room
+        g.floor_p = cproj->P_amax;
+        g.floor_w = reinterpret_cast<const unsigned*>(w + (L.slabs - L.pk_d) + L.hdr) + HDR_D;      // the next block's slice of the packed slabs
+      }
+    }
     if (g.add16 || g.y16) VQ_REQUIRE(!skip, "resblock_fwd: a bf16 residual stream (desc.storage) is served by the chain form only (no per-block skip output)");
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st)) return e;
   }
@@ -3697,7 +4097,23 @@ extern "C" int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
     add(pack_bwd_job(w + L.pk_gz_s, p.Ws, d->Cs, Ch, 1, ldz), w, HDR_GZ_S);
     add(pack_bwd_job(w + L.pk_bd, p.Wd, d->Cd, d->Cr, d->K, ldr), w, HDR_BD);
   }
-  return flush();
+  if (int e = flush()) return e;
+  if (f16 && f16x2_storage_supported(d) && Ch <= 256) {       // the weight norms behind the pre-split tensors' bounds
+    for (int l0 = 0; l0 < nblocks; l0 += MAXSEG) {
+      L1Args la; memset(&la, 0, sizeof(la));
+      la.Cr = d->Cr; la.Cs = d->Cs; la.Ch = Ch;
+      const int n = nblocks - l0 < MAXSEG ? nblocks - l0 : MAXSEG;
+      for (int i = 0; i < n; ++i) {
+        const vqvae_resblock_params& p = params[l0 + i];
+        float* w = (float*)packed + (size_t)(l0 + i) * per - L.pk_d;
+        la.job[i].Wr = has_res[l0 + i] ? p.Wr : nullptr; la.job[i].br = has_res[l0 + i] ? p.br : nullptr;
+        la.job[i].Ws = p.Ws; la.job[i].out = w + L.hdr + HDR_L1;
+      }
+      hipLaunchKernelGGL(wl1_kernel, dim3(n, 3), dim3(256), 0, st, la);
+      VQ_LAUNCH_CHECK();
+    }
+  }
+  return 0;
 }
 
 static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_params* p,
@@ -3725,6 +4141,8 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
   const bool gres16 = g_res && (d->storage & VQVAE_STORE_GRES_BF16), gx16 = gx && (d->storage & VQVAE_STORE_GX_BF16);
   if (h16 || (d->storage & (VQVAE_STORE_GRES_BF16 | VQVAE_STORE_GX_BF16)))
     VQ_REQUIRE(packed, "resblock_bwd: bf16-stored gh / gradient stream (desc.storage) are kept by the packed chain form only");
+  const bool hpre = (d->storage & VQVAE_STORE_GH_F16X2) != 0;
+  if (hpre) VQ_REQUIRE(f16 && am->gh_scale, "resblock_bwd: a pre-split gh (desc.storage) is kept by the packed float32x2 chain only and needs amax->gh_scale");
 
   if (!packed) {
   PackArgs pa; pa.njob = 0;
@@ -3756,8 +4174,12 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].add = gates; g.out[0].add_bstride = (long)d->Cd * T;
     g.out[0].amax_out = am ? am->gh : nullptr;
     g.g16 = gates_bf16(d) ? 1 : 0;
-    g.h16 = h16 ? 1 : 0;
+    g.h16 = (h16 || hpre) ? 1 : 0;
     g.x16 = gres16 ? 1 : 0;                       // segment 0 = g_res
+    if (hpre) {                                   // bound: out[1] max|g_res| + out[2] max|g_skip| (wl1_kernel), segment order [g_res,] g_skip
+      g.bound_l1 = wpk + L.hdr + HDR_L1 + (g_res ? 1 : 2);
+      g.scale_out = am->gh_scale;
+    }
     if (int e = launch_gemm<EPI_GATE_BWD>(g, VQVAE_PROF_RESBLOCK_BWD_GZ, st)) return e;
   }
   // K4: gx = g_res + sum_j Wd_j^T gh[t + (K-1-j) dil]
@@ -3770,14 +4192,14 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
       sg.x = gh; sg.x_bstride = (long)d->Cd * T; sg.x_cstride = T; sg.cin = d->Cd; sg.Tin = T;
       sg.tmul = 1; sg.toff = (d->K - 1 - j) * d->dil; sg.tdiv = 1;
       sg.w = wpk + L.pk_bd + (size_t)j * rp * ldr; sg.ldw = ldr;
-      if (f16) { sg.amax = am->gh; sg.wamax = reinterpret_cast<const unsigned*>(wpk + L.hdr) + HDR_BD; }
+      if (f16) { sg.amax = hpre ? am->gh_scale : am->gh; sg.wamax = reinterpret_cast<const unsigned*>(wpk + L.hdr) + HDR_BD; }
     }
     g.f16x2 = f16 ? 1 : 0;
     g.M = d->Cr; g.Tout = T; g.B = d->B;
     g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cr * T; g.out[0].rows = d->Cr;
     g.out[0].add = g_res; g.out[0].add_bstride = (long)d->Cr * T;
     g.out[0].amax_out = am ? am->gx : nullptr;
-    g.x16 = h16 ? 3 : 0;
+    g.x16 = (h16 || hpre) ? 3 : 0;
     g.add16 = gres16 ? 1 : 0; g.y16 = gx16 ? 1 : 0;
     if (int e = launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_BWD_GX, st)) return e;
   }
@@ -4112,8 +4534,10 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
   wa.nseg = n;
   wa.accumulate = accumulate;
-  wa.g16 = (d->storage & VQVAE_STORE_GH_BF16) ? 1 : 0;
-  wa.x16 = (d->storage & VQVAE_STORE_X_BF16) ? 1 : 0;        // every block of this launch (the caller groups them accordingly)
+  wa.g16 = (d->storage & (VQVAE_STORE_GH_BF16 | VQVAE_STORE_GH_F16X2)) ? 1 : 0;
+  wa.x16 = (d->storage & (VQVAE_STORE_X_BF16 | VQVAE_STORE_X_F16X2)) ? 1 : 0;        // every block of this launch (the caller groups them accordingly)
+  if (d->storage & (VQVAE_STORE_GH_F16X2 | VQVAE_STORE_X_F16X2))
+    VQ_REQUIRE(wa.f16x2, "resstack_dil_wgrad: pre-split operands (desc.storage) need the float32x2 launch: every block's scale words");
   return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
 }
 

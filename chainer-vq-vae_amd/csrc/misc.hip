@@ -210,12 +210,15 @@ __global__ __launch_bounds__(UPB_NT, 8) void upsample_bwd_rows_kernel(
 // IN16: gy is stored as bf16 (the bf16 mode's gh, vqvae_upsample_linear_bwd_bf16): 8-byte loads of 4 t, widened in
 // registers; gy_bstride counts elements either way.
 constexpr int UPS_NT = 1024, UPS_PITCH = 2048 + 128;
-template <bool IN16>
+// IN16 = 2: gy is stored PRE-SPLIT (matmul mode 3, VQVAE_STORE_GH_F16X2: one dword per element = fp16 hi | fp16 lo << 16 of
+// gy * 2^k, k from the bound in its `scale` words): hi + lo is exact in fp32 and the pull-back is linear, so the rows are
+// summed as they are and the weights carry the 2^-k.
+template <int IN16>
 __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
     const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
     const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
     const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
-    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride) {
+    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride, const uint32_t* __restrict__ scale) {
   __shared__ float S[2][4][UPS_PITCH];       // [row parity][w0 lo, w0 hi, w1 lo, w1 hi][q + (q >> 4)]
   const int tid = threadIdx.x, n4 = Tout >> 2, rows = B * C;
   // phase-1 constants: weights and the lo / hi split point of this thread's column groups q = tid, tid + 1024
@@ -227,6 +230,14 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
     const bool ok = q < n4;
     wa[k] = ok ? reinterpret_cast<const float4*>(w0)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     wb[k] = ok ? reinterpret_cast<const float4*>(w1)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (IN16 == 2) {                 // the stored values are gy * 2^(14 - e): an exact power of two, folded into the weights
+      unsigned mx = 0u;
+      for (int i = 0; i < 16; ++i) mx = max(mx, scale[i]);
+      const int e = (int)((mx >> 23) & 0xffu);
+      const int kinv = ((e < 1 ? 1 : e) - 127) - 14;
+      wa[k] = make_float4(ldexpf(wa[k].x, kinv), ldexpf(wa[k].y, kinv), ldexpf(wa[k].z, kinv), ldexpf(wa[k].w, kinv));
+      wb[k] = make_float4(ldexpf(wb[k].x, kinv), ldexpf(wb[k].y, kinv), ldexpf(wb[k].z, kinv), ldexpf(wb[k].w, kinv));
+    }
     // source index of element 4q: the v whose w0 range [lo0[v], hi0[v]) holds it (the ranges tile [0, Tout)
     // in order); floor(t (Tin-1) / (Tout-1)) is right to within one -- three independent table reads
     // settle it (a binary search here was seven dependent L2 round trips before the first row)
@@ -251,7 +262,13 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
     const unsigned short* h_ = reinterpret_cast<const unsigned short*>(gy) + e_;               \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
       const int q = k * UPS_NT + tid;                                                          \
-      if constexpr (IN16) {                                                                    \
+      if constexpr (IN16 == 2) {                                                               \
+        typedef _Float16 h2_t_ __attribute__((ext_vector_type(2)));                            \
+        const uint4 u_ = q < n4 ? reinterpret_cast<const uint4*>(g_)[q] : make_uint4(0u, 0u, 0u, 0u); \
+        const h2_t_ a_ = __builtin_bit_cast(h2_t_, u_.x), b_ = __builtin_bit_cast(h2_t_, u_.y), c_ = __builtin_bit_cast(h2_t_, u_.z), d_ = __builtin_bit_cast(h2_t_, u_.w); \
+        V[k] = make_float4((float)a_[0] + (float)a_[1], (float)b_[0] + (float)b_[1], (float)c_[0] + (float)c_[1], (float)d_[0] + (float)d_[1]); \
+      } else                                                                                   \
+      if constexpr (IN16 == 1) {                                                               \
         const uint2 u_ = q < n4 ? reinterpret_cast<const uint2*>(h_)[q] : make_uint2(0u, 0u);  \
         V[k] = make_float4(__builtin_bit_cast(float, u_.x << 16), __builtin_bit_cast(float, u_.x & 0xffff0000u), \
                            __builtin_bit_cast(float, u_.y << 16), __builtin_bit_cast(float, u_.y & 0xffff0000u)); \
@@ -1005,7 +1022,7 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
       ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0) {
     int nb = B * C;
     if (nb > 512) nb = 512;                      // persistent: 2 workgroups per CU
-    hipLaunchKernelGGL(upsample_bwd_seg_kernel<false>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel<0>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr);
     VQ_LAUNCH_CHECK();
     return 0;
   }
@@ -1037,7 +1054,24 @@ int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C
              "upsample_bwd_bf16: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
   int nb = B * C;
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(upsample_bwd_seg_kernel<true>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride);
+  hipLaunchKernelGGL(upsample_bwd_seg_kernel<1>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// gy stored pre-split (matmul mode 3's gh: vqvae_resblock_desc::storage & VQVAE_STORE_GH_F16X2; `scale`: its scale
+// words); the decoder's pull-back shape only
+int vqvae_upsample_linear_bwd_f16x2(const void* gy, long gy_bstride, int B, int C, int Tin, int Tout,
+                                    const float* w0, const float* w1, const int32_t* lo0,
+                                    const int32_t* hi0, const int32_t* lo1, const int32_t* hi1, float* gx,
+                                    long gx_bstride, const uint32_t* scale, vqvae_stream_t s) {
+  VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx && scale, "upsample_bwd_f16x2: null pointer");
+  VQ_REQUIRE(Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 &&
+             ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0,
+             "upsample_bwd_f16x2: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
+  int nb = B * C;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(upsample_bwd_seg_kernel<2>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, scale);
   VQ_LAUNCH_CHECK();
   return 0;
 }

@@ -34,12 +34,12 @@ class ResblockParams(C.Structure):
 
 
 class ResblockCproj(C.Structure):
-    _fields_ = [('P', P), ('P_bstride', c_long), ('Tl', c_int), ('v0', P), ('w0', P), ('w1', P)]
+    _fields_ = [('P', P), ('P_bstride', c_long), ('Tl', c_int), ('v0', P), ('w0', P), ('w1', P), ('P_has_bd', c_int), ('P_amax', P)]
 
 
 class ResblockAmax(C.Structure):
     """vqvae_resblock_amax: device uint32 slots (float bit patterns of absolute maxima), matmul mode 3."""
-    _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx')]
+    _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx', 'x_max', 'res_scale', 'gh_scale')]
 
 
 class Conv1dAmax(C.Structure):
@@ -151,6 +151,10 @@ PROTOTYPES = {
     'vqvae_upsample_linear_bwd_bf16': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                P, c_long, P]),
     'vqvae_resblock_bf16_storage': (c_int, [C.POINTER(ResblockDesc)]),
+    'vqvae_resblock_f16x2_storage': (c_int, [C.POINTER(ResblockDesc)]),
+    'vqvae_set_presplit': (c_int, [c_int]),
+    'vqvae_upsample_linear_bwd_f16x2': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
+                                                P, c_long, P, P]),
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
     'vqvae_onehot': (c_int, [P, c_long, c_int, c_int, c_int, P, P]),
     'vqvae_embed_gather_fwd': (c_int, [P, c_long, c_int, c_int, P, P, c_int, c_int, c_int, P, P]),
@@ -196,6 +200,7 @@ MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gem
 STORE_X_BF16, STORE_RES_BF16 = 2, 4
 STORE_GX_BF16, STORE_GRES_BF16 = 8, 16
 STORE_GH_BF16 = 1                 # vqvae_resblock_desc.storage bits (VQVAE_STORE_*)
+STORE_GH_F16X2, STORE_X_F16X2, STORE_RES_F16X2 = 32, 64, 128      # matmul mode 3: kept pre-split (fp16 hi | lo dwords)
 AMAX_SLOTS = 16                   # uint32 words per absolute maximum (vqvae_absmax, vqvae_resblock_amax)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
     EW_MUL_SCALAR_DEV = range(10)

@@ -166,6 +166,13 @@ def set_f32x2_min_gflop(gflop):
     _lib.call('vqvae_set_f32x2_min_gflop', float(gflop))
 
 
+def set_presplit(mask):
+    """'float32x2' only: which tensors of ResidualNet's chain are kept PRE-SPLIT in HBM (fp16 hi | lo dwords written once
+    by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; default 3
+    ($VQVAE_PRESPLIT), 0 = every tensor fp32 and every reader splits for itself (round 4's form, the A/B alternate)."""
+    _lib.call('vqvae_set_presplit', int(mask))
+
+
 def synchronize():
     _lib.call('vqvae_stream_synchronize', stream())
     if _state['side'] is not None:

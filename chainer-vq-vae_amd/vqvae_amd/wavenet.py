@@ -133,6 +133,7 @@ class ResidualStackFunction(FunctionNode):
             Cd = inputs[2].shape[0]
             self.Wc_all = DeviceArray((nb * Cd, Cc, 1, 1), np.float32)
             bc_all = DeviceArray((nb * Cd,), np.float32)
+            bd_all = DeviceArray((nb * Cd,), np.float32)
             for lo, hi in _groups(nb):
                 _lib.call('vqvae_concat', self.Wc_all.ptr + lo * Cd * Cc * 4,
                           _lib.ptr_array([inputs[2 + 8 * i + 2] for i in range(lo, hi)]),
@@ -140,11 +141,19 @@ class ResidualStackFunction(FunctionNode):
                 _lib.call('vqvae_concat', bc_all.ptr + lo * Cd * 4,
                           _lib.ptr_array([inputs[2 + 8 * i + 3] for i in range(lo, hi)]),
                           hi - lo, Cd, _S())
+                _lib.call('vqvae_concat', bd_all.ptr + lo * Cd * 4,
+                          _lib.ptr_array([inputs[2 + 8 * i + 1] for i in range(lo, hi)]),
+                          hi - lo, Cd, _S())
+            # the dilated convs' biases ride in the projection's bias (the lerp weights of a column sum to one): the gate
+            # kernels then add no bias, and their condition term is one more step of the contraction
+            # (vqvae_resblock_cproj::P_has_bd / P_amax)
+            _lib.call('vqvae_elementwise', 0, nb * Cd, bc_all.ptr, bd_all.ptr, bc_all.ptr, 1.0, 1.0, _S())
             self.pdesc = _lib.Conv1dDesc(B, Cc, Tl, nb * Cd, Tl, 1, 1, 0, 1, 0)
             P_all = DeviceArray((B, nb * Cd, Tl), np.float32)
+            P_amax = backend.new_amax()
             ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
-            _lib.call('vqvae_conv1d_fwd', C.byref(self.pdesc), lat.ptr, self.Wc_all.ptr, bc_all.ptr,
-                      P_all.ptr, ws.ptr, ws.nbytes, _S())
+            _lib.call('vqvae_conv1d_fwd_amax', C.byref(self.pdesc), lat.ptr, self.Wc_all.ptr, bc_all.ptr,
+                      P_all.ptr, ws.ptr, ws.nbytes, C.byref(_lib.Conv1dAmax(None, None, P_amax.ptr)), _S())
             tb = F.resize_tables(Tl, x.shape[2])
         self.packed = None
         self.amax = None
@@ -152,8 +161,9 @@ class ResidualStackFunction(FunctionNode):
             # matmul mode 3 (float32x2): the absolute maximum of every tensor of the chain travels with it as a
             # group of _lib.AMAX_SLOTS device uint32 (float bits) -- groups x_l | gh_l | g_res_l | g_skip; the kernels'
             # epilogues raise the words of what they store (atomicMax), only the tensors that arrive from outside
-            # are scanned
-            self.amax = backend.zeros(((3 * nb + 1) * _lib.AMAX_SLOTS,), np.uint32)
+            # are scanned.  Behind them the SCALE words of the tensors kept pre-split (vqvae_resblock_desc.storage &
+            # VQVAE_STORE_*_F16X2): x_l | gh_l again -- the bound each was split under, written by its producer
+            self.amax = backend.zeros(((5 * nb + 1) * _lib.AMAX_SLOTS,), np.uint32)
             if getattr(x, 'amax', None) is not None:     # it travelled with the tensor
                 _lib.call('vqvae_memcpy_d2d', self.amax.ptr, x.amax.ptr, 4 * _lib.AMAX_SLOTS, _S())
             else:
@@ -181,18 +191,27 @@ class ResidualStackFunction(FunctionNode):
                 sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(d))
                 if sup & _lib.STORE_RES_BF16 and sup & _lib.STORE_X_BF16:
                     d.storage = (0 if last else _lib.STORE_RES_BF16) | (_lib.STORE_X_BF16 if i > 0 else 0)
+                # matmul mode 'float32x2': the same stream kept PRE-SPLIT (fp16 hi | lo dwords under an a-priori bound:
+                # its three readers stage it with two v_perm_b32 per element pair instead of splitting it again)
+                if self.amax is not None:
+                    sup = _lib.load().vqvae_resblock_f16x2_storage(C.byref(d))
+                    if sup & _lib.STORE_RES_F16X2 and sup & _lib.STORE_X_F16X2:
+                        d.storage = (0 if last else _lib.STORE_RES_F16X2) | (_lib.STORE_X_F16X2 if i > 0 else 0)
             res = None if last else DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
             gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
             z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
             ws = _rb_workspace(d)
             if self.lat is not None:
                 cp = _lib.ResblockCproj(P_all.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, Tl,
-                                        tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr)
+                                        tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr, 1, P_amax.ptr)
                 if self.packed is not None:
                     am = None
                     if self.amax is not None:
-                        am = C.byref(_lib.ResblockAmax(self._slot(i), None if last else self._slot(i + 1),
-                                                       None, None, None, None))
+                        xpre = bool(d.storage & _lib.STORE_X_F16X2)
+                        am = C.byref(_lib.ResblockAmax(
+                            self._slot(3 * nb + 1 + i) if xpre else self._slot(i), None if last else self._slot(i + 1),
+                            None, None, None, None,
+                            self._slot(i), None if last else self._slot(3 * nb + 1 + i + 1), None))
                     _lib.call('vqvae_resblock_fwd_packed', C.byref(d), C.byref(prm), h.ptr, C.byref(cp),
                               _p(res), gates.ptr, z.ptr, ws.ptr, ws.nbytes,
                               self.packed.ptr + i * self.packed_stride, am, _S())
@@ -221,7 +240,8 @@ class ResidualStackFunction(FunctionNode):
         return skip,
 
     def _slot(self, i):
-        """Device address of group i of self.amax (x_l: l, gh_l: nb + l, g_res_l: 2 nb + l, g_skip: 3 nb)."""
+        """Device address of group i of self.amax (x_l: l, gh_l: nb + l, g_res_l: 2 nb + l, g_skip: 3 nb; scale words of
+        a pre-split x_l: 3 nb + 1 + l, of a pre-split gh_l: 4 nb + 1 + l)."""
         return self.amax.ptr + 4 * _lib.AMAX_SLOTS * i
 
     def backward(self, indexes, gys):
@@ -242,7 +262,10 @@ class ResidualStackFunction(FunctionNode):
         store = 0
         if self.packed is not None and lat is not None:
             store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0])) & _lib.STORE_GH_BF16
-        stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16       # the forward's choice for the residual stream stays
+        if f16 and self.packed is not None and lat is not None:    # matmul mode 'float32x2': gh kept pre-split
+            store = _lib.load().vqvae_resblock_f16x2_storage(C.byref(self.descs[0])) & _lib.STORE_GH_F16X2
+        hpre = bool(store & _lib.STORE_GH_F16X2)
+        stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16 | _lib.STORE_X_F16X2 | _lib.STORE_RES_F16X2       # the forward's choice for the residual stream stays
         gstream = 0                                              # ... and its counterpart, the gradient stream g_res_l = gx_{l+1}
         if self.packed is not None and lat is not None:
             sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))
@@ -291,15 +314,17 @@ class ResidualStackFunction(FunctionNode):
             if overlap:
                 backend.wait_event(side, backend.Event().record(_S()))    # their gh are complete
             # one launch per kind of x: the blocks whose input is the bf16 residual stream, and the rest (block 0)
-            for x16 in (_lib.STORE_X_BF16, 0):
-                sel = [i for i in blocks if (self.descs[i].storage & _lib.STORE_X_BF16) == x16]
+            for x16 in (_lib.STORE_X_BF16, _lib.STORE_X_F16X2, 0):
+                sel = [i for i in blocks if (self.descs[i].storage & (_lib.STORE_X_BF16 | _lib.STORE_X_F16X2)) == x16]
                 if not sel:
                     continue
                 dg = _lib.ResblockDesc.from_buffer_copy(d0)
                 dg.storage = store | x16
                 dils = (C.c_int * len(sel))(*[self.dilations[i] for i in sel])
-                xam = (C.c_void_p * len(sel))(*[self._slot(i) for i in sel]) if f16 else None
-                gam = (C.c_void_p * len(sel))(*[self._slot(nb + i) for i in sel]) if f16 else None
+                # (a pre-split operand is read under the bound it was split under: its scale words)
+                xam = (C.c_void_p * len(sel))(*[self._slot(3 * nb + 1 + i if x16 == _lib.STORE_X_F16X2 else i)
+                                                for i in sel]) if f16 else None
+                gam = (C.c_void_p * len(sel))(*[self._slot(4 * nb + 1 + i if hpre else nb + i) for i in sel]) if f16 else None
                 _lib.call('vqvae_resstack_dil_wgrad', C.byref(dg), len(sel), dils,
                           _lib.ptr_array([self.saved[i][0] for i in sel]),
                           _lib.ptr_array([ghs[i] for i in sel]),
@@ -362,7 +387,8 @@ class ResidualStackFunction(FunctionNode):
                     if f16:      # in: g_res_i, g_skip; out: gh_i and gx = g_res_{i-1}
                         am = C.byref(_lib.ResblockAmax(
                             None, None, None if g_res is None else self._slot(2 * nb + i), self._slot(3 * nb),
-                            self._slot(nb + i), self._slot(2 * nb + i - 1) if (gx is not None and i > 0) else None))
+                            self._slot(nb + i), self._slot(2 * nb + i - 1) if (gx is not None and i > 0) else None,
+                            None, None, self._slot(4 * nb + 1 + i) if hpre else None))
                     _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), h.ptr, gates.ptr,
                               z.ptr, _p(g_res), g_skip.ptr, _p(gx), gh.ptr, ws.ptr, ws.nbytes,
                               self.packed.ptr + i * self.packed_stride, am, _S())
@@ -378,10 +404,15 @@ class ResidualStackFunction(FunctionNode):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
-                _lib.call('vqvae_upsample_linear_bwd_bf16' if store & _lib.STORE_GH_BF16 else 'vqvae_upsample_linear_bwd',
-                          gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
-                          tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
-                          tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, side)
+                if hpre:
+                    _lib.call('vqvae_upsample_linear_bwd_f16x2', gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
+                              tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
+                              tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, self._slot(4 * nb + 1 + i), side)
+                else:
+                    _lib.call('vqvae_upsample_linear_bwd_bf16' if store & _lib.STORE_GH_BF16 else 'vqvae_upsample_linear_bwd',
+                              gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
+                              tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
+                              tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, side)
                 gp[2] = gp[3] = None           # condition_proj grads: one latent-rate conv, below
             else:
                 grd = _lib.ResblockGrads(*([_p(a) for a in gp] + [None] * 4))

@@ -38,7 +38,7 @@ extern "C" {
 typedef void* vqvae_stream_t;
 
 const char* vqvae_last_error_string(void);
-int vqvae_abi_version(void);      /* 3 since vqvae_resblock_desc grew `storage` (bindings must zero it or set it) */
+int vqvae_abi_version(void);      /* 4 since vqvae_resblock_amax grew x_max / res_scale / gh_scale (3: vqvae_resblock_desc grew `storage`; bindings must zero what they do not set) */
 
 /* ---- device / memory / stream plumbing (replaces CuPy's allocator + streams,
  *      reached in the reference through model.to_gpu()/converter, updaters.py:8) */
@@ -218,6 +218,26 @@ typedef struct {
 /* the bits the library supports for this block shape in the current matmul mode (0 outside mode 1)    */
 int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 
+/* Matmul mode 3 (float32x2): tensors of the packed chain kept PRE-SPLIT.  Every float32x2 GEMM splits each fp32 operand
+ * element into fp16 hi + fp16 lo of x * 2^k while staging it; a tensor that three GEMMs read (x_l: gate GEMM + dilated
+ * weight gradient; gh_l: backward-data GEMM + dilated weight gradient + pull-back) is stored split by its producer
+ * instead: ONE dword per element at the fp32 element's address = hi | lo << 16.  k comes from a rigorous bound on the
+ * tensor's absolute maximum that is known before the producer runs (weight norms found by vqvae_resstack_pack x the
+ * ACTUAL maxima of the producer's inputs); the producer writes that bound into the tensor's SCALE words (a zeroed
+ * VQVAE_AMAX_SLOTS group, vqvae_resblock_amax::res_scale / gh_scale) and every reader is handed those words where it
+ * used to get the maximum.  The values are fp32-accurate (an element within 2^-10 of the bound keeps 24 significant bits,
+ * smaller ones an absolute 2^-39 of the bound: DESIGN.md 3a); they are opaque to the caller.
+ *   GH : gh (B, Cd, T), written by resblock_bwd_packed; readers resstack_dil_wgrad, upsample_linear_bwd_f16x2.
+ *   X / RES: the residual stream, as VQVAE_STORE_X_BF16 / RES_BF16 (first block: RES only; last block: X only).   */
+#define VQVAE_STORE_GH_F16X2 32
+#define VQVAE_STORE_X_F16X2 64
+#define VQVAE_STORE_RES_F16X2 128
+/* the pre-split bits the library supports for this block shape in the current matmul mode (0 outside mode 3)      */
+int vqvae_resblock_f16x2_storage(const vqvae_resblock_desc* d);
+/* which tensors vqvae_resblock_f16x2_storage may offer: bit 0 = gh, bit 1 = the residual stream (default 3, or
+ * $VQVAE_PRESPLIT; 0 = every tensor of the chain stays fp32 -- the A/B switch of the pre-split tests)              */
+int vqvae_set_presplit(int mask);
+
 typedef struct {            /* parameters, Chainer layouts (modules.py:13-22)     */
   const float *Wd, *bd;     /* conv            (Cd, Cr, K, 1), (Cd)               */
   const float *Wc, *bc;     /* condition_proj  (Cd, Cc, 1, 1), (Cd)               */
@@ -240,6 +260,12 @@ typedef struct {
   long P_bstride;
   int Tl;
   const int32_t* v0; const float* w0; const float* w1;
+  /* ABI 4.  P_has_bd != 0: P also includes the dilated conv's bias bd (the caller added bd to the projection's bias: the
+   * lerp weights sum to one), so the gate kernel adds no bias at all.  P_amax: max |P| as VQVAE_AMAX_SLOTS words (as
+   * vqvae_conv1d_fwd_amax publishes them; NULL = unknown).  With both, and T >= 26 Tl, the two-tap gate GEMM adds the
+   * lerp as ONE more step of its contraction -- an (M x 8) x (8 x 128) product of P's columns under the tile with the
+   * lerp coefficients -- instead of fetching four values of P per output element in its epilogue.                  */
+  int P_has_bd; const uint32_t* P_amax;
 } vqvae_resblock_cproj;
 
 size_t vqvae_resblock_workspace_bytes(const vqvae_resblock_desc* d);
@@ -288,6 +314,12 @@ typedef struct {
   const uint32_t* g_skip;   /* bwd in : max |g_skip|                                                  */
   uint32_t* gh;             /* bwd out: max |gh_out| (also read by the backward-data launch)           */
   uint32_t* gx;             /* bwd out: max |gx|     (the previous block's g_res); may be NULL         */
+  /* pre-split storage (VQVAE_STORE_*_F16X2; NULL / ignored otherwise).  With VQVAE_STORE_X_F16X2 `x` above holds the
+   * SCALE words of x (the res_scale of the block before) and x_max its actual maximum (that block's `res`); with an
+   * fp32 x both are the same group.  With VQVAE_STORE_GH_F16X2 `gh` still receives the actual maximum.              */
+  const uint32_t* x_max;    /* fwd in : actual max |x| (enters the bound of the residual output)              */
+  uint32_t* res_scale;      /* fwd out: scale words of the pre-split residual output (zeroed by the caller)    */
+  uint32_t* gh_scale;       /* bwd out: scale words of the pre-split gh_out (zeroed by the caller)             */
 } vqvae_resblock_amax;
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
@@ -390,6 +422,12 @@ int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C
                                    const int32_t* lo0, const int32_t* hi0,
                                    const int32_t* lo1, const int32_t* hi1,
                                    float* gx, long gx_bstride, vqvae_stream_t s);
+/* the same with gy stored pre-split (VQVAE_STORE_GH_F16X2; `scale` = its scale words): ratios Tout >= 8 Tin only */
+int vqvae_upsample_linear_bwd_f16x2(const void* gy, long gy_bstride, int B, int C, int Tin,
+                                    int Tout, const float* w0, const float* w1,
+                                    const int32_t* lo0, const int32_t* hi0,
+                                    const int32_t* lo1, const int32_t* hi1,
+                                    float* gx, long gx_bstride, const uint32_t* scale, vqvae_stream_t s);
 
 /* ---- L.EmbedID + broadcast along T (net.py:57-61): y[b,c,t] = E[id[b],c]      */
 int vqvae_embed_broadcast_fwd(const float* E, const int32_t* ids, int B, int G, int T,

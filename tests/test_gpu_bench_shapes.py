@@ -116,6 +116,69 @@ def test_resstack_b16_vs_oracle(gpu, matmul_mode):
             assert_close_scaled(gb.get(), bg[i][n][1], 1e-4, 'block %d gb %s' % (i, n))
 
 
+def test_presplit_storage_changes_only_the_rounding_point(gpu):
+    """'float32x2', PRE-SPLIT storage (csrc/conv_gemm.hip; vqvae_resblock_desc.storage & VQVAE_STORE_*_F16X2): gh_l and
+    the residual stream x_l are written by their producers as fp16 hi | lo dwords under an a-priori bound, and their
+    readers stage them with two permutes per element pair instead of splitting them again.  Against the same chain with
+    every tensor fp32 (backend.set_presplit(0), round 4's form) the only difference is WHERE the split is rounded: every
+    output and gradient of a four-block stack (B = 16, T = 7680, dilations 1, 2, 256, 512) agrees to 2e-6 of its scale
+    -- fifty times inside the 1e-4 parity bar that test_resstack_b16_vs_oracle holds both forms to -- for gh alone
+    (mask 1), the stream alone (mask 2) and both (mask 3)."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualStackFunction
+    gpu.set_matmul_dtype('float32x2')
+    dils = [1, 2, 256, 512]
+    Tl, Cl, G, nspk = T // 64, 64, 128, 7
+    rs = np.random.RandomState(11)
+    blocks = [_rb_params(rs, 256, 256, 256, Cl + G, 2) for _ in dils]
+    x = rs.standard_normal((B, 256, T)).astype(np.float32)
+    local = rs.standard_normal((B, Cl, Tl)).astype(np.float32)
+    E = rs.standard_normal((nspk, G)).astype(np.float32)
+    ids = rs.randint(0, nspk, B).astype(np.int32)
+    gy = rs.standard_normal((B, 256, T)).astype(np.float32)
+    order = ['conv', 'condition_proj', 'res', 'skip']
+
+    def run(mask):
+        gpu.set_presplit(mask)
+        vx = Variable(_dev(gpu, to4(x)))
+        vlocal, vE = Variable(_dev(gpu, to4(local))), Variable(_dev(gpu, E))
+        vcond = F.condition_assemble(vlocal, vE, _dev(gpu, ids), 64)
+        pv = []
+        for blk in blocks:
+            for n in order:
+                pv += [Variable(_dev(gpu, to4(blk[n][0]))), Variable(_dev(gpu, blk[n][1]))]
+        fn = ResidualStackFunction(dils)
+        skip = fn.apply([vx, vcond] + pv)[0]
+        used = [d.storage for d in fn.descs]
+        out = {'skip': skip.data.get()}
+        skip.grad = _dev(gpu, to4(gy))
+        skip.backward()
+        used = [u | d.storage for u, d in zip(used, fn.descs)]
+        out['gx'] = vx.grad.get()
+        out['glocal'] = vlocal.grad.get()
+        out['gE'] = vE.grad.get()
+        for i, v in enumerate(pv):
+            if v.grad is not None:
+                out['p%d' % i] = v.grad.get()
+        return out, used
+    try:
+        ref, used0 = run(0)
+        assert all(u == 0 for u in used0)
+        for mask in (1, 2, 3):
+            got, used = run(mask)
+            if mask & 1:
+                assert all(u & 32 for u in used), used                      # VQVAE_STORE_GH_F16X2 on every block
+            if mask & 2:
+                assert used[0] & 128 and not used[0] & 64 and used[-1] & 64 and not used[-1] & 128 and all(u & 192 == 192 for u in used[1:-1]), used
+            assert set(got) == set(ref)
+            for k in ref:
+                assert_close_scaled(got[k], ref[k], 2e-6, 'mask %d: %s' % (mask, k))
+    finally:
+        gpu.set_presplit(3)
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+
+
 def test_config1_whole_step_matches_oracle(gpu):
     """BASELINE configs[1] as configured (batch 16, length 7680, d=64 k=512, 20 blocks, 256 channels,
     EMA on): one VQVAE_StandardUpdater.update() against oracle.train_step -- 1 920 argmin indices

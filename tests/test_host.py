@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
         assert s in _lib.PROTOTYPES, 'no ctypes prototype for ' + s
     for s in _lib.PROTOTYPES:
         assert s in syms, 'prototype %s is not declared in include/vqvae_hip.h' % s
-    assert lib.vqvae_abi_version() == 3
+    assert lib.vqvae_abi_version() == 4
 
 
 def test_argument_validation_without_device():
@@ -427,7 +427,9 @@ def test_hot_kernels_keep_their_staging_in_registers(tmp_path):
         'conv_gemm_x3_kernelILi0ELi4ELi2ELi1E': 32768, 'conv_gemm_x3_kernelILi1ELi4ELi2ELi1E': 32768,
         # float32x2 (two pieces per operand)
         'conv_gemm_x3_kernelILi0ELi4ELi2ELi2E': 65536, 'conv_gemm_x3_kernelILi0ELi4ELi1ELi2E': 49152,
-        'conv_gemm_x3_kernelILi1ELi4ELi1ELi2E': 49152, 'conv_gemm_x3_kernelILi2ELi2ELi1ELi2E': 32768,
+        'conv_gemm_x3_kernelILi1ELi4ELi1ELi2ELb0': 49152, 'conv_gemm_x3_kernelILi2ELi2ELi1ELi2E': 32768,
+        'conv_gemm_x3_kernelILi1ELi4ELi1ELi2ELb1': 73728,      # + the condition step's operand image (round 5); still two workgroups per CU
+
         'wgrad3_kernelILi4ELi1ELi2E': 50176,
         'wgrad3_kernelILi4ELi1ELi3E': 75264, 'wgrad3_kernelILi2ELi1ELi3E': 50688, 'wgrad3_kernelILi4ELi1ELi1E': 25088,
         'conv_gemm_kernelILi1ELi4ELb0E': 49152, 'wgrad2_kernelILi4E': None,
