@@ -90,7 +90,12 @@ struct OutR {          // one row range of M
   const float* bias; const float* bias2;
   int rows; int accumulate; int relu;
   unsigned* amax_out;  // range 0 only, nullable: atomicMax of |y| over everything this launch stores (float bits)
+  // add_is_mask != 0: `add` is not added but gates the result -- y = add > 0 ? value : 0: the backward of a ReLU whose OUTPUT
+  // is the tensor this GEMM's result is the gradient of (conv1d_bwd_data_relu), applied where the gradient is produced
+  // instead of in a pass of its own (three passes over 126 MB per step at the configs)
+  int add_is_mask;
 };
+__device__ __forceinline__ float lin_combine(float acc, float p, int is_mask) { return is_mask ? (p > 0.f ? acc : 0.f) : acc + p; }
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_GATE_BWD = 2 };
 
@@ -416,7 +421,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = acc[mi][ni][r] + pv[p][r];
+            float v = lin_combine(acc[mi][ni][r], pv[p][r], od.add_is_mask);
             if (od.relu) v = fmaxf(v, 0.f);
             am = fmaxf(am, fabsf(v));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
@@ -454,7 +459,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
             const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = acc[mi][ni][r] + pv[p & 1][r];
+              float v = lin_combine(acc[mi][ni][r], pv[p & 1][r], od.add_is_mask);
               if (od.relu) v = fmaxf(v, 0.f);
               am = fmaxf(am, fabsf(v));
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
@@ -512,7 +517,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
             if (tok && mrb + dr < rows_left) {
-              float v = acc[mi][ni][r] + bias[r] + addv[r] + oldv[r];
+              float v = lin_combine(acc[mi][ni][r] + bias[r], addv[r], od.add_is_mask) + oldv[r];
               if (od.relu) v = fmaxf(v, 0.f);
               am = fmaxf(am, fabsf(v));
               yp[(long)dr * T] = v;
@@ -2962,12 +2967,21 @@ __global__ __launch_bounds__(256) void wl1_kernel(const L1Args a) {
   float m = 0.f;
   if (blockIdx.y == 0) {
     if (j.Wr)
-      for (int r = wave; r < a.Cr; r += 4) {
-        float sum = 0.f;
-        for (int c = lane; c < Ch; c += 64) sum += fabsf(j.Wr[(long)r * Ch + c]);
+      for (int r0 = 16 * wave; r0 < a.Cr; r0 += 64) {      // sixteen rows per pass: their loads travel together
+        float sum[16];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        m = fmaxf(m, sum + (j.br ? fabsf(j.br[r]) : 0.f));
+        for (int i = 0; i < 16; ++i) {
+          sum[i] = 0.f;
+          const int r = min(r0 + i, a.Cr - 1);
+          for (int c = lane; c < Ch; c += 64) sum[i] += fabsf(j.Wr[(long)r * Ch + c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) sum[i] += __shfl_xor(sum[i], o);
+          const int r = min(r0 + i, a.Cr - 1);
+          m = fmaxf(m, sum[i] + (j.br ? fabsf(j.br[r]) : 0.f));
+        }
       }
   } else {
     const float* W = blockIdx.y == 1 ? j.Wr : j.Ws;
@@ -2976,6 +2990,7 @@ __global__ __launch_bounds__(256) void wl1_kernel(const L1Args a) {
     const int c = tid % Ch, grp = tid / Ch;
     float sum = 0.f;
     if (W && grp < ngrp)
+#pragma unroll 32
       for (int r = grp; r < R; r += ngrp) sum += fabsf(W[(long)r * Ch + c]);
     red[tid] = sum;
     __syncthreads();
@@ -3025,7 +3040,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
     const int mr = o ? m - a.out[0].rows : m;
     const long off = (long)mr * a.Tout + t;
     if (od.bias) v += od.bias[mr];
-    if (od.add) v += od.add[(long)b * od.add_bstride + off];
+    if (od.add) v = lin_combine(v, od.add[(long)b * od.add_bstride + off], od.add_is_mask);
     float* yp = od.y + (long)b * od.y_bstride + off;
     if (od.accumulate) v += *yp;
     if (od.relu) v = fmaxf(v, 0.f);
@@ -3101,7 +3116,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
     static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;   // 0: off; 32 / 64: column tile
     const Seg& s0 = g.seg[0];
     if (lin128 && mode != 0 && g.nseg == 1 && g.M == 256 && s0.cin == 128 && g.out[1].y == nullptr &&
-        !g.out[0].relu && !g.out[0].accumulate && s0.tmul == 1 && s0.tdiv == 1 && s0.toff == 0 && s0.Tin == g.Tout &&
+        !g.out[0].relu && !g.out[0].accumulate && !g.out[0].add_is_mask && s0.tmul == 1 && s0.tdiv == 1 && s0.toff == 0 && s0.Tin == g.Tout &&
         s0.x_cstride == g.Tout && g.Tout % 64 == 0 && s0.vec && s0.ldw >= 256 && g.lerp.P == nullptr &&
         g.skip_flag == nullptr && g.ksplit == 1) {
       Lin128Args la;
@@ -3626,7 +3641,12 @@ static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const flo
 }
 
 static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, const float* gy, float* gx, int accumulate,
-                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s);
+                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s, const float* x_relu = nullptr);
+extern "C" int vqvae_conv1d_bwd_data_relu(const vqvae_conv1d_desc* d, const float* W, const float* gy, const float* x_relu,
+                                          float* gx, void* ws, size_t ws_bytes, const vqvae_conv1d_amax* amax, vqvae_stream_t s) {
+  VQ_REQUIRE(x_relu, "conv1d_bwd_data_relu: null x_relu");
+  return conv1d_bwd_data_impl(d, W, gy, gx, 0, ws, ws_bytes, amax, s, x_relu);
+}
 extern "C" int vqvae_conv1d_bwd_data(const vqvae_conv1d_desc* d, const float* W, const float* gy,
                                      float* gx, int accumulate, void* ws, size_t ws_bytes,
                                      vqvae_stream_t s) {
@@ -3638,8 +3658,9 @@ extern "C" int vqvae_conv1d_bwd_data_amax(const vqvae_conv1d_desc* d, const floa
   return conv1d_bwd_data_impl(d, W, gy, gx, accumulate, ws, ws_bytes, amax, s);
 }
 static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, const float* gy, float* gx, int accumulate,
-                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s) {
+                                void* ws, size_t ws_bytes, const vqvae_conv1d_amax* cam, vqvae_stream_t s, const float* x_relu) {
   if (int e = check_conv_desc(d)) return e;
+  VQ_REQUIRE(!x_relu || !accumulate, "conv1d_bwd_data_relu: the ReLU mask applies to a freshly written gx (accumulate == 0)");
   VQ_REQUIRE(W && gy && gx && ws, "conv1d_bwd_data: null pointer");
   hipStream_t st = (hipStream_t)s;
   const int ldw = pad128(d->Cin), rp = slab_rows(d->Cout);
@@ -3672,6 +3693,7 @@ static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, cons
   g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;
   g.out[0].accumulate = accumulate;
   g.out[0].amax_out = cam ? cam->out : nullptr;
+  if (x_relu) { g.out[0].add = x_relu; g.out[0].add_bstride = (long)d->Cin * d->Tin; g.out[0].add_is_mask = 1; }
   {
     const size_t pkb = align_up((size_t)d->K * rp * ldw * sizeof(float), 256);
     const size_t need = ksplit_partial_floats(d->Cin, d->Tin, d->B, d->K * cdiv(d->Cout, BK)) * sizeof(float);
@@ -4325,7 +4347,7 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
 
 extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                                        const float* const* Ws, const float* const* bs,
-                                       const float* const* z, float* skip, int accumulate,
+                                       const float* const* z, float* skip, int accumulate, int relu,
                                        void* ws, size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_fwd: 1..%d blocks", MAXSEG);
@@ -4363,6 +4385,7 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   g.out[0].y = skip; g.out[0].y_bstride = (long)d->Cs * T; g.out[0].rows = d->Cs;
   g.out[0].bias = bsum;
   g.out[0].accumulate = accumulate;
+  g.out[0].relu = relu ? 1 : 0;                  // the F.relu behind ResidualNet (modules.py:158) in this epilogue: one pass over (B, Cs, T) less
   g.out[0].amax_out = skip_amax_out;
   g.z16 = z_bf16(d) ? 1 : 0;
   g.x_nt = X3_SKIP_X_NT;

@@ -130,8 +130,9 @@ PROTOTYPES = {
     'vqvae_resblock_bwd_packed': (c_int, [C.POINTER(ResblockDesc), C.POINTER(ResblockParams), P, P, P,
                                           P, P, P, P, P, c_size_t, P, C.POINTER(ResblockAmax), P]),
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
-    'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, P,
+    'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, c_int, P,
                                         c_size_t, P, P]),
+    'vqvae_conv1d_bwd_data_relu': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, C.POINTER(Conv1dAmax), P]),
     'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
                                          c_size_t, P]),
     'vqvae_resstack_skip_wgrad': (c_int, [C.POINTER(ResblockDesc), c_int, P, PP, PP, PP, c_int, P,

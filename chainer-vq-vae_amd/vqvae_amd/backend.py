@@ -288,12 +288,16 @@ def memory_stats():
 class DeviceArray(object):
     """A contiguous device buffer with NumPy-like metadata (the ``xp.ndarray``
     of this backend).  Views share the owning block."""
-    __slots__ = ('ptr', 'shape', 'dtype', '_block', 'amax', '__weakref__')
+    __slots__ = ('ptr', 'shape', 'dtype', '_block', 'amax', 'relu_out', 'relu_masked', '__weakref__')
 
     def __init__(self, shape, dtype=np.float32, _block=None, _ptr=None):
         # matmul mode 'float32x2': the tensor's absolute maximum (an upper bound will do), when a producer published
         # it -- a DeviceArray of _lib.AMAX_SLOTS uint32 (see vqvae_absmax); travels with views, dropped by writes
         self.amax = None
+        # relu_out: these values are the output of a ReLU (a conv that reads them may apply that ReLU's backward to the
+        # gradient it produces: vqvae_conv1d_bwd_data_relu); relu_masked: this GRADIENT already carries that mask
+        self.relu_out = False
+        self.relu_masked = False
         if isinstance(shape, int):
             shape = (shape,)
         self.shape = tuple(int(s) for s in shape)
@@ -345,6 +349,7 @@ class DeviceArray(object):
             raise ValueError('cannot reshape %s into %s' % (self.shape, tuple(shape)))
         out = DeviceArray(tuple(shape), self.dtype, _block=self._block, _ptr=self.ptr)
         out.amax = self.amax
+        out.relu_out, out.relu_masked = self.relu_out, self.relu_masked
         return out
 
     def flat_view(self, offset, size, shape=None):

@@ -275,7 +275,9 @@ class Variable(object):
         if self.grad is None:
             self.grad = gx
         else:
+            masked = getattr(self.grad, 'relu_masked', False) and getattr(gx, 'relu_masked', False)
             self.grad = F.raw_add(self.grad, gx)
+            self.grad.relu_masked = masked       # a sum of masked gradients is the masked sum
 
 
 class Parameter(Variable):

@@ -6,6 +6,7 @@ F.resize_images + EmbedID + F.concat net.py:54-63; F.mean net.py:90-91;
 softmax_cross_entropy train.py:95; Variable arithmetic net.py:90-92.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -154,10 +155,15 @@ class ReLU(FunctionNode):
         backend.require_device(inputs[0])
         y = _ew(_lib.EW_RELU, inputs[0])
         y.amax = getattr(inputs[0], 'amax', None)   # max |relu(x)| <= max |x|: an upper bound is all a scale needs
+        y.relu_out = True
         self._y = y
         return y,
 
     def backward(self, indexes, gys):
+        if getattr(gys[0].data, 'relu_masked', False):      # the conv that read y applied the mask where it produced this gradient
+            g = gys[0].data.reshape(gys[0].data.shape)
+            g.relu_masked = False                           # (the mask was THIS function's: nothing upstream may claim it)
+            return g,
         gx = _ew(_lib.EW_RELU_BWD, gys[0].data, self._y)
         gx.amax = getattr(gys[0].data, 'amax', None)
         return gx,
@@ -191,6 +197,11 @@ def mean(a):
 
 def reshape(a, shape):
     return Reshape(shape).apply((a,))[0]
+
+
+# A ReLU's backward gx = gy * (y > 0) runs in the epilogue of the conv that reads y and produces gy (VQVAE_FUSE_RELU_BWD=0:
+# in a pass of its own, as until round 4)
+FUSE_RELU_BWD = os.environ.get('VQVAE_FUSE_RELU_BWD', '1') != '0'
 
 
 def relu(a):
@@ -247,6 +258,7 @@ class Conv1dFunction(FunctionNode):
                       ws.nbytes, _S())
         self.retain_inputs((0, 1))
         self._y = y if self.relu else None
+        y.relu_out = bool(self.relu)
         self._has_b = b is not None
         self._x_shape = x.shape
         return y,
@@ -254,7 +266,7 @@ class Conv1dFunction(FunctionNode):
     def backward(self, indexes, gys):
         x, W = (v.data for v in self.get_retained_inputs())
         gy = gys[0].data
-        if self.relu:
+        if self.relu and not getattr(gy, 'relu_masked', False):     # (masked: the conv that read y did it in its epilogue)
             gy0 = gy
             gy = _ew(_lib.EW_RELU_BWD, gy, self._y)
             gy.amax = getattr(gy0, 'amax', None)
@@ -264,9 +276,16 @@ class Conv1dFunction(FunctionNode):
         gx = None
         if 0 in indexes:
             gx = DeviceArray(self._x_shape, np.float32)
+            am = None
             if f32x2:
                 gx.amax = backend.new_amax()
                 am = _lib.Conv1dAmax(None, backend.absmax(gy).ptr, gx.amax.ptr)
+            if getattr(x, 'relu_out', False) and FUSE_RELU_BWD:
+                # x is the output of a ReLU: that ReLU's backward, gx * (x > 0), in this launch's epilogue
+                _lib.call('vqvae_conv1d_bwd_data_relu', C.byref(self.desc), W.ptr, gy.ptr, x.ptr, gx.ptr,
+                          ws.ptr, ws.nbytes, C.byref(am) if am is not None else None, _S())
+                gx.relu_masked = True
+            elif f32x2:
                 _lib.call('vqvae_conv1d_bwd_data_amax', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
                           ws.ptr, ws.nbytes, C.byref(am), _S())
             else:

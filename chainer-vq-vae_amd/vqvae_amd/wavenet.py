@@ -115,8 +115,11 @@ class ResidualStackFunction(FunctionNode):
         condition gradient sum_l Wc_l^T gh_l is ONE GEMM over K = n_blocks*Cd, and all
         skip-weight gradients share one launch (g_skip is their common operand)."""
 
-    def __init__(self, dilations):
+    def __init__(self, dilations, relu_out=False):
         self.dilations = [int(d) for d in dilations]
+        # relu_out: the F.relu WaveNet applies to the skip sum (modules.py:158) in the skip GEMM's epilogue; its backward
+        # arrives done when the conv that reads the result masked its gradient (functions.FUSE_RELU_BWD)
+        self.relu_out = bool(relu_out)
 
     def forward(self, inputs):
         backend.require_device(*inputs)
@@ -235,7 +238,9 @@ class ResidualStackFunction(FunctionNode):
             bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(lo, hi)])
             zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
             _lib.call('vqvae_resstack_skip_fwd', C.byref(d), n, Ws, bs, zs, skip.ptr,
-                      0 if lo == 0 else 1, ws.ptr, ws.nbytes, _p(skip.amax), _S())
+                      0 if lo == 0 else 1, 1 if (self.relu_out and hi == nb) else 0, ws.ptr, ws.nbytes, _p(skip.amax), _S())
+        skip.relu_out = self.relu_out
+        self._skip = skip if self.relu_out else None
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
 
@@ -250,6 +255,10 @@ class ResidualStackFunction(FunctionNode):
         cond = ins[1]
         lat = self.lat
         g_skip = gys[0].data
+        if self.relu_out and not getattr(g_skip, 'relu_masked', False):     # the fused ReLU's backward, unless the reader did it
+            g0 = g_skip
+            g_skip = F._ew(_lib.EW_RELU_BWD, g0, self._skip)
+            g_skip.amax = getattr(g0, 'amax', None)
         nb = len(self.dilations)
         f16 = self.amax is not None
         if f16:
@@ -523,11 +532,18 @@ class ResidualNet(ChainList):
                 condition_dim, dropout_zero_rate))
 
     def __call__(self, x, condition):
+        return self._forward(x, condition, False)
+
+    def relu_call(self, x, condition):
+        """F.relu(self(x, condition)) with the ReLU in the skip sum's epilogue (WaveNet.__call__, modules.py:158)."""
+        return self._forward(x, condition, True)
+
+    def _forward(self, x, condition, relu):
         blocks = list(self.children())
         args = [x, condition]
         for b in blocks:
             args += b.param_list()
-        return ResidualStackFunction([b.dilation for b in blocks]).apply(args)[0]
+        return ResidualStackFunction([b.dilation for b in blocks], relu_out=relu).apply(args)[0]
 
 
 class WaveNet(Chain):
@@ -579,7 +595,7 @@ class WaveNet(Chain):
         # `generating` is accepted and ignored, as in modules.py:148-160
         x = self.embed_input(x)
         # residual & skip connections (modules.py:155)
-        z = F.relu(self.resnet(x, condition))
+        z = self.resnet.relu_call(x, condition)
         # output (modules.py:158-159); the ReLU after proj1 is fused into its epilogue
         z = self.proj1(z, relu=True)
         y = self.proj2(z)

@@ -165,6 +165,11 @@ int vqvae_conv1d_fwd_amax(const vqvae_conv1d_desc* d, const float* x, const floa
 int vqvae_conv1d_bwd_data_amax(const vqvae_conv1d_desc* d, const float* W, const float* gy,
                                float* gx, int accumulate, void* ws, size_t ws_bytes,
                                const vqvae_conv1d_amax* amax, vqvae_stream_t s);
+/* gx = x_relu > 0 ? conv^T(gy) : 0 -- backward-data of a conv whose INPUT x_relu (B, Cin, Tin) is the output of a ReLU,
+ * with that ReLU's backward applied where the gradient is produced (amax may be NULL)                               */
+int vqvae_conv1d_bwd_data_relu(const vqvae_conv1d_desc* d, const float* W, const float* gy,
+                               const float* x_relu, float* gx, void* ws, size_t ws_bytes,
+                               const vqvae_conv1d_amax* amax, vqvae_stream_t s);
 int vqvae_conv1d_bwd_weight_amax(const vqvae_conv1d_desc* d, const float* x, const float* gy,
                                  float* gW, float* gb, int accumulate, void* ws, size_t ws_bytes,
                                  const vqvae_conv1d_amax* amax, vqvae_stream_t s);
@@ -354,8 +359,10 @@ size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, int nblocks)
 /*      skip_amax_out (nullable): max |skip| is raised there (VQVAE_AMAX_SLOTS zeroed words)         */
 int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                             const float* const* Ws, const float* const* bs,
-                            const float* const* z, float* skip, int accumulate, void* ws,
+                            const float* const* z, float* skip, int accumulate, int relu, void* ws,
                             size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s);
+/*      relu != 0: skip = max(skip (+ old skip), 0) -- WaveNet's F.relu(resnet(...)) (modules.py:158) in this epilogue; with
+ *      more than one group of blocks pass it with the LAST group only                                                   */
 int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
                              const float* const* Wc, const float* const* gh, float* gcond,
                              int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
