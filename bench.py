@@ -355,8 +355,9 @@ def run_c4(args, rank, n, local):
     seen = comm.ranks_seen()
     if rank == 0:
         mode = backend.default_matmul_dtype() if not getattr(args, 'matmul', None) else args.matmul
-        x3 = mode in ('float32x3', 'float32x2')          # (mode 3 runs the VQ sweep on mode 2's six-product kernel)
-        X3_PRODUCTS = 6
+        x3 = mode in ('float32x3', 'float32x2')
+        # 'float32x2': three fp16 products of the scaled two-piece split since round 5 (VQVAE_VQ_X2=0: mode 2's six bf16 products)
+        X3_PRODUCTS = 3 if (mode == 'float32x2' and os.environ.get('VQVAE_VQ_X2', '1') != '0') else 6
         peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS
         flop = 2.0 * N * k * d                              # expansion form, re-check not counted
         byts = 4.0 * (N * d + k * d + N + N * d)            # z read, codebook once, idx write, e write
@@ -389,7 +390,7 @@ def run_c4(args, rank, n, local):
                          '+ gather): MFMA pairwise distance, wavefront argmin, exact re-check of ambiguous rows'
                          % ('vq_wsplit + vq_mfma_x3_kernel' if x3 else 'vq_mfma_reg_kernel'),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                         'peak_is': ('dense bf16 MFMA peak / %d bf16 products per fp32 product; achieved counts '
+                         'peak_is': ('dense 16-bit MFMA peak / %d MFMA products per fp32 product; achieved counts '
                                      'algorithmic fp32 FLOPs' % X3_PRODUCTS if x3 else 'fp32 MFMA peak'),
                          'frac': (ach / peak) if ach else None,
                          'achieved_vs_fp32_mfma_peak': (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None,

@@ -2973,7 +2973,9 @@ __global__ __launch_bounds__(256) void wl1_kernel(const L1Args a) {
         for (int i = 0; i < 16; ++i) {
           sum[i] = 0.f;
           const int r = min(r0 + i, a.Cr - 1);
-          for (int c = lane; c < Ch; c += 64) sum[i] += fabsf(j.Wr[(long)r * Ch + c]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)            // (host: Ch <= 256; a fixed trip count, so that all loads of a pass are requested before the first is used)
+            sum[i] += (lane + 64 * q < Ch) ? fabsf(j.Wr[(long)r * Ch + lane + 64 * q]) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -36,6 +36,16 @@ __global__ void vq_wnorm_kernel(const float* __restrict__ W, int k, int d, float
   wn[j] = s;
   atomicMax(wmax_bits, __float_as_int(s));   // s >= 0: int order == float order
 }
+// the same, plus max_ij |W_ij| in wmax_bits[1] (the two-piece fp16 sweep scales the codebook by a power of two from it)
+__global__ void vq_wnorm_elt_kernel(const float* __restrict__ W, int k, int d, float* wn, int* wmax_bits) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  float s = 0.f, m = 0.f;
+  for (int c = 0; c < d; ++c) { const float w = W[(long)j * d + c]; s = fmaf(w, w, s); m = fmaxf(m, fabsf(w)); }
+  wn[j] = s;
+  atomicMax(wmax_bits, __float_as_int(s));
+  atomicMax(wmax_bits + 1, __float_as_int(m));
+}
 
 // block: NW wavefronts, each owning 32 latent columns; Zs[d][32*NW], Ws[32][d+1]
 template <int NW>
@@ -250,6 +260,43 @@ __device__ __forceinline__ void vq_split3(float x0, float x1, unsigned& h, unsig
   r0 -= __builtin_bit_cast(float, m << 16); r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
   l = vq_pk(r0, r1);
 }
+// ---- the sweep as THREE fp16 products (matmul mode 3, `float32x2`: csrc/conv_gemm.hip "matmul mode 3") ------------------
+// x 2^k = hi + lo (fp16, RNE), <w, z> ~= (w_lo z_hi + w_hi z_lo + w_hi z_hi) 2^-(kw + kz): half the MFMAs of the six-product
+// sweep.  The codebook takes ONE power of two (from max_ij |W_ij|: vq_wnorm_elt_kernel), every latent row its OWN (from its
+// d entries, which its lane pair holds anyway): 2^(14 - e) puts the largest entry in [2^14, 2^15).  Rounding band:
+//   * representation: |x - (hi + lo) 2^-k| <= 2^-22 |x| + 2^-39 max|x| per entry, the dropped w_lo z_lo <= 2^-22 |w z|: over a
+//     row, <= 3 * 2^-22 |w||z| + 2^-39 sqrt(d) (max|z_n| |w| + max|W| |z|) <= (6 + 2^-13 sqrt(d)) u S  (u = 2^-24, S = |z|^2 +
+//     max|w|^2 >= 2 |w||z|, max|W_ij| <= max|w|, max|z_n| <= |z|);
+//   * accumulation: 3 MFMAs per 16 c, each taken as 17 individually rounded additions (the pessimistic end, as for the
+//     six-product sweep): 3 d / 16 * 17 u |w||z| <= 1.6 d u S;
+//   so a dot product is within (1.6 d + 7) u S, dist' = |w|^2 - 2 <w,z> within E_ours = (4.2 d + 16) u S (|w|^2 itself: (d + 1) u
+//   |w|^2, the final fma: u S), and the band 2 (E_ours + E_ref) = (16.4 d + 44) u S -> 17 (d + 4) u S (the six-product sweep: 24).
+// fp16 range: products reach 2^30, row sums 2^37 -- far inside fp32; an all-zero row or codebook keeps a finite scale
+// (exponents clamped to >= -60, so that 2^-(kw + kz) stays a normal fp32).
+using f16x8v = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2v = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ int vq_expo(float m) {                  // exponent e with m in [2^e, 2^(e+1)), clamped to >= -60
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+  return e < -60 ? -60 : e;
+}
+__device__ __forceinline__ void vq_split2(float x0, float x1, int k, unsigned& h, unsigned& l) {
+  const float y0 = __builtin_ldexpf(x0, k), y1 = __builtin_ldexpf(x1, k);
+  f16x2v hv; hv[0] = (_Float16)y0; hv[1] = (_Float16)y1;
+  h = __builtin_bit_cast(unsigned, hv);
+  f16x2v lv; lv[0] = (_Float16)(y0 - (float)hv[0]); lv[1] = (_Float16)(y1 - (float)hv[1]);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+// Wp[piece][code][d] fp16 of W 2^kw (two per 32-bit word)
+__global__ void vq_wsplit2_kernel(const float* __restrict__ W, int k, int d, const int* __restrict__ wmax_bits, unsigned* __restrict__ Wp) {
+  const long pairs = (long)k * d / 2;
+  const int kw = 14 - vq_expo(__int_as_float(wmax_bits[1]));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+    unsigned h, l;
+    vq_split2(W[2 * i], W[2 * i + 1], kw, h, l);
+    Wp[i] = h; Wp[pairs + i] = l;
+  }
+}
+
 // Wp[piece][code][d] bf16 (two per 32-bit word)
 __global__ void vq_wsplit_kernel(const float* __restrict__ W, int k, int d, unsigned* __restrict__ Wp) {
   const long pairs = (long)k * d / 2;
@@ -268,7 +315,9 @@ __global__ void vq_wsplit_kernel(const float* __restrict__ W, int k, int d, unsi
 //   more than VQ_CAP: the row keeps count > VQ_CAP and takes the all-codes re-check).  The distances are
 //   the first pass's to the last bit (same fragments, same MFMA order).
 constexpr int VQ_CAP = 16;
-template <int D, bool CAND>
+// NP = 3: six bf16 products of the exact three-way split (matmul mode 2); NP = 2: three fp16 products of the scaled two-way
+// split (matmul mode 3, see vq_split2) -- same tiles, same bookkeeping, half the MFMAs and a narrower band.
+template <int D, bool CAND, int NP = 3>
 __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
     const float* __restrict__ z, const uint4* __restrict__ Wp, const float* __restrict__ wn,
     const int* __restrict__ wmax_bits, int B, int T, int k,
@@ -277,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   constexpr int TILE = 64, KS = D / 16;              // K steps of 16 c
   constexpr int ROW = D / 8 + 1;                     // 16-byte words per LDS row (+1: conflict-free fragment reads)
   constexpr int WPR = D / 8;                         // 16-byte words per code row in global memory
-  extern __shared__ uint4 wt[];                      // [2][3][TILE][ROW]
+  extern __shared__ uint4 wt[];                      // [2][NP][TILE][ROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const long N = (long)B * T;
@@ -292,29 +341,58 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
     thr = ok_row ? fminb[2 * slot] + fminb[2 * slot + 1] : -INFINITY;
   }
   // B fragment of K step s: lane (column li, half lk) holds c = 16 s + 8 lk .. + 7, split in three
-  uint4 zh[KS], zm[KS], zl[KS];
+  uint4 zh[KS], zm[NP == 3 ? KS : 1], zl[KS];
   float zn = 0.f;
+  float cn = -2.f;                                             // distance = wn[j] + cn * accumulator (NP = 2: carries the way back from the scales)
   {
     const bool ok = ok_row;
     const long bb = ok ? n / T : 0, t = ok ? n % T : 0;
     const float* zp = z + (bb * D) * T + t;
+    if constexpr (NP == 3) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float v[8];
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = ok ? zp[(long)(16 * s + 8 * lk + e) * T] : 0.f;
-        zn = fmaf(v[e], v[e], zn);
+        for (int e = 0; e < 8; ++e) {
+          v[e] = ok ? zp[(long)(16 * s + 8 * lk + e) * T] : 0.f;
+          zn = fmaf(v[e], v[e], zn);
+        }
+        vq_split3(v[0], v[1], zh[s].x, zm[s].x, zl[s].x);
+        vq_split3(v[2], v[3], zh[s].y, zm[s].y, zl[s].y);
+        vq_split3(v[4], v[5], zh[s].z, zm[s].z, zl[s].z);
+        vq_split3(v[6], v[7], zh[s].w, zm[s].w, zl[s].w);
       }
-      vq_split3(v[0], v[1], zh[s].x, zm[s].x, zl[s].x);
-      vq_split3(v[2], v[3], zh[s].y, zm[s].y, zl[s].y);
-      vq_split3(v[4], v[5], zh[s].z, zm[s].z, zl[s].z);
-      vq_split3(v[6], v[7], zh[s].w, zm[s].w, zl[s].w);
+    } else {
+      // the row's own power of two: its largest entry (both halves of the column) into [2^14, 2^15)
+      float zmx = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = ok ? zp[(long)(16 * s + 8 * lk + e) * T] : 0.f;
+          zn = fmaf(v[e], v[e], zn);
+          zmx = fmaxf(zmx, fabsf(v[e]));
+        }
+        zh[s] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));   // parked: split below, once the scale is known
+        zl[s] = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+      }
+      zmx = fmaxf(zmx, __shfl_xor(zmx, 32, 64));
+      const int kz = 14 - vq_expo(zmx), kw = 14 - vq_expo(__int_as_float(wmax_bits[1]));
+      cn = -__builtin_ldexpf(2.f, -(kz + kw));
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const uint4 a = zh[s], bq = zl[s];
+        vq_split2(__uint_as_float(a.x), __uint_as_float(a.y), kz, zh[s].x, zl[s].x);
+        vq_split2(__uint_as_float(a.z), __uint_as_float(a.w), kz, zh[s].y, zl[s].y);
+        vq_split2(__uint_as_float(bq.x), __uint_as_float(bq.y), kz, zh[s].z, zl[s].z);
+        vq_split2(__uint_as_float(bq.z), __uint_as_float(bq.w), kz, zh[s].w, zl[s].w);
+      }
     }
     zn += __shfl_xor(zn, 32, 64);           // both halves of the column
   }
   // staging: a tile is 3 pieces x 64 codes x WPR words; 512 threads
-  constexpr int WORDS = 3 * TILE * WPR, PER_THREAD = (WORDS + 511) / 512;
+  constexpr int WORDS = NP * TILE * WPR, PER_THREAD = (WORDS + 511) / 512;
   uint4 st[PER_THREAD];
   const long piece_words = (long)k * WPR;
   auto load_tile = [&](int jt) {
@@ -327,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
     }
   };
   auto store_tile = [&](int buf) {
-    uint4* dst = wt + (size_t)buf * 3 * TILE * ROW;
+    uint4* dst = wt + (size_t)buf * NP * TILE * ROW;
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       const int f = tid + 512 * i;
@@ -346,10 +424,28 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   for (int jt = 0; jt < ntile; ++jt) {
     const int cur = jt & 1;
     if (jt + 1 < ntile) load_tile(jt + 1);
-    const uint4* base = wt + (size_t)cur * 3 * TILE * ROW;
+    const uint4* base = wt + (size_t)cur * NP * TILE * ROW;
     f32x16 a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        f16x8v w0[2], w1[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          w0[p] = __builtin_bit_cast(f16x8v, base[(p * TILE + li) * ROW + 2 * s + lk]);
+          w1[p] = __builtin_bit_cast(f16x8v, base[(p * TILE + 32 + li) * ROW + 2 * s + lk]);
+        }
+        const f16x8v bh = __builtin_bit_cast(f16x8v, zh[s]), bl = __builtin_bit_cast(f16x8v, zl[s]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[1], bh, a0, 0, 0, 0);      // small products first
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[1], bh, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[0], bl, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[0], bl, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[0], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[0], bh, a1, 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       bf16x8v w0[3], w1[3];
@@ -379,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
       for (int r = 0; r < 16; ++r) {
         const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (j < k) {
-          const float v = fmaf(-2.f, h ? a1[r] : a0[r], wn[j]);
+          const float v = fmaf(cn, h ? a1[r] : a0[r], wn[j]);
           if constexpr (CAND) {
             if (v <= thr) {                                    // (never for lanes without a row: thr = -inf)
               const int c = atomicAdd(&ccount[slot], 1);
@@ -408,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   }
   if (lk == 0 && n < N) {
     const float wmax = __int_as_float(*wmax_bits);
-    const float band = 24.f * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
+    const float band = (NP == 2 ? 17.f : 24.f) * (float)(D + 4) * 5.9604645e-8f * (zn + wmax);
     idx[n] = i1;
     if (!(m2 - m1 > band)) {
       const int sl = atomicAdd(nflag, 1);
@@ -874,31 +970,38 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     const int nw = vq_cols_per_block(dpad);
     VQ_REQUIRE(nw > 0, "vq_nearest_fwd: d=%d too large for the LDS-staged MFMA path (max ~1000)", d);
     VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
-    hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
+    // mode 3: three fp16 products (VQVAE_VQ_X2=0: mode 2's six bf16 products, the A/B alternate)
+    static const int x2_on = getenv("VQVAE_VQ_X2") ? atoi(getenv("VQVAE_VQ_X2")) : 1;
+    const bool x2 = x2_on && (d == 64 || d == 128) && vqvae_get_matmul_dtype() == 3;
+    if (x2) hipLaunchKernelGGL(vq_wnorm_elt_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
+    else hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
-    if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() >= 2) {      // modes 2 and 3: the sweep on the bf16 matrix pipe
+    if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() >= 2) {      // modes 2 and 3: the sweep on the 16-bit matrix pipe
       int nb = (int)(((long)k * d / 2 + 255) / 256);
       if (nb > 2048) nb = 2048;
-      hipLaunchKernelGGL(vq_wsplit_kernel, dim3(nb), dim3(256), 0, st, W, k, d, wsplit);
+      if (x2) hipLaunchKernelGGL(vq_wsplit2_kernel, dim3(nb), dim3(256), 0, st, W, k, d, wmax_bits, wsplit);
+      else hipLaunchKernelGGL(vq_wsplit_kernel, dim3(nb), dim3(256), 0, st, W, k, d, wsplit);
       VQ_LAUNCH_CHECK();
-      const size_t lds = 2 * 3 * 64 * (size_t)(d / 8 + 1) * 16;
+      const size_t lds = 2 * (x2 ? 2 : 3) * 64 * (size_t)(d / 8 + 1) * 16;
       const unsigned grid = (unsigned)((N + 255) / 256);
       // the candidate pass pays when re-checking a row against all k codes costs more than sweeping it again
       static const int cand_on = getenv("VQVAE_VQ_CAND") ? atoi(getenv("VQVAE_VQ_CAND")) : 1;
-      cand_path = cand_on && k >= 1024 && N >= 4096;
+      static const long cand_minN = getenv("VQVAE_VQ_CAND_MINN") ? atol(getenv("VQVAE_VQ_CAND_MINN")) : 1024;      // (round 5: N = 1920 at k = 8192 1.49 -> 1.32 ms with it; 4096 until then)
+      cand_path = cand_on && k >= 1024 && N >= cand_minN;
       // the candidate sweep covers at most N/8 flagged rows per launch geometry; rows beyond are re-checked in full
       const unsigned cgrid = (unsigned)((N / 8 + 255) / 256);
       if (cand_path) VQ_CHECK_HIP(hipMemsetAsync(ccount, 0, (size_t)N * 4, st));
-#define VQ_X3_LAUNCH(Dv)                                                                                        \
+#define VQ_X3_LAUNCH(Dv, NPv)                                                                                   \
       {                                                                                                         \
-        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, false>), dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
+        VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, false, NPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, false, NPv>), dim3(grid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
         if (cand_path) {                                                                                        \
-          VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-          hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, true>), dim3(cgrid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
+          VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_mfma_x3_kernel<Dv, true, NPv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+          hipLaunchKernelGGL((vq_mfma_x3_kernel<Dv, true, NPv>), dim3(cgrid), dim3(512), lds, st, z, (const uint4*)wsplit, wn, wmax_bits, B, T, k, idx, flagged, nflag, fminb, cand, ccount); \
         }                                                                                                       \
       }
-      if (d == 64) VQ_X3_LAUNCH(64) else VQ_X3_LAUNCH(128)
+      if (d == 64) { if (x2) VQ_X3_LAUNCH(64, 2) else VQ_X3_LAUNCH(64, 3) }
+      else { if (x2) VQ_X3_LAUNCH(128, 2) else VQ_X3_LAUNCH(128, 3) }
 #undef VQ_X3_LAUNCH
       VQ_LAUNCH_CHECK();
     } else if (d == 64 || d == 128) {

@@ -179,6 +179,63 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
+def test_presplit_chain_keeps_a_quiet_sample(gpu):
+    """The dynamic-range contract of 'float32x2' (test_gpu_kernels.py::test_float32x2_dynamic_range_contract) through
+    ResidualNet's chain with its PRE-SPLIT tensors: x_l and gh_l are split under a-priori BOUNDS (max |x_l| + the res
+    conv's row norm; the column norms of Wr / Ws times max |g_res| / max |g_skip|), which sit up to 2^6 above the true
+    maxima, so the absolute floor under a quiet sample is that much higher than for a tensor split under its own maximum:
+    2 * K * 2^-33 * max|x| * max|W| per contraction.  A B = 4 batch whose last sample is 1e-4 of the others in x and in
+    the output gradient still gets that sample's forward output and input gradient to 1e-4 of ITS OWN scale against the
+    oracle (three blocks, dilations 1, 2, 4; T = 2048)."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    from vqvae_amd.wavenet import ResidualStackFunction
+    gpu.set_matmul_dtype('float32x2')
+    try:
+        Bq, Tq, ratio = 4, 2048, 1e-4
+        dils = [1, 2, 4]
+        Tl, Cl, G, nspk = Tq // 64, 64, 128, 7
+        rs = np.random.RandomState(23)
+        blocks = [_rb_params(rs, 256, 256, 256, Cl + G, 2) for _ in dils]
+        x = rs.standard_normal((Bq, 256, Tq)).astype(np.float32)
+        x[-1] *= ratio
+        local = rs.standard_normal((Bq, Cl, Tl)).astype(np.float32)
+        E = rs.standard_normal((nspk, G)).astype(np.float32)
+        ids = rs.randint(0, nspk, Bq).astype(np.int32)
+        gy = rs.standard_normal((Bq, 256, Tq)).astype(np.float32)
+        gy[-1] *= ratio
+        cond = np.concatenate([O.upsample_fwd(local, Tq), np.repeat(E[ids][:, :, None], Tq, axis=2)], axis=1).astype(np.float32)
+        h, caches, skip_ref = x, [], None
+        for blk, d in zip(blocks, dils):
+            h, sk, cch = O.resblock_fwd(blk, h, cond, d)
+            caches.append(cch)
+            skip_ref = sk if skip_ref is None else skip_ref + sk
+        g_res = None
+        for i in range(len(dils) - 1, -1, -1):
+            g_res, _, _ = O.resblock_bwd(blocks[i], caches[i], cond, dils[i], g_res, gy)
+        vx = Variable(_dev(gpu, to4(x)))
+        vlocal, vE = Variable(_dev(gpu, to4(local))), Variable(_dev(gpu, E))
+        vcond = F.condition_assemble(vlocal, vE, _dev(gpu, ids), 64)
+        pv = []
+        for blk in blocks:
+            for n in ['conv', 'condition_proj', 'res', 'skip']:
+                pv += [Variable(_dev(gpu, to4(blk[n][0]))), Variable(_dev(gpu, blk[n][1]))]
+        fn = ResidualStackFunction(dils)
+        skip = fn.apply([vx, vcond] + pv)[0]
+        assert all(d.storage & 192 for d in fn.descs), 'the chain did not take the pre-split stream'
+        assert_close(skip.data.get()[..., 0], skip_ref, 1e-4, 'skip_connections')
+        skip.grad = _dev(gpu, to4(gy))
+        skip.backward()
+        assert all(d.storage & 32 for d in fn.descs), 'the chain did not keep gh pre-split'
+        gx = vx.grad.get()[..., 0]
+        assert_close_scaled(gx, g_res, 1e-4, 'gx')
+        rel = np.abs(gx[-1] - g_res[-1]).max() / np.abs(g_res[-1]).max()
+        print('quiet sample (%g of the batch): gx %.2e of its own scale' % (ratio, rel))
+        assert rel <= 1e-4, 'gx of the quiet sample: %.2e of its own scale' % rel
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+
+
 def test_config1_whole_step_matches_oracle(gpu):
     """BASELINE configs[1] as configured (batch 16, length 7680, d=64 k=512, 20 blocks, 256 channels,
     EMA on): one VQVAE_StandardUpdater.update() against oracle.train_step -- 1 920 argmin indices

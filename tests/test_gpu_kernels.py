@@ -538,6 +538,64 @@ def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
             assert e3 <= 1.25 * e1 + 1e-7, '%s: %s %.3e vs fp32 MFMA %.3e (of scale, against float64)' % (name, mode, e3, e1)
 
 
+@pytest.mark.parametrize('ratio', [1e-3, 1e-6])
+def test_float32x2_dynamic_range_contract(gpu, ratio):
+    """What 'float32x2' does NOT promise, pinned: its accuracy is relative to each TENSOR's absolute maximum.
+    An operand element x is carried as fp16 hi + fp16 lo of x 2^k (k: one power of two per tensor), i.e. to within
+    2^-22 |x| + 2^-39 max|x|; a B = 4 batch whose last sample is `ratio` times the others (activations and output
+    gradients alike) therefore gets, on that sample, an ABSOLUTE error floor set by the loud samples.  The contract, per
+    output element of a contraction over K_tot = Cin * K terms, against float64:
+        |err| <= (3 * 2^-22 + K_tot / 16 * 2^-24) * (|W| (*) |x|) + 2 * K_tot * 2^-39 * max|x| * max|W|
+    (first term: what the fp32 MFMA path also has -- operand rounding and fp32 accumulation in 16-deep steps; second term:
+    the floor) for forward, backward-data and backward-weight of a two-tap dilated conv, and the quiet sample's own
+    relative error stays inside the 1e-4 parity tolerance down to a ratio of 1e-6.  A caller whose tensors span more (or who
+    needs bit-exact batch independence / causality) selects 'float32x3': backend.set_matmul_dtype."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    B, Cin, Tin, Cout, K, stride, pad, dil = 4, 256, 1024, 256, 2, 1, 4, 4
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((B, Cin, Tin)).astype(np.float32)
+    x[B - 1] *= ratio
+    W = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = np.zeros(Cout, np.float32)
+    y64 = _conv64(x, W, b, stride, pad, dil)
+    gy = rs.standard_normal(y64.shape).astype(np.float32)
+    gy[B - 1] *= ratio
+    gx64, gW64 = _bwd64(x, W, gy, stride, pad, dil)
+    # the |W| (*) |x| sums of the three contractions
+    ay = _conv64(np.abs(x), np.abs(W), b, stride, pad, dil)
+    agx, agW = _bwd64(np.abs(x), np.abs(W), np.abs(gy), stride, pad, dil)
+    gpu.set_matmul_dtype('float32x2')
+    gpu.set_f32x2_min_gflop(0.0)
+    try:
+        vx, vW, vb = Variable(_dev(gpu, to4(x))), Variable(_dev(gpu, to4(W))), Variable(_dev(gpu, b))
+        y = F.convolution_1d(vx, vW, vb, stride=stride, pad=pad, dilate=dil)
+        yd = y.data.get()[..., 0].astype(np.float64)
+        y.grad = _dev(gpu, to4(gy))
+        y.backward()
+        gxd = vx.grad.get()[..., 0].astype(np.float64)
+        gWd = vW.grad.get()[..., 0].astype(np.float64)
+    finally:
+        gpu.set_f32x2_min_gflop(8.0)
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+    mx, mw, mg = float(np.abs(x).max()), float(np.abs(W).max()), float(np.abs(gy).max())
+
+    def bound(S, ktot, ma, mb):
+        return (3 * 2.0 ** -22 + ktot / 16.0 * 2.0 ** -24) * S + 2.0 * ktot * 2.0 ** -39 * ma * mb + 1e-30
+    checks = [('y', yd, y64, bound(ay, Cin * K, mx, mw)),
+              ('gx', gxd, gx64, bound(agx, Cout * K, mg, mw)),
+              ('gW', gWd, gW64, bound(agW, B * y64.shape[2], mg, mx))]
+    for name, got, want, bd in checks:
+        worst = float((np.abs(got - want) / bd).max())
+        assert worst <= 1.0, '%s: error %.2f x the contract bound' % (name, worst)
+    # the quiet sample against ITS OWN scale
+    for name, got, want in (('y', yd, y64), ('gx', gxd, gx64)):
+        rel = np.abs(got[B - 1] - want[B - 1]).max() / np.abs(want[B - 1]).max()
+        floor = 2.0 * Cin * K * 2.0 ** -39 * max(mx, mg) * mw / np.abs(want[B - 1]).max()
+        print('%s, quiet sample at %g: %.2e of its own scale (floor term of the contract: %.2e)' % (name, ratio, rel, floor))
+        assert rel <= 1e-4, '%s: the quiet sample (%g of the batch) is %.2e of its own scale from float64' % (name, ratio, rel)
+
+
 @pytest.mark.parametrize('mode', ['float32x3', 'float32x2'])
 @pytest.mark.parametrize('scale', [1e-15, 1.0, 1e15])
 def test_float32x3_is_scale_invariant(gpu, scale, mode):
