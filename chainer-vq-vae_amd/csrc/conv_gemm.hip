@@ -145,6 +145,10 @@ struct GemmArgs {
   // ... whose scale also leaves room for the NEXT block's condition step (see "the condition as a K step"): the exponent
   // of x_{l+1}'s scale is at least e(max |P|) - e(max |Wd_{l+1}|) - 1 (floor_p / floor_w: those maxima; NULL = no floor)
   const unsigned* floor_w; const unsigned* floor_p;
+  // EPI_GATE_BWD, float32x2 (OUT bit 1): the pull-back of gh to the latent rate (the adjoint of the gate kernels' condition
+  // lerp, net.py:54-55) in this epilogue -- every workgroup leaves the sums of its 128 columns for the four latent positions
+  // under them in pb_part[b][column tile][2 Ch][4]; lerp.v0 / w0 / w1 are the resize tables (pullback_reduce_kernel finishes)
+  float* pb_part;
 };
 
 // Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error
@@ -428,44 +432,51 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
           }
         }
       } else {
-        float pv[2][16];
+        // LOOK sub-tiles of operands in flight ahead of the one being finished
+        constexpr int LOOK = 2;      // (three in flight for the 256 x 128-tile kernels: epilogue 32 k -> 41 k cycles, measured: the phase is bound by the CU's ~10 B / cycle memory path, not by latency)
+        float pv[LOOK][16];
+        auto request = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const int mi = q >> 1, ni = q & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+          const float* src = od.add ? od.add + (long)b * od.add_bstride
+                                    : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
+          if (src) {
+            const rsrc_t rs = make_rsrc(src);
 #pragma unroll
-        for (int q = 0; q <= 4; ++q) {
-          if (q < 4) {                 // request the operands of sub-tile q
-            const int mi = q >> 1, ni = q & 1;
-            const int mb = m0 + wm * 64 + mi * 32;
-            const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-            const OutR& od = a.out[o];
-            const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
-            const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
-            const float* src = od.add ? od.add + (long)b * od.add_bstride
-                                      : (od.accumulate ? od.y + (long)b * od.y_bstride : nullptr);
-            if (src) {
-              const rsrc_t rs = make_rsrc(src);
+            for (int r = 0; r < 16; ++r) pv[q % LOOK][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ADD_AUX));
+          } else {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) pv[q & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ADD_AUX));
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) pv[q & 1][r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) pv[q % LOOK][r] = 0.f;
           }
-          if (q > 0) {                 // finish sub-tile q - 1
-            const int p = q - 1, mi = p >> 1, ni = p & 1;
-            const int mb = m0 + wm * 64 + mi * 32;
-            const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
-            const OutR& od = a.out[o];
-            const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
-            const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
-            const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
+        };
+        auto finish = [&](auto pc) {
+          constexpr int p = decltype(pc)::value;
+          const int mi = p >> 1, ni = p & 1;
+          const int mb = m0 + wm * 64 + mi * 32;
+          const int o = __builtin_amdgcn_readfirstlane((mb < a.out[0].rows) ? 0 : 1);
+          const OutR& od = a.out[o];
+          const unsigned voff = 4u * (unsigned)(4 * lk * T + wn * 64 + ni * 32 + li);
+          const unsigned sbase = 4u * (unsigned)((o ? mb - a.out[0].rows : mb) * T + t0);
+          const rsrc_t ry = make_rsrc(od.y + (long)b * od.y_bstride);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float v = lin_combine(acc[mi][ni][r], pv[p & 1][r], od.add_is_mask);
-              if (od.relu) v = fmaxf(v, 0.f);
-              am = fmaxf(am, fabsf(v));
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
-            }
+          for (int r = 0; r < 16; ++r) {
+            float v = lin_combine(acc[mi][ni][r], pv[p % LOOK][r], od.add_is_mask);
+            if (od.relu) v = fmaxf(v, 0.f);
+            am = fmaxf(am, fabsf(v));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)(v)), ry, voff, sbase + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * T), X3_LIN_ST_AUX);
           }
-        }
+        };
+        using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+        using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+        request(Q0{}); request(Q1{});
+        if constexpr (LOOK == 3) { request(Q2{}); finish(Q0{}); request(Q3{}); finish(Q1{}); }
+        else { finish(Q0{}); request(Q2{}); finish(Q1{}); request(Q3{}); }
+        finish(Q2{}); finish(Q3{});
       }
     } else {
     // ---- edge tiles: fully predicated ---------------------------------------------------------
@@ -662,6 +673,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         }
       };
       if (ST16 && a.g16) load_gates(std::true_type{}); else load_gates(std::false_type{});
+      // ---- fused latent pull-back (OUT bit 1).  gP[c, v] = sum_t gh[c, t] W(t, v), W(t, v0[t]) = w0[t], W(t, v0[t] + 1) = w1[t]: the
+      // 32 columns of a sub-tile touch the latent positions vs, vs + 1, vs + 2 (vs = v0 of its first column; T >= 64 Tl: the host
+      // checks), the 128 columns of the tile vb .. vb + 3.  The accumulator layout has a lane per COLUMN; the sums run over columns,
+      // so each wave transposes a sub-tile through LDS (64 gh rows x 32 t, row pitch 36 floats: conflict-free both ways) and
+      // lane L then owns row L: 8 ds_read_b128 + 32 broadcast reads of the columns' coefficient triples + 96 FMAs.  The stand-alone
+      // kernel (upsample_bwd_seg_kernel) re-read all of gh, 126 MB per block, for the same sums: 36 us per block, 0.7 ms per step.
+      constexpr bool PB = (OUT & 2) != 0;
+      __shared__ __attribute__((aligned(16))) float pbG[PB ? 4 * 64 * 36 : 4];
+      __shared__ float4 pbC[PB ? 128 : 1];
+      __shared__ float pbT[PB ? 2 * 256 * 4 : 1];              // [column half wn][gh channel][position - vb]
+      [[maybe_unused]] int pb_vb = 0;
+      if constexpr (PB) {
+        pb_vb = a.lerp.v0[t0];
+        const int tid_ = (wm * 2 + wn) * 64 + lk * 32 + li;      // 0 .. 255
+        if (tid_ < 128) {
+          const int tc = min(t0 + tid_, T - 1);
+          const int dv = a.lerp.v0[tc] - a.lerp.v0[min(t0 + (tid_ & ~31), T - 1)];      // 0 or 1
+          const float c0 = t0 + tid_ < T ? a.lerp.w0[tc] : 0.f, c1 = t0 + tid_ < T ? a.lerp.w1[tc] : 0.f;
+          pbC[tid_] = dv == 0 ? make_float4(c0, c1, 0.f, 0.f) : make_float4(0.f, c0, c1, 0.f);
+        }
+        for (int i = tid_; i < 2 * 256 * 4; i += 256) pbT[i] = 0.f;
+        __syncthreads();
+      }
       auto store_gh = [&](auto h16c) {         // (ONE wave-uniform branch around the whole store loop, as for the loads)
         constexpr bool H16 = decltype(h16c)::value;
         // H16 (GemmArgs::h16): gh is read back only as an MFMA operand (backward-data, weight gradient), i.e. rounded
@@ -684,11 +718,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
                 const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
                 const unsigned so = 4u * (unsigned)(dr * T);
                 const float ga = gz * sv * (1.f - tv * tv), gb = gz * tv * sv * (1.f - sv);
+                if constexpr (PB) {
+                  float* gw = pbG + (wm * 2 + wn) * (64 * 36);
+                  gw[(4 * lk + dr) * 36 + li] = ga;
+                  gw[(32 + 4 * lk + dr) * 36 + li] = gb;
+                }
                 if constexpr (H16) {
                   const unsigned pr = pack_bf16x2(ga, gb);
                   __builtin_amdgcn_raw_buffer_store_b16((short)(pr & 0xffffu), rGh16, voff >> 1, so >> 1, X3_GBWD_ST_AUX);
                   __builtin_amdgcn_raw_buffer_store_b16((short)(pr >> 16), rGh16, voff >> 1, (so + sQ) >> 1, X3_GBWD_ST_AUX);
-                } else if constexpr (OUT == 1) {
+                } else if constexpr ((OUT & 1) != 0) {
                   am = fmaxf(am, fmaxf(fabsf(ga), fabsf(gb)));
                   unsigned da, db;
                   presplit_pair(ga, gb, kout, da, db);
@@ -699,11 +738,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
                   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ga), rGh, voff, so, X3_GBWD_ST_AUX);
                   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gb), rGh, voff, so + sQ, X3_GBWD_ST_AUX);
                 }
+              } else if constexpr (PB) {           // rows / columns beyond the tensor contribute nothing
+                float* gw = pbG + (wm * 2 + wn) * (64 * 36);
+                gw[(4 * lk + dr) * 36 + li] = 0.f;
+                gw[(32 + 4 * lk + dr) * 36 + li] = 0.f;
+              }
+            }
+            if constexpr (PB) {
+              // lane L = 32 lk + li owns gh row L of this sub-tile (rows 0..31: ga of z channels mb0 .., rows 32..63: gb)
+              const int L = 32 * lk + li;
+              const float* gr = pbG + (wm * 2 + wn) * (64 * 36) + L * 36;
+              const float4* cc = pbC + (wn * 2 + ni) * 32;
+              float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gr + 4 * q);
+                const float4 ca = cc[4 * q], cb = cc[4 * q + 1], cd = cc[4 * q + 2], ce = cc[4 * q + 3];
+                s0 = fmaf(g4.x, ca.x, s0); s1 = fmaf(g4.x, ca.y, s1); s2 = fmaf(g4.x, ca.z, s2);
+                s0 = fmaf(g4.y, cb.x, s0); s1 = fmaf(g4.y, cb.y, s1); s2 = fmaf(g4.y, cb.z, s2);
+                s0 = fmaf(g4.z, cd.x, s0); s1 = fmaf(g4.z, cd.y, s1); s2 = fmaf(g4.z, cd.z, s2);
+                s0 = fmaf(g4.w, ce.x, s0); s1 = fmaf(g4.w, ce.y, s1); s2 = fmaf(g4.w, ce.z, s2);
+              }
+              // gh channel of row L: ga rows -> z channel, gb rows -> Ch + z channel; position offset of this sub-tile in the tile
+              const int zc = m0 + wm * 64 + mi * 32 + (L & 31);
+              const int ghc = (L >> 5) * Ch + zc;
+              const int off = a.lerp.v0[min(t0 + wn * 64 + ni * 32, T - 1)] - pb_vb;      // 0 .. 2 (wave-uniform)
+              if (zc < Ch) {
+                float* tp = pbT + (wn * 2 * Ch + ghc) * 4;      // (2 Ch = 256 gh channels per column half)
+                tp[off] += s0;
+                tp[off + 1] += s1;
+                if (off + 2 < 4) tp[off + 2] += s2;             // (s2 is exactly 0 when the sub-tile starts at vb + 2)
               }
             }
           }
       };
       if (ST16 && a.h16) store_gh(std::true_type{}); else store_gh(std::false_type{});
+      if constexpr (PB) {
+        __syncthreads();
+        const int tid_ = (wm * 2 + wn) * 64 + lk * 32 + li;
+        const int nt_ = t0 / BN;
+        float* dst = a.pb_part + (((long)b * a.ntile_n + nt_) * (2 * Ch)) * 4;
+        for (int i = tid_; i < 2 * Ch * 4; i += 256) dst[i] = pbT[i] + pbT[2 * Ch * 4 + i];      // column halves in a fixed order
+      }
     } else {                    // the fp32 MFMA kernel runs four waves per SIMD (128 VGPRs): one sub-tile's gate values at a time
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -1155,7 +1231,7 @@ template <int EPI, int WM, int NB, int NP, bool TAP2 = false, int X16 = 0, int O
 __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM == 4 && NB == 1 && TAP2 && X3_LEAN) ? 4 : 2)) void conv_gemm_x3_kernel(const GemmArgs a) {
   static_assert(NB == 1 || WM == 4, "256-column tiles exist for 256-row tiles only");
   static_assert(X16 == 0 || NP == 1 || NP == 2, "bf16-stored activations: mode 1; pre-split activations: mode 3");
-  static_assert(OUT == 0 || (NP == 2 && EPI == EPI_GATE_BWD), "pre-split output: the float32x2 gate-derivative GEMM");
+  static_assert(OUT == 0 || (NP == 2 && EPI == EPI_GATE_BWD), "pre-split output (bit 0) / fused latent pull-back (bit 1): the float32x2 gate-derivative GEMM");
   static_assert(X16 >= 0 && X16 <= (TAP2 ? 3 : 1), "X16: one bit per TAP2 segment, one bit otherwise");
   constexpr bool SEL0 = (X16 & 1) != 0, SEL1 = TAP2 ? (X16 & 2) != 0 : SEL0;
   constexpr bool RAW0 = SEL0 && NP == 1, RAW1 = SEL1 && NP == 1;      // stored as bf16 (2-byte elements, staged as they are)
@@ -1215,11 +1291,25 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // ---- float32x2 (NP == 2): the launch's common product scale 2^(28 - emax) and each segment's activation scale
   // 2^(14 - emax + e_w) (see split2); all wave-uniform, read once per workgroup / per segment switch
   [[maybe_unused]] int emax = 0;
+  // (two-tap launches read their four maxima -- and max |P| -- in straight-line code, once: the loads travel together; a loop
+  // over a runtime segment count, and a second read per use, made the prologue a chain of eight dependent L2 round trips)
+  [[maybe_unused]] unsigned axb[2] = {0u, 0u}, awb[2] = {0u, 0u}, apb = 0u;
+  if constexpr (NP == 2 && TAP2) {
+    const unsigned x0 = a.seg[0].amax ? amax_load(a.seg[0].amax) : __builtin_bit_cast(unsigned, a.seg[0].amax_static);
+    const unsigned w0 = amax_load(a.seg[0].wamax);
+    const unsigned x1 = a.seg[1].amax ? amax_load(a.seg[1].amax) : __builtin_bit_cast(unsigned, a.seg[1].amax_static);
+    const unsigned w1 = amax_load(a.seg[1].wamax);
+    if (EPI == EPI_GATE && a.lerp.fold) apb = amax_load(a.lerp.amax);
+    axb[0] = x0; axb[1] = x1; awb[0] = w0; awb[1] = w1;
+  }
   [[maybe_unused]] auto seg_kx = [&](int s) -> int {
-    return 14 - emax + amax_expo(amax_load(a.seg[s].wamax));
+    if constexpr (TAP2) return 14 - emax + amax_expo(awb[s]);
+    else return 14 - emax + amax_expo(amax_load(a.seg[s].wamax));
   };
   if constexpr (NP == 2) {
     int em = -100000;
+    if constexpr (TAP2) em = max(amax_expo(awb[0]) + amax_expo(axb[0]), amax_expo(awb[1]) + amax_expo(axb[1]));
+    else
     for (int s = 0; s < a.nseg; ++s) {
       const Seg& sg = a.seg[s];
       const int eb = amax_expo(sg.amax ? amax_load(sg.amax) : __builtin_bit_cast(unsigned, sg.amax_static));
@@ -1227,7 +1317,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     }
     // the condition step's products P * c, c <= 1, join the scale -- unless the activations are PRE-SPLIT: their scale,
     // hence the launch's, was fixed by their producer (which saw max |P| too: lin128_stream_kernel's floor)
-    if (EPI == EPI_GATE && a.lerp.fold && !PRE0) em = max(em, amax_expo(amax_load(a.lerp.amax)));
+    if (EPI == EPI_GATE && a.lerp.fold && !PRE0) em = max(em, amax_expo(TAP2 ? apb : amax_load(a.lerp.amax)));
     emax = em;
   }
   // the condition as a K step (see behind the two-tap loop): P is scaled by 2^kp, its lerp coefficients by 2^kc, kp + kc = the
@@ -1237,15 +1327,17 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   [[maybe_unused]] int kp = 0, kc = 0;
   if constexpr (NP == 2 && EPI == EPI_GATE) {
     if (fold) {
-      const int ep = amax_expo(amax_load(a.lerp.amax));
+      const int ep = amax_expo(TAP2 ? apb : amax_load(a.lerp.amax));
       kp = 14 - ep; kc = 14 - emax + ep;
       if (kc > 15) fold = false;
     }
   }
   // pre-split output (OUT): the power of two gh is stored under, from the a-priori bound sum_seg l1[seg] * max|x_seg|
   [[maybe_unused]] int kout = 0;
-  if constexpr (OUT == 1) {
+  if constexpr ((OUT & 1) != 0) {
     float bound = 0.f;
+    if constexpr (TAP2) bound = a.bound_l1[0] * __builtin_bit_cast(float, axb[0]) + a.bound_l1[1] * __builtin_bit_cast(float, axb[1]);
+    else
     for (int s = 0; s < a.nseg; ++s) {
       const Seg& sg = a.seg[s];
       bound += a.bound_l1[s] * __builtin_bit_cast(float, sg.amax ? amax_load(sg.amax) : __builtin_bit_cast(unsigned, sg.amax_static));
@@ -3214,7 +3306,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // not instantiated
   // activations stored as bf16 (matmul mode 1): a linear GEMM over z tensors (z16: every segment), or the caller's mask
   const int xm = (EPI == EPI_LINEAR && g.z16) ? 3 : g.x16;
-  if (mode == 3 && (xm != 0 || g.h16)) {       // float32x2 with pre-split tensors (see presplit_pair)
+  if (mode == 3 && (xm != 0 || g.h16 || (EPI == EPI_GATE_BWD && g.pb_part))) {       // float32x2 with pre-split tensors (see presplit_pair) / the fused pull-back
     VQ_REQUIRE(g.ksplit == 1, "conv_gemm: pre-split tensors: no split-K");
     if constexpr (EPI == EPI_GATE) {
       VQ_REQUIRE(tap2 && lean && xm == 3 && g.seg[0].amax == g.seg[1].amax && g.seg[0].wamax == g.seg[1].wamax,
@@ -3225,9 +3317,17 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
                  "conv_gemm: backward-data GEMM over a pre-split gh: both taps of one tensor, 256 x 128 tiles");
       LG_LAUNCH((conv_gemm_x3_kernel<EPI_LINEAR, 4, 1, 2, true, 3>), dim3((unsigned)nblk), dim3(512), g);
     } else {
-      VQ_REQUIRE(xm == 0 && g.h16 && g.bound_l1 && g.scale_out, "conv_gemm: gate-derivative GEMM storing a pre-split gh needs its bound's inputs (fp32 operands)");
-      if (tap2) LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, true, 0, 1>), dim3((unsigned)grid), dim3(256), g);
-      else LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, false, 0, 1>), dim3((unsigned)grid), dim3(256), g);
+      VQ_REQUIRE(xm == 0 && (!g.h16 || (g.bound_l1 && g.scale_out)), "conv_gemm: gate-derivative GEMM storing a pre-split gh needs its bound's inputs (fp32 operands)");
+      if (g.pb_part) VQ_REQUIRE(g.M == 128 && g.Tout % BN == 0 && g.lerp.v0 && g.lerp.w0 && g.lerp.w1 && (long)g.Tout >= 64L * g.lerp.Tl,
+                                "conv_gemm: the fused latent pull-back serves 128 gate channels, T %% 128 == 0, T >= 64 Tl");
+      const int out = (g.h16 ? 1 : 0) | (g.pb_part ? 2 : 0);
+#define GB_LAUNCH(OUTv)                                                                                                  \
+      do {                                                                                                                \
+        if (tap2) LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, true, 0, OUTv>), dim3((unsigned)grid), dim3(256), g); \
+        else LG_LAUNCH((conv_gemm_x3_kernel<EPI_GATE_BWD, 2, 1, 2, false, 0, OUTv>), dim3((unsigned)grid), dim3(256), g);  \
+      } while (0)
+      if (out == 1) GB_LAUNCH(1); else if (out == 2) GB_LAUNCH(2); else GB_LAUNCH(3);
+#undef GB_LAUNCH
     }
     VQ_LAUNCH_CHECK();
     return 0;
@@ -4200,6 +4300,9 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.g16 = gates_bf16(d) ? 1 : 0;
     g.h16 = (h16 || hpre) ? 1 : 0;
     g.x16 = gres16 ? 1 : 0;                       // segment 0 = g_res
+    if (f16 && am->pb_part) {                     // the latent pull-back of gh in this launch's epilogue
+      g.pb_part = am->pb_part; g.lerp.v0 = am->pb_v0; g.lerp.w0 = am->pb_w0; g.lerp.w1 = am->pb_w1; g.lerp.Tl = am->pb_Tl;
+    }
     if (hpre) {                                   // bound: out[1] max|g_res| + out[2] max|g_skip| (wl1_kernel), segment order [g_res,] g_skip
       g.bound_l1 = wpk + L.hdr + HDR_L1 + (g_res ? 1 : 2);
       g.scale_out = am->gh_scale;
@@ -4576,4 +4679,45 @@ extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_
     if (p.slab_floats + p.bslab_floats > need) need = p.slab_floats + p.bslab_floats;
   }
   return need * sizeof(float) + 256;
+}
+
+// ---------------------------------------------------------------------------
+// The second half of the fused latent pull-back (gemm_epilogue, EPI_GATE_BWD, OUT bit 1): every 128-column tile left its
+// sums for the four latent positions under it; an output position collects the (at most three) tiles that cover it, in
+// ascending tile order.
+// ---------------------------------------------------------------------------
+namespace vq {
+__global__ __launch_bounds__(256) void pullback_reduce_kernel(const float* __restrict__ part, const int32_t* __restrict__ v0,
+                                                             int nblocks, int B, int nt, int Cd, int Tl, float* __restrict__ gP) {
+  const long total = (long)nblocks * B * Cd * Tl;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % Tl);
+    long rest = i / Tl;
+    const int c = (int)(rest % Cd); rest /= Cd;
+    const int l = (int)(rest % nblocks);
+    const int b = (int)(rest / nblocks);
+    // tiles n with v0[128 n] <= v <= v0[128 n] + 3: v0 is non-decreasing in n; start from the proportional guess
+    int n = (int)(((long)v * nt) / Tl) - 3;
+    n = n < 0 ? 0 : n;
+    float sum = 0.f;
+    for (int k = 0; k < 8 && n < nt; ++k, ++n) {
+      const int vb = v0[n * BN];
+      if (vb > v) break;
+      if (v - vb <= 3) sum += part[((((long)l * B + b) * nt + n) * Cd + c) * 4 + (v - vb)];
+    }
+    gP[((long)b * nblocks * Cd + (long)l * Cd + c) * Tl + v] = sum;
+  }
+}
+}  // namespace vq
+
+extern "C" int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
+                                     float* gP, vqvae_stream_t s) {
+  VQ_REQUIRE(part && v0 && gP && nblocks > 0 && B > 0 && Cd > 0 && Tl > 0 && T % vq::BN == 0 && (long)T >= 64L * Tl,
+             "pullback_reduce: bad arguments (T %% 128 == 0, T >= 64 Tl)");
+  const long total = (long)nblocks * B * Cd * Tl;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(vq::pullback_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, part, v0, nblocks, B, T / vq::BN, Cd, Tl, gP);
+  VQ_LAUNCH_CHECK();
+  return 0;
 }

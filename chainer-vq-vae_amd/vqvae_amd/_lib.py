@@ -39,7 +39,8 @@ class ResblockCproj(C.Structure):
 
 class ResblockAmax(C.Structure):
     """vqvae_resblock_amax: device uint32 slots (float bit patterns of absolute maxima), matmul mode 3."""
-    _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx', 'x_max', 'res_scale', 'gh_scale')]
+    _fields_ = [(n, P) for n in ('x', 'res', 'g_res', 'g_skip', 'gh', 'gx', 'x_max', 'res_scale', 'gh_scale',
+                                 'pb_part', 'pb_v0', 'pb_w0', 'pb_w1')] + [('pb_Tl', c_int)]
 
 
 class Conv1dAmax(C.Structure):
@@ -154,6 +155,7 @@ PROTOTYPES = {
     'vqvae_resblock_bf16_storage': (c_int, [C.POINTER(ResblockDesc)]),
     'vqvae_resblock_f16x2_storage': (c_int, [C.POINTER(ResblockDesc)]),
     'vqvae_set_presplit': (c_int, [c_int]),
+    'vqvae_pullback_reduce': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     'vqvae_upsample_linear_bwd_f16x2': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                 P, c_long, P, P]),
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),

@@ -170,6 +170,7 @@ def bind_to_numa_node(node, allowed_cpus=None):
 
 class RcclCommunicator(object):
     always_reduce = True      # a 1-rank communicator still exercises the all-reduce (self-test)
+    capture_safe = True       # allreduce_grad only enqueues ncclAllReduce on the given stream: nothing host-side to lose in a recorded step
 
     def __init__(self, rank=None, size=None, device=None, timeout=300.0):
         from . import _lib, backend

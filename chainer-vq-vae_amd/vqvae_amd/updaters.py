@@ -245,14 +245,23 @@ class VQVAE_ParallelUpdater(StandardUpdater):
     optimizer's alpha must already be lr/n (train.py:101)."""
 
     def __init__(self, iterator, optimizer, comm=None, converter=concat_examples, device=0,
-                 loss_func=None, overlap_comm=False, graph=False):
+                 loss_func=None, overlap_comm=None, graph=False):
         super(VQVAE_ParallelUpdater, self).__init__(iterator, optimizer, converter, device,
                                                     loss_func, graph=graph)
         self.comm = comm or SingleCommunicator()
-        # opt-in: exchange the gradients that are final after the reconstruction loss's backward (decoder,
-        # condition embed: 95 % of the arena) on the side stream while the codebook / commitment losses
-        # still back-propagate into vq.W and the encoder; fixed bucket order, same sums
-        self.overlap_comm = overlap_comm
+        # exchange the gradients that are final after the reconstruction loss's backward (decoder, condition embed: 95 % of
+        # the arena) on the side stream while the codebook / commitment losses still back-propagate into vq.W and the
+        # encoder; fixed bucket order, same sums.  Default (None): on whenever there is someone to exchange with
+        # (comm.size > 1); False keeps the whole arena in one all-reduce on the main stream.
+        self.overlap_comm = (self.comm.size > 1) if overlap_comm is None else bool(overlap_comm)
+        # A recorded step (graph=True) replays whatever the communicator ENQUEUED while it was recorded: a communicator that
+        # does host-side work per exchange would run it once, at capture, and never again -- replicas would diverge silently.
+        # Only communicators that declare themselves capture-safe (device-side collectives only) may be recorded with n > 1.
+        if self.graph and self.comm.size > 1 and not getattr(self.comm, 'capture_safe', False):
+            import warnings
+            warnings.warn('VQVAE_ParallelUpdater(graph=True): %s does not declare capture_safe; running eager steps'
+                          % type(self.comm).__name__)
+            self.graph = False
         self._buckets = None
 
     def _grad_buckets(self, optimizer, model, merged=False):

@@ -94,6 +94,9 @@ def _groups(nb, size=_lib.MAX_STACK_GROUP):
     return [(lo, min(nb, lo + size)) for lo in range(0, nb, size)]
 
 
+FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
+
+
 def _grad_out(var, shape):
     """Gradient destination for input ``var``: its slot in the flat gradient arena
     when it is a Parameter that has no gradient yet, else a fresh array."""
@@ -300,6 +303,12 @@ class ResidualStackFunction(FunctionNode):
             Bl, Cc, Tl = lat.shape
             tb = F.resize_tables(Tl, d0.T)
             gP = DeviceArray((Bl, nb * d0.Cd, Tl), np.float32)
+        # 'float32x2': the pull-back of every gh_l to the latent rate runs inside the launch that produces gh_l
+        # (vqvae_resblock_amax.pb_part) and one reduce launch finishes all blocks; VQVAE_FUSE_PULLBACK=0: a launch per block
+        pb_part = None
+        if (f16 and lat is not None and self.packed is not None and FUSE_PULLBACK and d0.Cd == 256
+                and d0.T % 128 == 0 and d0.T >= 64 * Tl):
+            pb_part = DeviceArray((nb, d0.B, d0.T // 128, d0.Cd, 4), np.float32)
         # side-stream scratch, sized once for everything it will run (never regrown mid-flight)
         # res-conv weight gradients: one batched launch on the MAIN stream after the chain (it
         # then overlaps with whatever the side stream still has queued); balances the two queues
@@ -397,7 +406,9 @@ class ResidualStackFunction(FunctionNode):
                         am = C.byref(_lib.ResblockAmax(
                             None, None, None if g_res is None else self._slot(2 * nb + i), self._slot(3 * nb),
                             self._slot(nb + i), self._slot(2 * nb + i - 1) if (gx is not None and i > 0) else None,
-                            None, None, self._slot(4 * nb + 1 + i) if hpre else None))
+                            None, None, self._slot(4 * nb + 1 + i) if hpre else None,
+                            (pb_part.ptr + i * (pb_part.nbytes // nb)) if pb_part is not None else None,
+                            tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr, Tl))
                     _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), h.ptr, gates.ptr,
                               z.ptr, _p(g_res), g_skip.ptr, _p(gx), gh.ptr, ws.ptr, ws.nbytes,
                               self.packed.ptr + i * self.packed_stride, am, _S())
@@ -413,7 +424,9 @@ class ResidualStackFunction(FunctionNode):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
-                if hpre:
+                if pb_part is not None:
+                    pass                       # done in the gate-derivative launch's epilogue; reduced below
+                elif hpre:
                     _lib.call('vqvae_upsample_linear_bwd_f16x2', gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
                               tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
                               tb['hi1'].ptr, gP.ptr + i * d.Cd * Tl * 4, nb * d.Cd * Tl, self._slot(4 * nb + 1 + i), side)
@@ -441,6 +454,8 @@ class ResidualStackFunction(FunctionNode):
             # join: everything issued after this point on the main stream (and everything the
             # caller issues after backward returns) is ordered behind the side stream's work
             backend.wait_event(_S(), backend.Event().record(side))
+        if pb_part is not None:
+            _lib.call('vqvae_pullback_reduce', pb_part.ptr, tb['v0'].ptr, nb, d.B, d.T, d.Cd, Tl, gP.ptr, _S())
         if lat is not None:
             # every block's gh has been pulled back to the latent rate (adjoint of the epilogue
             # lerp) on the side stream; the (nb*Cd, Cc) 1x1 conv's own backward then gives

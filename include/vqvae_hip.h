@@ -325,7 +325,17 @@ typedef struct {
   const uint32_t* x_max;    /* fwd in : actual max |x| (enters the bound of the residual output)              */
   uint32_t* res_scale;      /* fwd out: scale words of the pre-split residual output (zeroed by the caller)    */
   uint32_t* gh_scale;       /* bwd out: scale words of the pre-split gh_out (zeroed by the caller)             */
+  /* the latent pull-back of gh (the adjoint of the forward's condition lerp) inside resblock_bwd_packed: with pb_part !=
+   * NULL (Cd == 256, T % 128 == 0, T >= 64 pb_Tl) the gate-derivative launch leaves, per 128-column tile, the sums of
+   * gh over the tile's columns for the four latent positions under it in pb_part[b][tile][Cd][4] -- the caller does not
+   * call vqvae_upsample_linear_bwd* for this block and finishes all blocks at once with vqvae_pullback_reduce.
+   * pb_v0 / pb_w0 / pb_w1: the Tl -> T resize tables (as vqvae_resblock_cproj).                                        */
+  float* pb_part; const int32_t* pb_v0; const float* pb_w0; const float* pb_w1; int pb_Tl;
 } vqvae_resblock_amax;
+/* gP[b][l * Cd + c][v] = sum over the tiles n whose four positions v0[128 n] .. + 3 hold v of part[l][b][n][c][v - v0[128 n]]
+ * (ascending n: deterministic); part = nblocks consecutive pb_part buffers of B * (T / 128) * Cd * 4 floats          */
+int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
+                          float* gP, vqvae_stream_t s);
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
                         const vqvae_resblock_params* params, const int* has_res, void* packed,

@@ -139,8 +139,10 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
     gy = rs.standard_normal((B, 256, T)).astype(np.float32)
     order = ['conv', 'condition_proj', 'res', 'skip']
 
-    def run(mask):
+    def run(mask, fuse_pullback=True):
+        import vqvae_amd.wavenet as wn
         gpu.set_presplit(mask)
+        wn.FUSE_PULLBACK = fuse_pullback
         vx = Variable(_dev(gpu, to4(x)))
         vlocal, vE = Variable(_dev(gpu, to4(local))), Variable(_dev(gpu, E))
         vcond = F.condition_assemble(vlocal, vE, _dev(gpu, ids), 64)
@@ -174,7 +176,14 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
             assert set(got) == set(ref)
             for k in ref:
                 assert_close_scaled(got[k], ref[k], 2e-6, 'mask %d: %s' % (mask, k))
+        # the latent pull-back inside the gate-derivative launch (vqvae_resblock_amax.pb_part + vqvae_pullback_reduce) against a
+        # vqvae_upsample_linear_bwd* launch per block: the same sums in another order
+        unfused, _ = run(3, fuse_pullback=False)
+        for k in ref:
+            assert_close_scaled(got[k], unfused[k], 2e-6, 'fused pull-back: %s' % k)
     finally:
+        import vqvae_amd.wavenet as wn
+        wn.FUSE_PULLBACK = True
         gpu.set_presplit(3)
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 

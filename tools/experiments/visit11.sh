@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_model.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -4
+for i in 1 2; do
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r = d['roofline']
+print('bench: ms/step %.3f (with input %.3f) | gate kernel avg %.1f us  frac %.3f  loss %s' % (d['ms_per_step'], d['ms_per_step_with_input'], 1e3 * r['avg_launch_ms'], r['frac'], d['losses_last_step']))"
+done
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --force-comm --graph 2>&1 | tail -3 | cut -c1-600
+bash tools/kstats.sh --no-graph 2>&1 | head -24
