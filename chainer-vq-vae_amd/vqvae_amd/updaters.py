@@ -254,6 +254,7 @@ class VQVAE_ParallelUpdater(StandardUpdater):
         # encoder; fixed bucket order, same sums.  Default (None): on whenever there is someone to exchange with
         # (comm.size > 1); False keeps the whole arena in one all-reduce on the main stream.
         self.overlap_comm = (self.comm.size > 1) if overlap_comm is None else bool(overlap_comm)
+        self._overlap_defaulted = overlap_comm is None      # (a defaulted request gives way when the model has no .encoder / .vq to bucket by)
         # A recorded step (graph=True) replays whatever the communicator ENQUEUED while it was recorded: a communicator that
         # does host-side work per exchange would run it once, at capture, and never again -- replicas would diverge silently.
         # Only communicators that declare themselves capture-safe (device-side collectives only) may be recorded with n > 1.
@@ -318,7 +319,9 @@ class VQVAE_ParallelUpdater(StandardUpdater):
             self.last_losses = (self.loss_func or model)(*in_arrays)
         exchange = n > 1 or getattr(self.comm, 'always_reduce', False)
         if self.overlap_comm and exchange:
-            return self._update_overlapped(optimizer, model)
+            lm = self.loss_func_model(model)
+            if not self._overlap_defaulted or (hasattr(lm, 'encoder') and hasattr(lm, 'vq')):
+                return self._update_overlapped(optimizer, model)
         three_loss_backward(model, self.last_losses)
 
         # parameters created during this forward (lazily shaped links, net.py:34-43) join the
