@@ -166,6 +166,23 @@ def set_f32x2_min_gflop(gflop):
     _lib.call('vqvae_set_f32x2_min_gflop', float(gflop))
 
 
+def defer_to_side(keep):
+    """Work has been enqueued on the side stream that the main stream does not wait for yet; ``keep``: everything that work
+    reads or writes through temporaries (the allocator invariant below: a block must not return to the pool before a join
+    has been enqueued behind its last side-stream user).  join_side() closes the window."""
+    _state.setdefault('side_keep', []).append(keep)
+    _state['side_pending'] = True
+
+
+def join_side():
+    """The main stream waits for everything deferred to the side stream (no-op when nothing is pending).  Called when a
+    backward sweep ends (core.Variable.backward), before anything reads the gradients."""
+    if _state.get('side_pending'):
+        wait_event(stream(), Event().record(side_stream()))
+        _state['side_pending'] = False
+        _state['side_keep'] = []
+
+
 def set_presplit(mask):
     """'float32x2' only: which tensors of ResidualNet's chain are kept PRE-SPLIT in HBM (fp16 hi | lo dwords written once
     by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; default 3

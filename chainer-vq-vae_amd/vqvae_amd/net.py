@@ -6,7 +6,7 @@ ConditionEmbed net.py:29-64, VAE net.py:67-96); the bodies are written for this
 runtime: activations fused into conv epilogues, the condition tensor kept at the
 latent rate until the decoder consumes it, one nearest-code search per step.
 """
-from . import core, functions as F, links as L
+from . import backend, core, functions as F, links as L
 from .core import Chain, Variable
 from .utils import VQ
 
@@ -76,6 +76,12 @@ class VAE(Chain):
             self.decoder = decoder
 
     def __call__(self, x_enc, x_dec, global_condition, t):
+        # the decoder's weight slabs are packed on the side stream while the encoder / quantiser / condition embed run
+        dec = self.decoder
+        dec = getattr(dec, 'target' if core.config.train else 'ema', dec)
+        rn = getattr(dec, 'resnet', None)
+        if hasattr(rn, 'prepack_async') and isinstance(x_dec, backend.DeviceArray):
+            rn.prepack_async(x_dec.shape[0], x_dec.shape[2] if x_dec.ndim == 4 else x_dec.shape[1])
         z = self.encoder(x_enc)
         z_const = Variable(z.data)            # stop-gradient view of the latents
 

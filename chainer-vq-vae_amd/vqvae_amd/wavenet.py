@@ -94,7 +94,25 @@ def _groups(nb, size=_lib.MAX_STACK_GROUP):
     return [(lo, min(nb, lo + size)) for lo in range(0, nb, size)]
 
 
+def _pack_key(params, d0):
+    return (tuple(p.ptr for p in params), d0.B, d0.T, d0.Cr, d0.Cd, d0.Cs, d0.Cc, d0.K,
+            _lib.load().vqvae_get_matmul_dtype())
+
+
+def _pack_stack(params, d0, nb, stream):
+    """Every block's weight slabs (forward and backward forms) re-laid for this step (vqvae_resstack_pack)."""
+    per = _lib.load().vqvae_resstack_packed_bytes(C.byref(d0))
+    packed = DeviceArray((nb * per // 4,), np.float32)
+    prms = (_lib.ResblockParams * nb)(*[
+        _lib.ResblockParams(*[params[8 * i + j].ptr for j in range(8)]) for i in range(nb)])
+    has_res = (C.c_int * nb)(*([1] * (nb - 1) + [0]))
+    _lib.call('vqvae_resstack_pack', C.byref(d0), nb, prms, has_res, packed.ptr, packed.nbytes, stream)
+    return packed, per
+
+
 FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
+DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
+PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
 
 
 def _grad_out(var, shape):
@@ -118,8 +136,9 @@ class ResidualStackFunction(FunctionNode):
         condition gradient sum_l Wc_l^T gh_l is ONE GEMM over K = n_blocks*Cd, and all
         skip-weight gradients share one launch (g_skip is their common operand)."""
 
-    def __init__(self, dilations, relu_out=False):
+    def __init__(self, dilations, relu_out=False, prepacked=None):
         self.dilations = [int(d) for d in dilations]
+        self.prepacked = prepacked       # ResidualNet.prepack_async's (key, packed, stride, event), or None
         # relu_out: the F.relu WaveNet applies to the skip sum (modules.py:158) in the skip GEMM's epilogue; its backward
         # arrives done when the conv that reads the result masked its gradient (functions.FUSE_RELU_BWD)
         self.relu_out = bool(relu_out)
@@ -130,6 +149,8 @@ class ResidualStackFunction(FunctionNode):
         nb = len(self.dilations)
         assert len(inputs) == 2 + 8 * nb
         self.descs, self.saved = [], []
+        if self.prepacked is not None:      # whatever becomes of the slabs, the main stream is behind the side stream's writes of them
+            backend.wait_event(_S(), self.prepacked[3])
         h = x
         # condition projection at the latent rate (see vqvae_resblock_cproj in the header)
         self.lat = None
@@ -177,14 +198,12 @@ class ResidualStackFunction(FunctionNode):
         if self.lat is not None and PACK_ONCE:
             # every block's weight slabs (forward and backward forms), re-laid once for this step
             d0 = _rb_desc(x, cond, inputs[2], inputs[8], self.dilations[0])
-            per = _lib.load().vqvae_resstack_packed_bytes(C.byref(d0))
-            self.packed = DeviceArray((nb * per // 4,), np.float32)
-            self.packed_stride = per
-            prms = (_lib.ResblockParams * nb)(*[
-                _lib.ResblockParams(*[inputs[2 + 8 * i + j].ptr for j in range(8)]) for i in range(nb)])
-            has_res = (C.c_int * nb)(*([1] * (nb - 1) + [0]))
-            _lib.call('vqvae_resstack_pack', C.byref(d0), nb, prms, has_res, self.packed.ptr,
-                      self.packed.nbytes, _S())
+            pre = self.prepacked
+            if pre is not None and pre[0] == _pack_key(inputs[2:], d0):
+                # packed on the side stream while the encoder / quantiser / condition embed ran (ResidualNet.prepack_async)
+                self.packed, self.packed_stride = pre[1], pre[2]
+            else:
+                self.packed, self.packed_stride = _pack_stack(inputs[2:], d0, nb, _S())
         for i, dil in enumerate(self.dilations):
             Wd, bd, Wc, bc, Wr, br, Ws, bs = inputs[2 + 8 * i: 10 + 8 * i]
             d = _rb_desc(h, cond, Wd, Ws, dil)
@@ -321,10 +340,19 @@ class ResidualStackFunction(FunctionNode):
                    _lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), min(nb, _lib.MAX_STACK_GROUP)),
                    _lib.load().vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d0), min(nb, dil_group)))
         ws_side = backend.workspace(need, slot)
+        # The weight gradients that are still due when the chain has reached the first block -- the last group of dilated-conv
+        # gradients and every res conv's -- need nothing that comes later, and what comes later is the latent-rate tail of the
+        # backward pass (pull-back reduce, condition embed, encoder, VQ: ~70 launches of 5-30 us on a handful of workgroups
+        # each, 0.7 ms during which the chip is all but idle).  They go to the side stream and run BESIDE that tail;
+        # Variable.backward() joins the streams when the sweep is done (backend.join_side).  VQVAE_DEFER_WGRAD=0: in line.
+        defer = DEFER_WGRAD and not overlap and lat is not None and self.packed is not None
+        ws_defer = backend.workspace(need, 'side') if defer else None
         dil_pending = []          # blocks whose gh exists but whose dilated-conv wgrad is not issued yet
         gdil = {}                 # block -> (gWd, gbd) destinations
 
-        def flush_dil():
+        def flush_dil(stream=None, ws=None):
+            stream = side if stream is None else stream
+            ws = ws_side if ws is None else ws
             if not dil_pending:
                 return
             blocks = list(dil_pending)
@@ -347,8 +375,8 @@ class ResidualStackFunction(FunctionNode):
                           _lib.ptr_array([self.saved[i][0] for i in sel]),
                           _lib.ptr_array([ghs[i] for i in sel]),
                           _lib.ptr_array([gdil[i][0] for i in sel]),
-                          _lib.ptr_array([gdil[i][1] for i in sel]), 0, ws_side.ptr, ws_side.nbytes,
-                          xam, gam, side)
+                          _lib.ptr_array([gdil[i][1] for i in sel]), 0, ws.ptr, ws.nbytes,
+                          xam, gam, stream)
 
         # skip-conv weight gradients need only g_skip and the saved z_l: start them right away
         gWs = [_grad_out(in_vars[2 + 8 * i + 6], ins[2 + 8 * i + 6].shape) for i in range(nb)]
@@ -365,9 +393,10 @@ class ResidualStackFunction(FunctionNode):
 
         pending = [nb]          # res-conv weight gradients are issued for blocks [lo, pending)
 
-        def flush_res(lo):
+        def flush_res(lo, stream=None, ws=None):
             """gWr_l, gbr_l for blocks lo..pending-1 (their g_res_l exist once the chain has
             passed block l+1)."""
+            stream = _S() if stream is None else stream
             hi = pending[0]
             if hi <= lo:
                 return
@@ -377,14 +406,14 @@ class ResidualStackFunction(FunctionNode):
                     gbr[i] = _grad_out(in_vars[2 + 8 * i + 5], ins[2 + 8 * i + 5].shape)
             for glo, ghi in _groups(hi - lo):
                 a, b = lo + glo, lo + ghi
-                wsm = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), b - a))
+                wsm = ws if ws is not None else backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), b - a))
                 zs = _lib.ptr_array([self.saved[i][2] for i in range(a, b)])
                 ram = None
                 if f16:      # g_res_l was published by block l + 1's backward-data launch
                     ram = (C.c_void_p * (b - a))(*[None if g_ress[i] is None else self._slot(2 * nb + i)
                                                    for i in range(a, b)])
                 _lib.call('vqvae_resstack_res_wgrad', C.byref(d0), b - a, _lib.ptr_array(g_ress[a:b]), zs,
-                          _lib.ptr_array(gWr[a:b]), _lib.ptr_array(gbr[a:b]), 0, wsm.ptr, wsm.nbytes, ram, _S())
+                          _lib.ptr_array(gWr[a:b]), _lib.ptr_array(gbr[a:b]), 0, wsm.ptr, wsm.nbytes, ram, stream)
             pending[0] = lo
 
         for i in range(nb - 1, -1, -1):
@@ -420,7 +449,7 @@ class ResidualStackFunction(FunctionNode):
                 ghs[i] = gh
                 gdil[i] = (gp[0], gp[1])
                 dil_pending.append(i)
-                if len(dil_pending) >= dil_group or i == 0:
+                if (len(dil_pending) >= dil_group or i == 0) and not (defer and i == 0):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
@@ -449,7 +478,14 @@ class ResidualStackFunction(FunctionNode):
                 flush_res(i)
         d = self.descs[0]
         # weight gradients of the res convs of the blocks not yet covered (those nearest the input)
-        flush_res(0)
+        if defer:
+            sd = backend.side_stream()
+            backend.wait_event(sd, backend.Event().record(_S()))       # every gh, g_res of the chain is complete
+            flush_dil(sd, ws_defer)
+            flush_res(0, sd, ws_defer)
+            backend.defer_to_side([self.saved, ghs, g_ress, gdil, ws_defer, self.packed, self.amax, g_skip])
+        else:
+            flush_res(0)
         if overlap:
             # join: everything issued after this point on the main stream (and everything the
             # caller issues after backward returns) is ordered behind the side stream's work
@@ -558,7 +594,26 @@ class ResidualNet(ChainList):
         args = [x, condition]
         for b in blocks:
             args += b.param_list()
-        return ResidualStackFunction([b.dilation for b in blocks], relu_out=relu).apply(args)[0]
+        pre, self._prepacked = getattr(self, '_prepacked', None), None
+        return ResidualStackFunction([b.dilation for b in blocks], relu_out=relu, prepacked=pre).apply(args)[0]
+
+    def prepack_async(self, B, T):
+        """The chain's weight slabs for an upcoming forward over (B, ., T), packed on the SIDE stream now -- VAE.__call__ calls
+        this before the encoder, so the ten-odd packing launches (~0.2 ms on a handful of workgroups) run beside the
+        encoder / quantiser / condition-embed chain instead of in front of the first gate GEMM.  The forward takes the
+        result if nothing changed (parameters, shapes, matmul mode), else packs as before."""
+        if not (PACK_ONCE and PREPACK_ASYNC):
+            return
+        blocks = list(self.children())
+        params = [p.data for b in blocks for p in b.param_list()]
+        if any(not isinstance(p, DeviceArray) for p in params):
+            return
+        Wd, Wc, Ws = params[0], params[2], params[6]
+        d0 = _lib.ResblockDesc(B, T, Wd.shape[1], Wd.shape[0], Ws.shape[0], Wc.shape[1], Wd.shape[2], blocks[0].dilation)
+        side = backend.side_stream()
+        backend.wait_event(side, backend.Event().record(_S()))       # the optimizer's last write of the parameters
+        packed, per = _pack_stack(params, d0, len(blocks), side)
+        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side))
 
 
 class WaveNet(Chain):

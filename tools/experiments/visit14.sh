@@ -1,0 +1,16 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 2400 python -m pytest tests/test_gpu_bench_shapes.py tests/test_gpu_model.py tests/test_gpu_configs.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -4
+for v in "X=1" "VQVAE_DEFER_WGRAD=0" "X=2" "VQVAE_DEFER_WGRAD=0"; do
+env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r = d['roofline']
+print('$v bench: ms/step %.3f (with input %.3f) | gate kernel avg %.1f us  loss %s' % (d['ms_per_step'], d['ms_per_step_with_input'], 1e3 * r['avg_launch_ms'], d['losses_last_step']))"
+done
+env VQVAE_DEFER_WGRAD=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph 2>/dev/null | python -c "
+import json,sys
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('eager defer: ms/step %.3f' % d['ms_per_step'])"
+env VQVAE_DEFER_WGRAD=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph 2>/dev/null | python -c "
+import json,sys
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('eager no defer: ms/step %.3f' % d['ms_per_step'])"
