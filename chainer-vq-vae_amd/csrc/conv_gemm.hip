@@ -213,6 +213,24 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
+// LDS-DMA plumbing (conv_gemm_x3_kernel's ADMA): a resource descriptor as four SGPRs for inline asm, an LDS byte address, and one
+// buffer_load_dwordx4 ... lds = LDS[m0 + 16 lane] <- buffer[voff + soff] (16 bytes per lane, 1 KB per wave)
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t make_rsrc4(const void* p) {
+  const unsigned long long a = (unsigned long long)p;
+  i32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+  r[2] = 0x7fffffff;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr32(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_dma16(unsigned lds_dst, unsigned voff, i32x4_t rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
@@ -1219,6 +1237,9 @@ __device__ __forceinline__ f32x16 mfma_chain(const uint4 (&a)[NP], const uint4 (
 // fetch of a group's rows then follows the first by one step and is served by L1 / L2 instead of HBM /
 // MALL (round 1's gate kernel read x 2.09 times from the fabric); for any pair, both segments advance
 // by the same scalar offsets and the loop never re-runs the per-segment setup.
+#ifndef X3_ADMA
+#define X3_ADMA 1             // the 256 x 128-tile two-tap loop brings its weights into LDS by LDS-DMA (see ADMA in the kernel)
+#endif
 #ifndef X3_LEAN
 #define X3_LEAN 1             // 256 x 128 tiles, two taps, NP >= 2: the 128-VGPR loop below (two 8-wave workgroups per CU)
 #endif
@@ -1520,12 +1541,26 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     int leftA = nsteps, leftB = nsteps;
     [[maybe_unused]] uint4 la0, la1, la2;
     float pb[CPT], qb[CPT];
-#define LN_FETCH_A(TAP1)                                                                      \
+    // ADMA: the weights -- already in the LDS image's order in their packed slab, a linear copy -- travel global -> LDS by
+    // LDS-DMA (buffer_load_dwordx4 ... lds: one 1 KB run per wave and piece) instead of through 8 VGPRs and two ds_write_b128.
+    // Issued from inline asm (hipcc would otherwise drain vmcnt(0) in front of every ds_read of the image); it is the FIRST
+    // VMEM operation of its half step, so `vmcnt(CPT)` behind the half step's CPT activation loads retires it before the barrier
+    // that publishes the image (the counter is in-order; hipcc's own counted waits, which do not know of it, only wait longer).
+    constexpr bool ADMA = X3_ADMA != 0;
+    [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    [[maybe_unused]] i32x4_t rw4;
+    if constexpr (ADMA) rw4 = make_rsrc4(a.seg[0].w);
+#define LN_FETCH_A(TAP1, BUF)                                                                 \
     {                                                                                         \
       const unsigned so_ = swA + ((TAP1) ? sw1 : 0u);                                         \
+      if constexpr (ADMA) {                                                                   \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                        \
+          lds_dma16(lds_addr32(&As[BUF][p][0][0] + 64 * wave_u), va, rw4, so_ + (unsigned)p * wl2b); \
+      } else {                                                                                \
       la0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
       la1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + wl2b, 0)); \
       if constexpr (NP == 3) la2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_ + 2u * wl2b, 0)); \
+      }                                                                                       \
       if (TAP1) { leftA -= 2; swA += leftA > 0 ? wadvb : 0u; }                                \
     }
 #define LN_FETCH_B(BV, TAP1)                                                                  \
@@ -1536,10 +1571,13 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     }
 #define LN_STAGE(BV, KX, BUF, PRE)                                                            \
     {                                                                                         \
+      if constexpr (!ADMA) {                                                                  \
       uint4* ad = &As[BUF][0][0][0];                                                          \
       ad[tid] = la0; ad[NT + tid] = la1;                                                      \
       if constexpr (NP == 3) ad[2 * NT + tid] = la2;                                          \
+      }                                                                                       \
       stage_b(std::integral_constant<bool, (PRE)>{}, BV, KX, BUF);                            \
+      if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CPT) : "memory");         \
     }
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
@@ -1600,7 +1638,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     };
     if (nsteps > 0) {
       LN_FETCH_B(pb, false);                   // step 0
-      LN_FETCH_A(false);                       // step 0
+      LN_FETCH_A(false, 0);                    // step 0
       LN_FETCH_B(qb, true);                    // step 1
       if constexpr (EPI == EPI_GATE && NBUF == 3) {
         if (fold) stage_cond(std::integral_constant<int, 2>{});     // its loads travel with the first steps'; read after the loop: the loop's barriers order the writes
@@ -1608,12 +1646,12 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       LN_STAGE(pb, kcur, 0, PRE0);
       __syncthreads();
       for (int i = 0; i < nsteps; i += 2) {    // nsteps is even: two taps per channel group
-        LN_FETCH_A(true);                      // weights of step i + 1
+        LN_FETCH_A(true, 1);                   // weights of step i + 1
         LN_FETCH_B(pb, false);                 // activations of step i + 2
         lmma(std::integral_constant<int, 0>{});
         LN_STAGE(qb, k1, 1, PRE1);             // step i + 1
         __syncthreads();
-        LN_FETCH_A(false);                     // weights of step i + 2
+        LN_FETCH_A(false, 0);                  // weights of step i + 2
         LN_FETCH_B(qb, true);                  // activations of step i + 3
         lmma(std::integral_constant<int, 1>{});
         LN_STAGE(pb, kcur, 0, PRE0);           // step i + 2
