@@ -141,8 +141,10 @@ class Adam(object):
         """Makes lr_table[*step] the step size of update number ``self.t + 1`` (what the next replayed step must
         use): a no-op while the device counter is where the host's ``t`` says; otherwise -- first use, the horizon
         reached, eager steps in between -- the table is refilled from ``t`` (one small synchronous upload)."""
+        hyper = (float(self.alpha), float(self.beta1), float(self.beta2))
         if (self._lr_table is not None and self._sched_next == self.t + 1
-                and self.t + 1 - self._sched_base <= self.SCHEDULE_HORIZON):
+                and self.t + 1 - self._sched_base <= self.SCHEDULE_HORIZON
+                and self._sched_hyper == hyper):        # (a changed alpha / beta -- a decay extension, a manual edit -- refills the table: ADVICE r4)
             return
         base, t_save = self.t, self.t
         tbl = np.empty(self.SCHEDULE_HORIZON, np.float32)
@@ -156,6 +158,11 @@ class Adam(object):
         self._lr_table.set(tbl)
         self._step_dev.set(np.zeros(1, np.int32))
         self._sched_base, self._sched_next = base, base + 1
+        self._sched_hyper = hyper
+
+    def capture_key(self):
+        """What a recorded step bakes into its Adam launch as kernel arguments: a change re-records (updaters._step_key)."""
+        return (float(self.beta1), float(self.beta2), float(self.eps))
 
     def replayed(self):
         """Host-side bookkeeping of one replayed (or just captured and launched) step."""

@@ -54,6 +54,12 @@ class GraphedStep(object):
         from . import _lib
         _lib.call('vqvae_graph_launch', self.graph, backend.stream())
 
+    def __del__(self):            # a dropped recording hands its graph and its arena's blocks back
+        try:
+            self.release()
+        except Exception:
+            pass
+
     def release(self):
         from . import _lib
         if self.graph is not None:
@@ -95,7 +101,8 @@ class StandardUpdater(object):
         from . import _lib
         sig = tuple((type(a).__name__, tuple(a.shape), str(a.dtype)) for a in in_arrays)
         return (sig, core.param_epoch('layout'), core.param_epoch('init'), _lib.load().vqvae_get_matmul_dtype(),
-                backend.overlap_enabled(), id(optimizer))
+                backend.overlap_enabled(), id(optimizer),
+                optimizer.capture_key() if hasattr(optimizer, 'capture_key') else None)
 
     def _run_step(self, in_arrays, body):
         """``body(in_arrays)`` = forward + backward (+ exchange) + optimizer.update, eagerly or through the recording."""

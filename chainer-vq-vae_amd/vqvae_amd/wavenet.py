@@ -113,6 +113,9 @@ def _pack_stack(params, d0, nb, stream):
 FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
 DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
 PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
+# 'bfloat16' mode: the chain's tensors the caller may keep in HBM as bf16 (x_l, gh_l, g_res_l: vqvae_resblock_desc.storage) are
+# taken whenever the library offers them; VQVAE_BF16_STORAGE=0 leaves every one fp32 (operand rounding only: ADVICE r4)
+BF16_STORAGE = os.environ.get('VQVAE_BF16_STORAGE', '1') != '0'
 
 
 def _grad_out(var, shape):
@@ -213,7 +216,7 @@ class ResidualStackFunction(FunctionNode):
                 # BASELINE configs[4] (matmul mode 'bfloat16'): the residual stream between the blocks kept as bf16 where
                 # the library offers it (vqvae_resblock_desc.storage; the buffers stay fp32-sized, half used): every
                 # block but the last stores its residual output that way, every block but the first reads it
-                sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(d))
+                sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(d)) if BF16_STORAGE else 0
                 if sup & _lib.STORE_RES_BF16 and sup & _lib.STORE_X_BF16:
                     d.storage = (0 if last else _lib.STORE_RES_BF16) | (_lib.STORE_X_BF16 if i > 0 else 0)
                 # matmul mode 'float32x2': the same stream kept PRE-SPLIT (fp16 hi | lo dwords under an a-priori bound:
@@ -291,14 +294,14 @@ class ResidualStackFunction(FunctionNode):
         # BASELINE configs[4] (matmul mode 'bfloat16'): the tensors of the backward chain the library can keep in HBM as
         # bf16 (vqvae_resblock_desc.storage); the buffers below stay fp32-sized, half used
         store = 0
-        if self.packed is not None and lat is not None:
+        if self.packed is not None and lat is not None and BF16_STORAGE:
             store = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0])) & _lib.STORE_GH_BF16
         if f16 and self.packed is not None and lat is not None:    # matmul mode 'float32x2': gh kept pre-split
             store = _lib.load().vqvae_resblock_f16x2_storage(C.byref(self.descs[0])) & _lib.STORE_GH_F16X2
         hpre = bool(store & _lib.STORE_GH_F16X2)
         stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16 | _lib.STORE_X_F16X2 | _lib.STORE_RES_F16X2       # the forward's choice for the residual stream stays
         gstream = 0                                              # ... and its counterpart, the gradient stream g_res_l = gx_{l+1}
-        if self.packed is not None and lat is not None:
+        if self.packed is not None and lat is not None and BF16_STORAGE:
             sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))
             if sup & _lib.STORE_GX_BF16 and sup & _lib.STORE_GRES_BF16:
                 gstream = _lib.STORE_GX_BF16 | _lib.STORE_GRES_BF16
@@ -325,6 +328,8 @@ class ResidualStackFunction(FunctionNode):
         # 'float32x2': the pull-back of every gh_l to the latent rate runs inside the launch that produces gh_l
         # (vqvae_resblock_amax.pb_part) and one reduce launch finishes all blocks; VQVAE_FUSE_PULLBACK=0: a launch per block
         pb_part = None
+        # (measured in the bf16 mode too: the gate-derivative kernel of that mode loses more than the launch costs -- configs[4]
+        # 18.8 -> 20.4 ms -- so it keeps its pull-back launches)
         if (f16 and lat is not None and self.packed is not None and FUSE_PULLBACK and d0.Cd == 256
                 and d0.T % 128 == 0 and d0.T >= 64 * Tl):
             pb_part = DeviceArray((nb, d0.B, d0.T // 128, d0.Cd, 4), np.float32)
@@ -438,6 +443,7 @@ class ResidualStackFunction(FunctionNode):
                             None, None, self._slot(4 * nb + 1 + i) if hpre else None,
                             (pb_part.ptr + i * (pb_part.nbytes // nb)) if pb_part is not None else None,
                             tb['v0'].ptr, tb['w0'].ptr, tb['w1'].ptr, Tl))
+
                     _lib.call('vqvae_resblock_bwd_packed', C.byref(d), C.byref(prm), h.ptr, gates.ptr,
                               z.ptr, _p(g_res), g_skip.ptr, _p(gx), gh.ptr, ws.ptr, ws.nbytes,
                               self.packed.ptr + i * self.packed_stride, am, _S())
