@@ -50,11 +50,11 @@ ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causa
 ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 3> '
                       '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
                       'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
-                      '+ latent-rate condition lerp + tanh*sigmoid gate)')
+                      '+ the latent-rate condition'"'"'s lerp as one more K step + tanh*sigmoid gate epilogue; weights by LDS-DMA)')
 ROOFLINE_KERNEL_X2 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 2> '
                       '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
                       'every fp32 product = 3 fp16 MFMA products of a scaled hi + lo operand split, fp32 accumulate '
-                      '+ latent-rate condition lerp + tanh*sigmoid gate)')
+                      '+ the latent-rate condition'"'"'s lerp as one more K step + tanh*sigmoid gate epilogue; weights by LDS-DMA)')
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense (bf16 and fp16 run at the same rate)
 # what the whole chip's matrix pipe sustains on the product stream alone with REAL operands (N(0,1) values split into
 # their pieces; registers only, no LDS / memory): tools/ubench/mfma_power.hip (six bf16 products, profiles/r3/

@@ -4725,26 +4725,33 @@ extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_
 // ascending tile order.
 // ---------------------------------------------------------------------------
 namespace vq {
-__global__ __launch_bounds__(256) void pullback_reduce_kernel(const float* __restrict__ part, const int32_t* __restrict__ v0,
-                                                             int nblocks, int B, int nt, int Cd, int Tl, float* __restrict__ gP) {
-  const long total = (long)nblocks * B * Cd * Tl;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % Tl);
-    long rest = i / Tl;
-    const int c = (int)(rest % Cd); rest /= Cd;
-    const int l = (int)(rest % nblocks);
-    const int b = (int)(rest / nblocks);
-    // tiles n with v0[128 n] <= v <= v0[128 n] + 3: v0 is non-decreasing in n; start from the proportional guess
-    int n = (int)(((long)v * nt) / Tl) - 3;
-    n = n < 0 ? 0 : n;
-    float sum = 0.f;
-    for (int k = 0; k < 8 && n < nt; ++k, ++n) {
-      const int vb = v0[n * BN];
-      if (vb > v) break;
-      if (v - vb <= 3) sum += part[((((long)l * B + b) * nt + n) * Cd + c) * 4 + (v - vb)];
-    }
-    gP[((long)b * nblocks * Cd + (long)l * Cd + c) * Tl + v] = sum;
+// one workgroup per (block l, batch item b, 64 gate channels): a thread walks ITS channel's tiles in ascending order (float4
+// per tile: coalesced across the channels) and adds them into its row of an LDS image of the output, which then leaves in
+// whole rows -- deterministic (one owner per channel, fixed order), every byte of `part` read once
+constexpr int PBR_C = 64;
+__global__ __launch_bounds__(PBR_C) void pullback_reduce_kernel(const float* __restrict__ part, const int32_t* __restrict__ v0,
+                                                               int nblocks, int B, int nt, int Cd, int Tl, float* __restrict__ gP) {
+  extern __shared__ float img[];                 // [PBR_C][Tl + 1]
+  const int chunks = Cd / PBR_C;
+  const int cchunk = blockIdx.x % chunks;
+  const int b = (blockIdx.x / chunks) % B;
+  const int l = blockIdx.x / (chunks * B);
+  const int c = cchunk * PBR_C + threadIdx.x;
+  float* row = img + threadIdx.x * (Tl + 1);
+  for (int v = 0; v < Tl; ++v) row[v] = 0.f;
+  const float4* src = reinterpret_cast<const float4*>(part) + (((long)l * B + b) * nt) * Cd + c;
+#pragma unroll 6                                 // (the tiles' loads are independent: six travel together)
+  for (int n = 0; n < nt; ++n) {
+    const int vb = v0[n * BN];                   // wave-uniform
+    const float4 p = src[(long)n * Cd];
+    row[vb] += p.x;
+    if (vb + 1 < Tl) row[vb + 1] += p.y;
+    if (vb + 2 < Tl) row[vb + 2] += p.z;
+    if (vb + 3 < Tl) row[vb + 3] += p.w;
   }
+  __syncthreads();
+  float* dst = gP + ((long)b * nblocks * Cd + (long)l * Cd + cchunk * PBR_C) * Tl;      // PBR_C consecutive rows of Tl: one contiguous run
+  for (int i = threadIdx.x; i < PBR_C * Tl; i += PBR_C) dst[i] = img[(i / Tl) * (Tl + 1) + i % Tl];
 }
 }  // namespace vq
 
@@ -4752,10 +4759,9 @@ extern "C" int vqvae_pullback_reduce(const float* part, const int32_t* v0, int n
                                      float* gP, vqvae_stream_t s) {
   VQ_REQUIRE(part && v0 && gP && nblocks > 0 && B > 0 && Cd > 0 && Tl > 0 && T % vq::BN == 0 && (long)T >= 64L * Tl,
              "pullback_reduce: bad arguments (T %% 128 == 0, T >= 64 Tl)");
-  const long total = (long)nblocks * B * Cd * Tl;
-  int nb = (int)((total + 255) / 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(vq::pullback_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, part, v0, nblocks, B, T / vq::BN, Cd, Tl, gP);
+  VQ_REQUIRE(Cd % vq::PBR_C == 0 && (size_t)vq::PBR_C * (Tl + 1) * 4 <= 64 * 1024, "pullback_reduce: Cd %% 64 == 0, Tl <= 255");
+  const size_t lds = (size_t)vq::PBR_C * (Tl + 1) * sizeof(float);
+  hipLaunchKernelGGL(vq::pullback_reduce_kernel, dim3((unsigned)(nblocks * B * (Cd / vq::PBR_C))), dim3(vq::PBR_C), lds, (hipStream_t)s, part, v0, nblocks, B, T / vq::BN, Cd, Tl, gP);
   VQ_LAUNCH_CHECK();
   return 0;
 }

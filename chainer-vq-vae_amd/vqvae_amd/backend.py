@@ -174,9 +174,27 @@ def defer_to_side(keep):
     _state['side_pending'] = True
 
 
-def join_side():
+class deferred_join(object):
+    """While open, backward sweeps do not join the side stream when they end (core.Variable.backward): the updaters run
+    their two or three sweeps inside one (updaters.three_loss_backward), so that the codebook loss's small sweep also
+    runs beside the deferred weight gradients; closing it joins.  Host reads (DeviceArray.get) join on their own."""
+
+    def __enter__(self):
+        _state['lazy_join'] = _state.get('lazy_join', 0) + 1
+
+    def __exit__(self, *exc):
+        _state['lazy_join'] -= 1
+        if _state['lazy_join'] == 0:
+            join_side()
+        return False
+
+
+def join_side(force=True):
     """The main stream waits for everything deferred to the side stream (no-op when nothing is pending).  Called when a
-    backward sweep ends (core.Variable.backward), before anything reads the gradients."""
+    backward sweep ends (core.Variable.backward; force=False: not inside a deferred_join), before anything reads the
+    gradients."""
+    if not force and _state.get('lazy_join', 0) > 0:
+        return
     if _state.get('side_pending'):
         wait_event(stream(), Event().record(side_stream()))
         _state['side_pending'] = False
@@ -386,6 +404,7 @@ class DeviceArray(object):
         return self
 
     def get(self):
+        join_side()
         out = np.empty(self.shape, dtype=self.dtype)
         _lib.call('vqvae_memcpy_d2h', out.ctypes.data, self.ptr, self.nbytes, stream())
         return out

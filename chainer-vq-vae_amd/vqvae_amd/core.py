@@ -267,7 +267,7 @@ class Variable(object):
                     grads[id(x)] = gx if cur is None else F.raw_add(cur, gx)
                     keep[id(x)] = x
                     push(x.creator)
-        backend.join_side()        # weight gradients a node deferred to the side stream (wavenet.ResidualStackFunction)
+        backend.join_side(force=False)        # weight gradients a node deferred to the side stream (wavenet.ResidualStackFunction)
 
     def _accumulate_grad(self, gx):
         from . import functions as F

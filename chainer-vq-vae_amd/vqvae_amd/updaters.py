@@ -215,15 +215,16 @@ def three_loss_backward(model, losses, merged=None):
     codebook, then add the codebook loss (-> vq.W only) and the commitment loss (-> encoder)."""
     loss1, loss2, loss3 = losses
     model.cleargrads()
-    with _codebook_share_discarded(model):
-        if _merged_sweep(losses, merged):
-            (loss1 + loss3).backward()  # decoder, condition embed, encoder (g1 + g3 at z)
-        else:
-            loss1.backward()
-    model.vq.cleargrads()
-    loss2.backward()
-    if not _merged_sweep(losses, merged):
-        loss3.backward()
+    with backend.deferred_join():       # (weight gradients deferred to the side stream are joined once, behind the last sweep)
+        with _codebook_share_discarded(model):
+            if _merged_sweep(losses, merged):
+                (loss1 + loss3).backward()  # decoder, condition embed, encoder (g1 + g3 at z)
+            else:
+                loss1.backward()
+        model.vq.cleargrads()
+        loss2.backward()
+        if not _merged_sweep(losses, merged):
+            loss3.backward()
 
 
 class VQVAE_StandardUpdater(StandardUpdater):

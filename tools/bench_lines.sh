@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's bench lines, taken AFTER tools/restamp.sh stamped profiles/roofline_traffic.json on the final sources
 # (so that `roofline.traffic` is non-null): default (configs[1]), c4, c5 --bf16 -> gpurun_out/lines_<tag>/
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd $GRAFT_REPO_ROOT; OUT=gpurun_out/lines_$TAG; mkdir -p $OUT
 python bench.py --steps 20 --warmup 5 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/c2_eager_bench_line.json

@@ -3,7 +3,7 @@
 #   kernel-trace stats of bench.py for c2 (default), c4, c5 --bf16, and separate --pmc passes
 #   (FETCH_SIZE / WRITE_SIZE / MFMA busy / instruction mix) for the dominant kernel of each.
 # usage: bash tools/profile_round.sh <tag>
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
