@@ -47,6 +47,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chi
 # residual 1x1 conv is a separate launch the extra term is 0.
 ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
                    '+ latent-rate condition lerp + tanh*sigmoid gate)')
+ROOFLINE_KERNEL_BF16 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 1> '
+                        '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM on bf16-rounded operands, fp32 accumulate '
+                        '+ latent-rate condition lerp + tanh*sigmoid gate epilogue; x, z, gates stored as bf16)')
 ROOFLINE_KERNEL_X3 = ('conv_gemm_x3_kernel<EPI_GATE, 256 x 128 tiles, two 8-wave workgroups per CU, NP = 3> '
                       '(ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM, '
                       'every fp32 product = 6 bf16 MFMA products of an exact 3-way operand split, fp32 accumulate '
@@ -714,7 +717,7 @@ def main():
                        'parallelism': 'dp%d (one process/GPU, RCCL all-reduce of the flat grad arena)' % n},
             'trainable_params': int(n_params),
             'losses_last_step': losses,
-            'roofline': {'bound': 'mfma', 'kernel': {'float32x3': ROOFLINE_KERNEL_X3, 'float32x2': ROOFLINE_KERNEL_X2}.get(mode, ROOFLINE_KERNEL),
+            'roofline': {'bound': 'mfma', 'kernel': {'float32x3': ROOFLINE_KERNEL_X3, 'float32x2': ROOFLINE_KERNEL_X2, 'bfloat16': ROOFLINE_KERNEL_BF16}.get(mode, ROOFLINE_KERNEL),
                          'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                          'peak_is': ('dense bf16 MFMA peak' if args.bf16 else
                                      ('dense 16-bit MFMA peak (2500) / %d MFMA products per fp32 product; achieved counts '
