@@ -89,6 +89,7 @@ PROTOTYPES = {
     'vqvae_memcpy2d_d2d': (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     'vqvae_memset': (c_int, [P, c_int, c_size_t, P]),
     'vqvae_stream_create': (c_int, [C.POINTER(c_void_p)]),
+    'vqvae_stream_create_priority': (c_int, [C.POINTER(c_void_p), c_int]),
     'vqvae_stream_destroy': (c_int, [P]),
     'vqvae_stream_synchronize': (c_int, [P]),
     'vqvae_device_synchronize': (c_int, []),
@@ -221,6 +222,9 @@ class HipError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 4        # include/vqvae_hip.h: vqvae_abi_version()
+
+
 def load():
     """Loads libvqvae_hip.so (once).  Raises loudly when it has not been built."""
     global _lib
@@ -239,6 +243,9 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.vqvae_abi_version() != ABI_VERSION:    # the ctypes structs below mirror ONE layout of include/vqvae_hip.h
+        raise ImportError('libvqvae_hip.so at %s has ABI %d, this package binds ABI %d: rebuild it (__graft_entry__.build())'
+                          % (LIB_PATH, lib.vqvae_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
