@@ -157,19 +157,6 @@ int vqvae_stream_create(vqvae_stream_t* s) {
   *s = (vqvae_stream_t)st;
   return 0;
 }
-// level < 0: the lowest priority the device offers, > 0: the highest, 0: the default.  The command processor serves
-// a higher-priority queue's workgroups first whenever both have some pending: a side stream of big launches then only takes
-// the slots the main stream's kernels leave (tails, gaps, latency-bound launches) instead of half of them.
-int vqvae_stream_create_priority(vqvae_stream_t* s, int level) {
-  VQ_REQUIRE(s, "vqvae_stream_create_priority: null");
-  int least = 0, greatest = 0;
-  VQ_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));      // numerically: least >= greatest
-  const int prio = level < 0 ? least : (level > 0 ? greatest : (least + greatest) / 2);
-  hipStream_t st;
-  VQ_CHECK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
-  *s = (vqvae_stream_t)st;
-  return 0;
-}
 int vqvae_stream_destroy(vqvae_stream_t s) { VQ_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return 0; }
 int vqvae_stream_synchronize(vqvae_stream_t s) { VQ_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int vqvae_device_synchronize(void) { VQ_CHECK_HIP(hipDeviceSynchronize()); return 0; }

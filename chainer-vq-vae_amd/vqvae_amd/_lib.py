@@ -89,7 +89,6 @@ PROTOTYPES = {
     'vqvae_memcpy2d_d2d': (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     'vqvae_memset': (c_int, [P, c_int, c_size_t, P]),
     'vqvae_stream_create': (c_int, [C.POINTER(c_void_p)]),
-    'vqvae_stream_create_priority': (c_int, [C.POINTER(c_void_p), c_int]),
     'vqvae_stream_destroy': (c_int, [P]),
     'vqvae_stream_synchronize': (c_int, [P]),
     'vqvae_device_synchronize': (c_int, []),

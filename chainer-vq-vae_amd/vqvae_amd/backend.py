@@ -13,10 +13,6 @@ import numpy as np
 
 from . import _lib
 
-# queue priorities of the two streams (vqvae_stream_create_priority: < 0 lowest, 0 default, > 0 highest): the side stream's
-# big launches (deferred weight gradients, pre-pack) should only take what the main stream's chain leaves
-MAIN_PRIO = int(os.environ.get('VQVAE_MAIN_PRIO', '0'))
-SIDE_PRIO = int(os.environ.get('VQVAE_SIDE_PRIO', '0'))
 _state = {'stream': None, 'side': None, 'device': None, 'pool': {}, 'live_bytes': 0,
           'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': os.environ.get('VQVAE_OVERLAP', '0') == '1'}
 
@@ -36,7 +32,7 @@ def init(device=0):
             % lib.vqvae_last_error_string().decode())
     _lib.call('vqvae_set_device', device)
     s = C.c_void_p()
-    _lib.call('vqvae_stream_create_priority', C.byref(s), MAIN_PRIO)
+    _lib.call('vqvae_stream_create', C.byref(s))
     _state['stream'] = s
     _state['device'] = device
     if not _state.get('matmul_explicit'):          # a mode chosen before init() stays
@@ -66,7 +62,7 @@ def side_stream():
     if _state['side'] is None:
         stream()
         s = C.c_void_p()
-        _lib.call('vqvae_stream_create_priority', C.byref(s), SIDE_PRIO)
+        _lib.call('vqvae_stream_create', C.byref(s))
         _state['side'] = s
     return _state['side']
 

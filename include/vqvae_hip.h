@@ -61,8 +61,6 @@ int vqvae_memcpy2d_d2d(void* dst, size_t dpitch, const void* src, size_t spitch,
                        size_t height, vqvae_stream_t s);
 int vqvae_memset(void* p, int byte_value, size_t bytes, vqvae_stream_t s);
 int vqvae_stream_create(vqvae_stream_t* s);
-/* level < 0: lowest device priority, > 0: highest, 0: default (hipStreamCreateWithPriority) */
-int vqvae_stream_create_priority(vqvae_stream_t* s, int level);
 int vqvae_stream_destroy(vqvae_stream_t s);
 int vqvae_stream_synchronize(vqvae_stream_t s);
 int vqvae_device_synchronize(void);
