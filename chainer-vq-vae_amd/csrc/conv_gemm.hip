@@ -3716,6 +3716,42 @@ static unsigned* conv_amax_slots(const vqvae_conv1d_desc* d, void* ws) {
   return reinterpret_cast<unsigned*>((char*)ws + vqvae_conv1d_workspace_bytes(d) - 2 * AMAX_SLOTS * sizeof(unsigned));
 }
 
+// ---- weights packed AHEAD of the launch that reads them (vqvae_conv1d_amax::packed).  The forward / backward-data entry
+// points re-lay W into their workspace in front of every GEMM: one or two small launches (wamax_kernel, pack_kernel) that a
+// latency-bound chain of small convs -- the encoder, the condition embed, their backward -- pays once per conv on its
+// critical path.  The weights only change in the optimizer, so a caller may pack all of a step's slabs at once, on
+// another stream, as soon as the optimizer is done (vqvae_amd/backend.py: PackPrefetch), and hand each launch its slab.
+// A packed buffer = the slab, then (256-byte aligned) the AMAX_SLOTS words of max |W| that a float32x2 launch reads.
+static size_t conv_slab_bytes(const vqvae_conv1d_desc* d, int backward) {
+  const size_t f = backward ? (size_t)d->K * slab_rows(d->Cout) * pad128(d->Cin) : (size_t)d->K * slab_rows(d->Cin) * pad128(d->Cout);
+  return align_up(f * sizeof(float), 256);
+}
+extern "C" size_t vqvae_conv1d_packed_bytes(const vqvae_conv1d_desc* d, int backward) {
+  if (!d || d->K < 1 || d->K > MAXTAPS) return 0;
+  return conv_slab_bytes(d, backward) + 256;
+}
+extern "C" int vqvae_conv1d_pack(int n, const vqvae_conv1d_desc* descs, const float* const* W, const int* backward,
+                                 void* const* packed, vqvae_stream_t s) {
+  VQ_REQUIRE(n >= 0 && (n == 0 || (descs && W && backward && packed)), "conv1d_pack: null pointer");
+  hipStream_t st = (hipStream_t)s;
+  for (int fmt3 = 0; fmt3 < 2; ++fmt3) {           // one run of launches per slab format (float32x2 launches: format 3 + the maxima)
+    PackArgs pa; pa.njob = 0;
+    for (int i = 0; i < n; ++i) {
+      const vqvae_conv1d_desc* d = descs + i;
+      if (int e = check_conv_desc(d)) return e;
+      VQ_REQUIRE(W[i] && packed[i], "conv1d_pack: null pointer in job %d", i);
+      if ((conv_f16x2(d) ? 1 : 0) != fmt3) continue;
+      PackJob j = backward[i] ? pack_bwd_job((float*)packed[i], W[i], d->Cout, d->Cin, d->K, pad128(d->Cin))
+                              : pack_fwd_job((float*)packed[i], W[i], d->Cout, d->Cin, d->K, 0, pad128(d->Cout), 0, pad128(d->Cout));
+      j.amax = fmt3 ? reinterpret_cast<unsigned*>((char*)packed[i] + conv_slab_bytes(d, backward[i])) : nullptr;
+      pa.job[pa.njob++] = j;
+      if (pa.njob == MAXSEG) { if (int e = launch_pack(pa, st, fmt3 ? 3 : -1)) return e; pa.njob = 0; }
+    }
+    if (int e = launch_pack(pa, st, fmt3 ? 3 : -1)) return e;
+  }
+  return 0;
+}
+
 static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const float* W, const float* b, float* y,
                            void* ws, size_t ws_bytes, const int32_t* skip_flag, const vqvae_conv1d_amax* cam,
                            vqvae_stream_t s);
@@ -3744,19 +3780,24 @@ static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const flo
   hipStream_t st = (hipStream_t)s;
   const int ldw = pad128(d->Cout), rp = slab_rows(d->Cin);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
-  float* pk = (float*)ws;
+  const void* pre = (cam && skip_flag == nullptr) ? cam->packed : nullptr;      // packed ahead (vqvae_conv1d_pack)
+  float* pk = pre ? (float*)pre : (float*)ws;
   const bool f16 = conv_f16x2(d) && skip_flag == nullptr && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
+  VQ_REQUIRE(!pre || f16 == conv_f16x2(d), "conv1d_fwd: workspace too small for the launch the packed slab was written for");
   unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
+  unsigned* wam = !f16 ? nullptr : (pre ? reinterpret_cast<unsigned*>((char*)pre + conv_slab_bytes(d, 0)) : am + AMAX_SLOTS);
   const unsigned* xam = am;          // the operand's maximum: the caller's (it travelled with the tensor) or a scan
   if (f16 && cam && cam->x) xam = cam->x;
   else if (f16) {
     VQ_CHECK_HIP(hipMemsetAsync(am, 0, AMAX_SLOTS * sizeof(unsigned), st));
     if (int e = launch_absmax(x, (long)d->B * d->Cin * d->Tin, am, st)) return e;
   }
-  PackArgs pa; pa.njob = 1;
-  pa.job[0] = pack_fwd_job(pk, W, d->Cout, d->Cin, d->K, 0, ldw, 0, ldw);
-  pa.job[0].amax = f16 ? am + AMAX_SLOTS : nullptr;
-  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
+  if (!pre) {
+    PackArgs pa; pa.njob = 1;
+    pa.job[0] = pack_fwd_job(pk, W, d->Cout, d->Cin, d->K, 0, ldw, 0, ldw);
+    pa.job[0].amax = wam;
+    if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
+  }
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.nseg = d->K;
   g.f16x2 = f16 ? 1 : 0;
@@ -3765,7 +3806,7 @@ static int conv1d_fwd_impl(const vqvae_conv1d_desc* d, const float* x, const flo
     sg.x = x; sg.x_bstride = (long)d->Cin * d->Tin; sg.x_cstride = d->Tin; sg.cin = d->Cin; sg.Tin = d->Tin;
     sg.tmul = d->stride; sg.toff = j * d->dil - d->pad; sg.tdiv = 1;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
-    if (f16) { sg.amax = xam; sg.wamax = am + AMAX_SLOTS; }
+    if (f16) { sg.amax = xam; sg.wamax = wam; }
   }
   g.M = d->Cout; g.Tout = d->Tout; g.B = d->B;
   g.out[0].y = y; g.out[0].y_bstride = (long)d->Cout * d->Tout; g.out[0].rows = d->Cout;
@@ -3805,19 +3846,24 @@ static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, cons
   hipStream_t st = (hipStream_t)s;
   const int ldw = pad128(d->Cin), rp = slab_rows(d->Cout);
   if ((size_t)d->K * rp * ldw * sizeof(float) > ws_bytes) { set_error("conv1d_bwd_data: workspace too small"); return VQVAE_E_WORKSPACE; }
-  float* pk = (float*)ws;
+  const void* pre = cam ? cam->packed : nullptr;      // packed ahead (vqvae_conv1d_pack, backward form)
+  float* pk = pre ? (float*)pre : (float*)ws;
   const bool f16 = conv_f16x2(d) && ws_bytes >= vqvae_conv1d_workspace_bytes(d);
+  VQ_REQUIRE(!pre || f16 == conv_f16x2(d), "conv1d_bwd_data: workspace too small for the launch the packed slab was written for");
   unsigned* am = f16 ? conv_amax_slots(d, ws) : nullptr;
+  unsigned* wam = !f16 ? nullptr : (pre ? reinterpret_cast<unsigned*>((char*)pre + conv_slab_bytes(d, 1)) : am + AMAX_SLOTS);
   const unsigned* gam = am;
   if (f16 && cam && cam->gy) gam = cam->gy;
   else if (f16) {
     VQ_CHECK_HIP(hipMemsetAsync(am, 0, AMAX_SLOTS * sizeof(unsigned), st));
     if (int e = launch_absmax(gy, (long)d->B * d->Cout * d->Tout, am, st)) return e;
   }
-  PackArgs pa; pa.njob = 1;
-  pa.job[0] = pack_bwd_job(pk, W, d->Cout, d->Cin, d->K, ldw);
-  pa.job[0].amax = f16 ? am + AMAX_SLOTS : nullptr;
-  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
+  if (!pre) {
+    PackArgs pa; pa.njob = 1;
+    pa.job[0] = pack_bwd_job(pk, W, d->Cout, d->Cin, d->K, ldw);
+    pa.job[0].amax = wam;
+    if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
+  }
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.nseg = d->K;
   g.f16x2 = f16 ? 1 : 0;
@@ -3827,7 +3873,7 @@ static int conv1d_bwd_data_impl(const vqvae_conv1d_desc* d, const float* W, cons
     // t_out(gy) = (u + pad - j*dil) / stride
     sg.tmul = 1; sg.toff = d->pad - j * d->dil; sg.tdiv = d->stride;
     sg.w = pk + (size_t)j * rp * ldw; sg.ldw = ldw;
-    if (f16) { sg.amax = gam; sg.wamax = am + AMAX_SLOTS; }
+    if (f16) { sg.amax = gam; sg.wamax = wam; }
   }
   g.M = d->Cin; g.Tout = d->Tin; g.B = d->B;
   g.out[0].y = gx; g.out[0].y_bstride = (long)d->Cin * d->Tin; g.out[0].rows = d->Cin;

@@ -74,7 +74,7 @@ using namespace vq;
 extern "C" {
 
 const char* vqvae_last_error_string(void) { return g_err; }
-int vqvae_abi_version(void) { return 4; }
+int vqvae_abi_version(void) { return 5; }
 
 int vqvae_device_count(int* n) {
   VQ_REQUIRE(n, "vqvae_device_count: null");

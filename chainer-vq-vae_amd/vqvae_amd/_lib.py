@@ -45,7 +45,7 @@ class ResblockAmax(C.Structure):
 
 class Conv1dAmax(C.Structure):
     """vqvae_conv1d_amax"""
-    _fields_ = [(n, P) for n in ('x', 'gy', 'out')]
+    _fields_ = [(n, P) for n in ('x', 'gy', 'out', 'packed')]
 
 
 class ResblockGrads(C.Structure):
@@ -111,6 +111,8 @@ PROTOTYPES = {
     'vqvae_conv1d_bwd_data': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, P]),
     'vqvae_conv1d_bwd_weight': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P]),
     'vqvae_conv1d_uses_f32x2': (c_int, [C.POINTER(Conv1dDesc)]),
+    'vqvae_conv1d_packed_bytes': (c_size_t, [C.POINTER(Conv1dDesc), c_int]),
+    'vqvae_conv1d_pack': (c_int, [c_int, C.POINTER(Conv1dDesc), C.POINTER(c_void_p), C.POINTER(c_int), C.POINTER(c_void_p), P]),
     'vqvae_conv1d_fwd_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, C.POINTER(Conv1dAmax), P]),
     'vqvae_conv1d_bwd_data_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, c_int, P, c_size_t, C.POINTER(Conv1dAmax), P]),
     'vqvae_conv1d_bwd_weight_amax': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t,
@@ -221,7 +223,7 @@ class HipError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 4        # include/vqvae_hip.h: vqvae_abi_version()
+ABI_VERSION = 5        # include/vqvae_hip.h: vqvae_abi_version()
 
 
 def load():

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from . import _lib, backend
+from . import _lib, backend, prepack
 from .backend import DeviceArray
 from .core import FunctionNode, Variable, as_variable, type_expect
 
@@ -248,11 +248,15 @@ class Conv1dFunction(FunctionNode):
         # 'float32x2', a launch large enough for the three-product kernels: the operand's maximum travels with it (or
         # is found once and remembered on it for the backward), the result's is published by the epilogue
         self._f32x2 = bool(_lib.load().vqvae_conv1d_uses_f32x2(C.byref(self.desc)))
+        pre = prepack.lookup(self.inputs[1], W, self.desc, 0)      # the weight slab, if this step packed it ahead
         if self._f32x2:
             y.amax = backend.new_amax()
-            am = _lib.Conv1dAmax(backend.absmax(x).ptr, None, y.amax.ptr)
+            am = _lib.Conv1dAmax(backend.absmax(x).ptr, None, y.amax.ptr, pre)
             _lib.call('vqvae_conv1d_fwd_amax', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
                       ws.nbytes, C.byref(am), _S())
+        elif pre is not None:
+            _lib.call('vqvae_conv1d_fwd_amax', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
+                      ws.nbytes, C.byref(_lib.Conv1dAmax(None, None, None, pre)), _S())
         else:
             _lib.call('vqvae_conv1d_fwd', C.byref(self.desc), x.ptr, W.ptr, _p(b), y.ptr, ws.ptr,
                       ws.nbytes, _S())
@@ -277,15 +281,18 @@ class Conv1dFunction(FunctionNode):
         if 0 in indexes:
             gx = DeviceArray(self._x_shape, np.float32)
             am = None
+            pre = prepack.lookup(self.inputs[1], W, self.desc, 1)
             if f32x2:
                 gx.amax = backend.new_amax()
-                am = _lib.Conv1dAmax(None, backend.absmax(gy).ptr, gx.amax.ptr)
+                am = _lib.Conv1dAmax(None, backend.absmax(gy).ptr, gx.amax.ptr, pre)
+            elif pre is not None:
+                am = _lib.Conv1dAmax(None, None, None, pre)
             if getattr(x, 'relu_out', False) and FUSE_RELU_BWD:
                 # x is the output of a ReLU: that ReLU's backward, gx * (x > 0), in this launch's epilogue
                 _lib.call('vqvae_conv1d_bwd_data_relu', C.byref(self.desc), W.ptr, gy.ptr, x.ptr, gx.ptr,
                           ws.ptr, ws.nbytes, C.byref(am) if am is not None else None, _S())
                 gx.relu_masked = True
-            elif f32x2:
+            elif am is not None:
                 _lib.call('vqvae_conv1d_bwd_data_amax', C.byref(self.desc), W.ptr, gy.ptr, gx.ptr, 0,
                           ws.ptr, ws.nbytes, C.byref(am), _S())
             else:

@@ -6,7 +6,7 @@ ConditionEmbed net.py:29-64, VAE net.py:67-96); the bodies are written for this
 runtime: activations fused into conv epilogues, the condition tensor kept at the
 latent rate until the decoder consumes it, one nearest-code search per step.
 """
-from . import backend, core, functions as F, links as L
+from . import backend, core, functions as F, links as L, prepack
 from .core import Chain, Variable
 from .utils import VQ
 
@@ -76,6 +76,11 @@ class VAE(Chain):
             self.decoder = decoder
 
     def __call__(self, x_enc, x_dec, global_condition, t):
+        # the weight slabs of the step's small convs (encoder, condition embed, proj1 / proj2; both directions), as the
+        # previous step used them: packed on the side stream now, in a few batched launches, instead of one pack in front
+        # of every conv on the critical path (prepack.py)
+        if isinstance(x_dec, backend.DeviceArray):
+            prepack.prefetch()
         # the decoder's weight slabs are packed on the side stream while the encoder / quantiser / condition embed run
         dec = self.decoder
         dec = getattr(dec, 'target' if core.config.train else 'ema', dec)
@@ -99,4 +104,5 @@ class VAE(Chain):
         loss3 = self.beta * F.mean((z - Variable(e.data)) ** 2)
         core.report({'loss1': loss1, 'loss2': loss2, 'loss3': loss3,
                      'loss': loss1 + loss2 + loss3}, self)
+        prepack.join()
         return loss1, loss2, loss3

@@ -38,7 +38,7 @@ extern "C" {
 typedef void* vqvae_stream_t;
 
 const char* vqvae_last_error_string(void);
-int vqvae_abi_version(void);      /* 4 since vqvae_resblock_amax grew x_max / res_scale / gh_scale (3: vqvae_resblock_desc grew `storage`; bindings must zero what they do not set) */
+int vqvae_abi_version(void);      /* 5 since vqvae_conv1d_amax grew `packed`; 4: vqvae_resblock_amax grew x_max / res_scale / gh_scale (3: vqvae_resblock_desc grew `storage`; bindings must zero what they do not set) */
 
 /* ---- device / memory / stream plumbing (replaces CuPy's allocator + streams,
  *      reached in the reference through model.to_gpu()/converter, updaters.py:8) */
@@ -157,7 +157,19 @@ typedef struct {
   const uint32_t* x;     /* fwd, bwd_weight: max |x|   */
   const uint32_t* gy;    /* bwd_data, bwd_weight: max |gy| */
   uint32_t* out;         /* fwd: max |y|; bwd_data: max |gx| */
+  const void* packed;    /* fwd, bwd_data (any matmul mode; NULL: the launch re-lays W into its workspace itself): W already
+                          * re-laid by vqvae_conv1d_pack for THIS desc and direction under the current matmul mode and
+                          * f32x2 threshold -- see below                                                              */
 } vqvae_conv1d_amax;
+/* Weights packed ahead of the launches that read them.  vqvae_conv1d_fwd / _bwd_data re-lay W into their workspace in front
+ * of every GEMM (one or two small launches); the weights only change in the optimizer, so a caller may pack all of a
+ * step's slabs at once -- on another stream, as soon as the optimizer is done -- and hand each launch its slab through
+ * vqvae_conv1d_amax::packed (ordering between the streams is the caller's: an event).  packed[i]: device buffer of
+ * vqvae_conv1d_packed_bytes(&descs[i], backward[i]) bytes; backward[i] = 0: the slab vqvae_conv1d_fwd* reads, 1: the one
+ * vqvae_conv1d_bwd_data* reads.  Jobs share launches (<= 24 per launch).                                             */
+size_t vqvae_conv1d_packed_bytes(const vqvae_conv1d_desc* d, int backward);
+int vqvae_conv1d_pack(int n, const vqvae_conv1d_desc* descs, const float* const* W, const int* backward,
+                      void* const* packed, vqvae_stream_t s);
 int vqvae_conv1d_uses_f32x2(const vqvae_conv1d_desc* d);
 int vqvae_conv1d_fwd_amax(const vqvae_conv1d_desc* d, const float* x, const float* W,
                           const float* b, float* y, void* ws, size_t ws_bytes,

@@ -1155,3 +1155,53 @@ def test_bf16_gradient_stream_changes_only_the_rounding_point(gpu, bf16_mode):
     np.testing.assert_array_equal(gxC, gxA)
     np.testing.assert_array_equal(_dec(ghE), _dec(ghD))
     np.testing.assert_array_equal(decode(gxE), O.bf16_round(gxD))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['float32x2', 'float32x3', 'float32', 'bfloat16'])
+def test_conv1d_pack_ahead_equals_inline_pack(gpu, mode):
+    """vqvae_conv1d_pack + vqvae_conv1d_amax::packed: forward and backward-data of a strided, a dilated and a 1x1 conv read
+    slabs that were packed ahead (three jobs per direction in ONE call) and give the bits of the launches that pack into
+    their workspace themselves -- in every matmul mode, in 'float32x2' both below and above the three-product threshold."""
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(77)
+    shapes = [(2, 24, 200, 40, 4, 2, 1, 1), (2, 64, 160, 64, 2, 1, 3, 3), (3, 96, 128, 130, 1, 1, 0, 1)]   # B Cin Tin Cout K stride pad dil
+    gpu.set_matmul_dtype(mode)
+    try:
+        for thr in ([8.0, 0.0] if mode == 'float32x2' else [8.0]):
+            gpu.set_f32x2_min_gflop(thr)
+            descs, xs, Ws, gys = [], [], [], []
+            for (B, Cin, Tin, Cout, K, st, pad, dil) in shapes:
+                Tout = (Tin + 2 * pad - dil * (K - 1) - 1) // st + 1
+                descs.append(_lib.Conv1dDesc(B, Cin, Tin, Cout, Tout, K, st, pad, dil, 0))
+                xs.append(_dev(gpu, rs.standard_normal((B, Cin, Tin)).astype(np.float32)))
+                Ws.append(_dev(gpu, (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)))
+                gys.append(_dev(gpu, rs.standard_normal((B, Cout, Tout)).astype(np.float32)))
+            n = len(shapes)
+            darr = (_lib.Conv1dDesc * (2 * n))()
+            for i in range(2 * n):
+                C.pointer(darr[i])[0] = descs[i % n]
+            bw = (C.c_int * (2 * n))(*([0] * n + [1] * n))
+            bufs = [gpu.DeviceArray((int(lib.vqvae_conv1d_packed_bytes(C.byref(descs[i % n]), bw[i])) // 4,), np.float32) for i in range(2 * n)]
+            _lib.call('vqvae_conv1d_pack', 2 * n, darr, (C.c_void_p * (2 * n))(*[Ws[i % n].ptr for i in range(2 * n)]), bw,
+                      (C.c_void_p * (2 * n))(*[b.ptr for b in bufs]), gpu.stream())
+            for i, d in enumerate(descs):
+                ws = gpu.workspace(lib.vqvae_conv1d_workspace_bytes(C.byref(d)))
+                out = []
+                for pre in (None, bufs[i].ptr):
+                    y = gpu.DeviceArray((d.B, d.Cout, d.Tout), np.float32)
+                    _lib.call('vqvae_conv1d_fwd_amax', C.byref(d), xs[i].ptr, Ws[i].ptr, None, y.ptr, ws.ptr, ws.nbytes,
+                              C.byref(_lib.Conv1dAmax(None, None, None, pre)), gpu.stream())
+                    out.append(y.get())
+                assert np.array_equal(out[0], out[1]), (mode, thr, 'fwd', shapes[i])
+                out = []
+                for pre in (None, bufs[n + i].ptr):
+                    gx = gpu.DeviceArray((d.B, d.Cin, d.Tin), np.float32)
+                    _lib.call('vqvae_conv1d_bwd_data_amax', C.byref(d), Ws[i].ptr, gys[i].ptr, gx.ptr, 0, ws.ptr, ws.nbytes,
+                              C.byref(_lib.Conv1dAmax(None, None, None, pre)), gpu.stream())
+                    out.append(gx.get())
+                assert np.array_equal(out[0], out[1]), (mode, thr, 'bwd', shapes[i])
+    finally:
+        gpu.set_f32x2_min_gflop(8.0)
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())

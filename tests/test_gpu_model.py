@@ -535,3 +535,64 @@ def test_one_sweep_for_loss1_and_loss3_gives_the_three_sweep_gradients(gpu):
     for name, arr in G.items():
         got = ga[H._dev_name(name, False)].reshape(arr.shape)
         assert np.abs(got - arr).max() <= 1e-5 * max(np.abs(arr).max(), 1e-30) + 1e-9, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('min_gflop', [8.0, 0.0])
+def test_prepacked_conv_slabs_give_the_same_step_bitwise(gpu, min_gflop):
+    """prepack.py: from the second step on, VAE.__call__ packs the weight slabs of the step's generic convs (encoder,
+    condition embed, proj1 / proj2; forward and backward-data forms) on the side stream in a few batched launches
+    (vqvae_conv1d_pack) and every conv finds its slab ready (vqvae_conv1d_amax::packed).  The same pack kernels write the
+    same slabs, so losses, parameters and Adam moments are bit-identical to the step that packs in line -- eager and
+    recorded, with every conv on the three-product kernels (threshold 0: format-3 slabs + their maxima) and at the
+    default threshold -- and the slabs really are used (every lookup of steps 2.. hits)."""
+    import vqvae_amd as V
+    from vqvae_amd import backend, prepack
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL)
+    batches = [O.synth_batch(3, length=512, n_speaker=cfg['n_speaker'], seed=900 + s) for s in range(4)]
+    backend.set_f32x2_min_gflop(min_gflop)
+    enabled = prepack.ENABLED
+    try:
+        def run(on, graph):
+            prepack.reset()
+            prepack.ENABLED = on
+            _, model = H.build_model(cfg, seed=9)
+            model.to_gpu()
+            opt = Adam(2e-4)
+            opt.setup(model)
+
+            class It(object):
+                i = 0
+
+                def next(self):
+                    It.i += 1
+                    x_enc, x_dec, spk, t = batches[It.i - 1]
+                    return [(x_enc[i][..., None], x_dec[i][..., None], spk[i], t[i][..., None]) for i in range(3)]
+            upd = V.VQVAE_StandardUpdater(It(), opt, device=0, graph=graph)
+            losses, hits = [], []
+            for _ in batches:
+                upd.update()
+                losses.append([l.data.get().copy() for l in upd.last_losses])
+                hits.append((prepack.stats['hits'], prepack.stats['misses'], len(prepack._ready), len(prepack._used)))
+                prepack.stats['hits'] = prepack.stats['misses'] = 0
+            return losses, opt.params.get(), opt.m.get(), opt.v.get(), hits
+        ref = run(False, False)
+        assert all(h == (0, 0, 0, 0) for h in ref[4])
+        for graph in (False, True):
+            got = run(True, graph)
+            for la, lb in zip(ref[0], got[0]):
+                for a, b in zip(la, lb):
+                    assert np.array_equal(a, b), (graph, ref[0], got[0])
+            for a, b in zip(ref[1:4], got[1:4]):
+                assert np.array_equal(a, b), 'graph=%s' % graph
+            if not graph:
+                # step 1 records its convs and packs in line; steps 2.. find every slab they look up
+                n = got[4][0][3]
+                assert got[4][0] == (0, n, 0, n) and n > 10, got[4]
+                for h in got[4][1:]:
+                    assert h == (n, 0, n, n), got[4]
+    finally:
+        prepack.ENABLED = enabled
+        prepack.reset()
+        backend.set_f32x2_min_gflop(8.0)

@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
         assert s in _lib.PROTOTYPES, 'no ctypes prototype for ' + s
     for s in _lib.PROTOTYPES:
         assert s in syms, 'prototype %s is not declared in include/vqvae_hip.h' % s
-    assert lib.vqvae_abi_version() == 4 == _lib.ABI_VERSION
+    assert lib.vqvae_abi_version() == 5 == _lib.ABI_VERSION
 
 
 def test_graft_entry_library_check():
