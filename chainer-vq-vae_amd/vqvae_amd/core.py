@@ -275,6 +275,8 @@ class Variable(object):
             self.grad = gx
         else:
             masked = getattr(self.grad, 'relu_masked', False) and getattr(gx, 'relu_masked', False)
+            if isinstance(self, Parameter):
+                backend.join_side()      # (a parameter's contributions may come from launches deferred to the side stream)
             self.grad = F.raw_add(self.grad, gx)
             self.grad.relu_masked = masked       # a sum of masked gradients is the masked sum
 
@@ -320,6 +322,7 @@ class Parameter(Variable):
                 self.grad = self._grad_slot
                 return
             gx = gx.reshape(self._grad_slot.shape)
+            backend.join_side()      # (gx, or an earlier contribution to the slot, may come from a launch deferred to the side stream)
             if self.grad is None:
                 self._grad_slot.copy_from(gx)
             else:

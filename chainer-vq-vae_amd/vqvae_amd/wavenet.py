@@ -351,6 +351,8 @@ class ResidualStackFunction(FunctionNode):
         # each, 0.7 ms during which the chip is all but idle).  They go to the side stream and run BESIDE that tail;
         # Variable.backward() joins the streams when the sweep is done (backend.join_side).  VQVAE_DEFER_WGRAD=0: in line.
         defer = DEFER_WGRAD and not overlap and lat is not None and self.packed is not None
+        if defer:          # (sized for everything this sweep sends to the side stream before the first of it is enqueued)
+            need = max(need, _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
         ws_defer = backend.workspace(need, 'side') if defer else None
         dil_pending = []          # blocks whose gh exists but whose dilated-conv wgrad is not issued yet
         gdil = {}                 # block -> (gWd, gbd) destinations
@@ -504,25 +506,33 @@ class ResidualStackFunction(FunctionNode):
             # gWc_l, gbc_l and the condition gradient
             B, Cc, Tl = lat.shape
             wsc = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
-            gWc_all = DeviceArray(self.Wc_all.shape, np.float32)
-            gbc_all = DeviceArray((nb * d.Cd,), np.float32)
-            _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.pdesc), lat.ptr, gP.ptr, gWc_all.ptr,
-                      gbc_all.ptr, 0, wsc.ptr, wsc.nbytes, _S())
-            gWc = [_grad_out(in_vars[2 + 8 * i + 2], ins[2 + 8 * i + 2].shape) for i in range(nb)]
-            gbc = [_grad_out(in_vars[2 + 8 * i + 3], ins[2 + 8 * i + 3].shape) for i in range(nb)]
-            for lo, hi in _groups(nb):
-                _lib.call('vqvae_split', gWc_all.ptr + lo * d.Cd * Cc * 4, _lib.ptr_array(gWc[lo:hi]),
-                          hi - lo, d.Cd * Cc, 0, _S())
-                _lib.call('vqvae_split', gbc_all.ptr + lo * d.Cd * 4, _lib.ptr_array(gbc[lo:hi]),
-                          hi - lo, d.Cd, 0, _S())
-            for i in range(nb):
-                grads[2 + 8 * i + 2] = gWc[i]
-                grads[2 + 8 * i + 3] = gbc[i]
+            # the condition gradient first: it is what the rest of the sweep (condition embed, quantiser, encoder) waits
+            # for; the projection's own weight gradient is a leaf -- on the side stream behind the other deferred ones
             if 1 in indexes:
                 glat = DeviceArray(lat.shape, np.float32)
                 _lib.call('vqvae_conv1d_bwd_data', C.byref(self.pdesc), self.Wc_all.ptr, gP.ptr,
                           glat.ptr, 0, wsc.ptr, wsc.nbytes, _S())
                 grads[1] = F.LatentGrad(cond.shape, glat)
+            sw, wsw = _S(), wsc
+            if defer:
+                sw, wsw = backend.side_stream(), ws_defer
+                backend.wait_event(sw, backend.Event().record(_S()))        # gP is complete
+            gWc_all = DeviceArray(self.Wc_all.shape, np.float32)
+            gbc_all = DeviceArray((nb * d.Cd,), np.float32)
+            _lib.call('vqvae_conv1d_bwd_weight', C.byref(self.pdesc), lat.ptr, gP.ptr, gWc_all.ptr,
+                      gbc_all.ptr, 0, wsw.ptr, wsw.nbytes, sw)
+            gWc = [_grad_out(in_vars[2 + 8 * i + 2], ins[2 + 8 * i + 2].shape) for i in range(nb)]
+            gbc = [_grad_out(in_vars[2 + 8 * i + 3], ins[2 + 8 * i + 3].shape) for i in range(nb)]
+            for lo, hi in _groups(nb):
+                _lib.call('vqvae_split', gWc_all.ptr + lo * d.Cd * Cc * 4, _lib.ptr_array(gWc[lo:hi]),
+                          hi - lo, d.Cd * Cc, 0, sw)
+                _lib.call('vqvae_split', gbc_all.ptr + lo * d.Cd * 4, _lib.ptr_array(gbc[lo:hi]),
+                          hi - lo, d.Cd, 0, sw)
+            if defer:
+                backend.defer_to_side([gWc_all, gbc_all, gP, lat, gWc, gbc, wsw])
+            for i in range(nb):
+                grads[2 + 8 * i + 2] = gWc[i]
+                grads[2 + 8 * i + 3] = gbc[i]
         elif 1 in indexes:
             gcond = DeviceArray(cond.shape, np.float32)
             for lo, hi in _groups(nb):
