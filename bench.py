@@ -215,13 +215,24 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def GATES_SIG_ACTIVE(cfg, B):
+    """Does ResidualNet's chain save sigmoid and z only (vqvae_resblock_desc.storage & VQVAE_STORE_GATES_SIG: float32x2,
+    configs-sized blocks)?  Asked of the library, as wavenet.py does."""
+    import ctypes as C
+    from vqvae_amd import _lib
+    d = _lib.ResblockDesc(B, cfg['length'], cfg['residual'], cfg['dilated'], cfg['skip'], 192, cfg['filter_size'], 1, 0)
+    return bool(_lib.load().vqvae_resblock_f16x2_storage(C.byref(d)) & _lib.STORE_GATES_SIG)
+
+
 def GATE_BYTES(cfg, B, bf16=False):
     """Algorithmic HBM bytes of one gate launch: 4 * (N Cr + N 1.5 Cd + K Cr Cd + B Cd T'); in
-    the bf16 mode of the configs-sized blocks the gate values, z and the residual stream x are kept as bf16: 2 bytes each."""
+    the bf16 mode of the configs-sized blocks the gate values, z and the residual stream x are kept as bf16: 2 bytes each.
+    Where the chain saves sigmoid and z only (float32x2, round 5) the stores are N Cd instead of N 1.5 Cd."""
     N = B * cfg['length']
     out_bytes = 2.0 if (bf16 and cfg['dilated'] == 256 and cfg['residual'] == 256 and cfg['length'] % 64 == 0) else 4.0
     x_bytes = 2.0 if (out_bytes == 2.0 and cfg['length'] % 128 == 0) else 4.0      # the bf16 residual stream (every block but the first)
-    return (x_bytes * N * cfg['residual'] + out_bytes * N * 1.5 * cfg['dilated']
+    saved = 1.0 if (not bf16 and GATES_SIG_ACTIVE(cfg, B)) else 1.5
+    return (x_bytes * N * cfg['residual'] + out_bytes * N * saved * cfg['dilated']
             + 4.0 * (cfg['filter_size'] * cfg['residual'] * cfg['dilated'] + B * cfg['dilated'] * (cfg['length'] // 64)))
 
 
@@ -734,7 +745,7 @@ def main():
                                  'peak': 8000.0, 'unit': 'GB/s',
                                  'frac': (GATE_BYTES(cfg, B, args.bf16) / (avg_ms * 1e-3) / 1e9 / 8000.0) if cnt.value else None,
                                  'algorithmic_bytes_per_launch': GATE_BYTES(cfg, B, args.bf16),
-                                 'note': 'x read once, gates + z written once (all three as bf16 with --bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3c)'},
+                                 'note': 'x read once, the saved gate values + z written once (float32x2: sigmoid and z, the backward takes tanh = z / sigmoid; other fp32 modes: tanh, sigmoid, z; --bf16: all as bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3a, 3c)'},
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms, 'avg_launch_ms_measured_over': roofline_pass,
                          'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},

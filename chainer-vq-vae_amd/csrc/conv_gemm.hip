@@ -149,6 +149,11 @@ struct GemmArgs {
   // lerp, net.py:54-55) in this epilogue -- every workgroup leaves the sums of its 128 columns for the four latent positions
   // under them in pb_part[b][column tile][2 Ch][4]; lerp.v0 / w0 / w1 are the resize tables (pullback_reduce_kernel finishes)
   float* pb_part;
+  // gsig (vqvae_resblock_desc::storage & VQVAE_STORE_GATES_SIG): the saved gate values are sigmoid and z = tanh * sigmoid only.
+  // EPI_GATE does not store the tanh half of out[0] (a third of its 189 MB of stores: gate launch 106 -> 88 us); EPI_GATE_BWD
+  // reads z from zsrc (B, Ch, T) where it used to read tanh, and takes tanh = z / sigmoid (z = fl(tanh * sigmoid): tanh to
+  // 2^-23 relative; sigmoid == 0 => z == 0 and both derivatives vanish whatever tanh is taken to be)
+  int gsig; const float* zsrc;
 };
 
 // Gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32): absolute error
@@ -619,6 +624,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) vT[ni] = 4u * (unsigned)(chl * T + tt[ni]);
     const unsigned sGq = 4u * (unsigned)(Ch * T);
+    auto gate_store = [&](auto sigc) {            // (ONE wave-uniform branch around the store loop: GemmArgs::gsig)
+    constexpr bool SIG = decltype(sigc)::value;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dr = (r & 3) + 8 * (r >> 2);
@@ -629,6 +636,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         if (tt[ni] >= T) continue;
         const float ta = fast_tanhf_(acc[0][ni][r]);
         const float sb = sigmoidf_(acc[1][ni][r]);
+        if constexpr (SIG) {       // sigmoid and z only: the backward takes tanh = z / sigmoid
+          buf_st_gate(sb, rG, vT[ni], sT + sGq);
+        } else
         if (ST16 && a.g16) {     // BASELINE configs[4] precision: the saved gate values are bf16 (the backward pass reads exactly these): the pair (tanh, sigmoid) of one (channel, t) as ONE dword in tanh's fp32 position -- one store, and one load in the backward, instead of two
           __builtin_amdgcn_raw_buffer_store_b32((int)pack_bf16x2(ta, sb), rG, vT[ni], sT, X3_GATE_ST_AUX);
         } else {
@@ -639,6 +649,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         else buf_st_gate(ta * sb, rZ, vT[ni], sT);
       }
     }
+    };
+    if (a.gsig) gate_store(std::true_type{}); else gate_store(std::false_type{});
   } else {  // EPI_GATE_BWD: rows are gz channels; add = gates (B,2Ch,T); y = gh (B,2Ch,T)
     const int Ch = a.M;
     const OutR& od = a.out[0];
@@ -651,8 +663,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
       // stores waited for those stores' acknowledgements -- four load + store round trips per tile, now one.
       float ta[2][2][16], sb[2][2][16];
       // (ONE wave-uniform branch around all of the loads: a branch per load makes hipcc drain vmcnt(0) at each)
+      const rsrc_t rZs = make_rsrc(a.zsrc ? a.zsrc + (long)b * Ch * T : od.add);      // gsig: z (B, Ch, T) in tanh's place
       auto load_gates = [&](auto packedc) {
-        constexpr bool PACKED = decltype(packedc)::value;
+        constexpr int LMODE = decltype(packedc)::value;      // 0: tanh | sigmoid as two fp32, 1: one packed bf16 pair, 2: z | sigmoid (gsig)
+        constexpr bool PACKED = LMODE == 1;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -670,6 +684,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
                 // are requested.  Unconditional loads (an out-of-range lane reads element 0; its value is never
                 // used): a branch per load made hipcc wait for each load before the next was issued
                 ta[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGt, ok ? voff + so : 0u, 0, X3_GBWD_LD16_AUX));
+              } else if constexpr (LMODE == 2) {
+                const unsigned vo = ok ? voff + so : 0u;
+                ta[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZs, vo, 0, X3_GBWD_LD_AUX));
+                sb[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGt, vo, sQ, X3_GBWD_LD_AUX));
               } else {
                 const unsigned vo = ok ? voff + so : 0u;
                 ta[mi][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rGt, vo, 0, X3_GBWD_LD_AUX));
@@ -690,7 +708,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
               }
         }
       };
-      if (ST16 && a.g16) load_gates(std::true_type{}); else load_gates(std::false_type{});
+      if (ST16 && a.g16) load_gates(std::integral_constant<int, 1>{});
+      else if (a.gsig) load_gates(std::integral_constant<int, 2>{});
+      else load_gates(std::integral_constant<int, 0>{});
       // ---- fused latent pull-back (OUT bit 1).  gP[c, v] = sum_t gh[c, t] W(t, v), W(t, v0[t]) = w0[t], W(t, v0[t] + 1) = w1[t]: the
       // 32 columns of a sub-tile touch the latent positions vs, vs + 1, vs + 2 (vs = v0 of its first column; T >= 64 Tl: the host
       // checks), the 128 columns of the tile vb .. vb + 3.  The accumulator layout has a lane per COLUMN; the sums run over columns,
@@ -714,6 +734,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         for (int i = tid_; i < 2 * 256 * 4; i += 256) pbT[i] = 0.f;
         __syncthreads();
       }
+      const bool gsig_ = a.gsig != 0;
       auto store_gh = [&](auto h16c) {         // (ONE wave-uniform branch around the whole store loop, as for the loads)
         constexpr bool H16 = decltype(h16c)::value;
         // H16 (GemmArgs::h16): gh is read back only as an MFMA operand (backward-data, weight gradient), i.e. rounded
@@ -733,7 +754,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
               const int dr = (r & 3) + 8 * (r >> 2);
               if (tok && mb + dr < Ch) {
                 const float gz = acc[mi][ni][r];
-                const float tv = ta[mi][ni][r], sv = sb[mi][ni][r];
+                const float sv = sb[mi][ni][r];
+                // gsig: ta holds z = tanh * sigmoid; tanh = z / sigmoid, taken where it is used (a pass over the 64 values in
+                // front of the stores cost 13 more registers than the kernel has)
+                const float tv = gsig_ ? ta[mi][ni][r] * __builtin_amdgcn_rcpf(fmaxf(sv, 1e-30f)) : ta[mi][ni][r];
                 const unsigned so = 4u * (unsigned)(dr * T);
                 const float ga = gz * sv * (1.f - tv * tv), gb = gz * tv * sv * (1.f - sv);
                 if constexpr (PB) {
@@ -4055,9 +4079,9 @@ static int bf16_storage_supported(const vqvae_resblock_desc* d) {
 // matmul mode 3 (float32x2): the tensors of the packed chain that can be kept PRE-SPLIT (see presplit_pair) -- the
 // configs-sized blocks whose two-tap GEMMs run the 256 x 128-tile loop and whose residual 1x1 runs the streaming kernel.
 // VQVAE_PRESPLIT=0 makes the library report none.
-static int g_presplit = -1;          // < 0: not set (VQVAE_PRESPLIT, else 3); bit 0: gh, bit 1: the residual stream
+static int g_presplit = -1;          // < 0: not set (VQVAE_PRESPLIT, else 7); bit 0: gh, bit 1: the residual stream, bit 2: sigmoid + z instead of tanh + sigmoid + z
 static int f16x2_storage_supported(const vqvae_resblock_desc* d) {
-  if (g_presplit < 0) g_presplit = getenv("VQVAE_PRESPLIT") ? atoi(getenv("VQVAE_PRESPLIT")) : 3;
+  if (g_presplit < 0) g_presplit = getenv("VQVAE_PRESPLIT") ? atoi(getenv("VQVAE_PRESPLIT")) : 7;
   const int on = g_presplit;
   static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
   static const int lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
@@ -4070,6 +4094,7 @@ static int f16x2_storage_supported(const vqvae_resblock_desc* d) {
   int m = 0;
   if (on & 1) m |= VQVAE_STORE_GH_F16X2;
   if ((on & 2) && lin128) m |= VQVAE_STORE_X_F16X2 | VQVAE_STORE_RES_F16X2;
+  if (on & 4) m |= VQVAE_STORE_GATES_SIG;
   return m;
 }
 
@@ -4112,7 +4137,7 @@ extern "C" int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d) {
   return bf16_storage_supported(d);
 }
 extern "C" int vqvae_set_presplit(int mask) {
-  VQ_REQUIRE(mask >= 0 && mask <= 3, "set_presplit: bit 0 = gh, bit 1 = the residual stream");
+  VQ_REQUIRE(mask >= 0 && mask <= 7, "set_presplit: bit 0 = gh, bit 1 = the residual stream, bit 2 = sigmoid + z instead of tanh + sigmoid + z");
   g_presplit = mask;
   return 0;
 }
@@ -4206,6 +4231,7 @@ static int resblock_fwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[1].y = z; g.out[1].y_bstride = (long)Ch * T;
     g.z16 = z_bf16(d) ? 1 : 0;
     g.g16 = gates_bf16(d) ? 1 : 0;
+    g.gsig = (d->storage & VQVAE_STORE_GATES_SIG) ? 1 : 0;
     g.x16 = (d->storage & VQVAE_STORE_X_BF16) ? 3 : 0;
     if (xpre) g.x16 = 3;                         // both taps read the pre-split x_l; amax->x holds its scale words
     if (int e = launch_gemm<EPI_GATE>(g, VQVAE_PROF_RESBLOCK_GATE, st)) return e;
@@ -4382,6 +4408,7 @@ static int resblock_bwd_impl(const vqvae_resblock_desc* d, const vqvae_resblock_
     g.out[0].add = gates; g.out[0].add_bstride = (long)d->Cd * T;
     g.out[0].amax_out = am ? am->gh : nullptr;
     g.g16 = gates_bf16(d) ? 1 : 0;
+    if (d->storage & VQVAE_STORE_GATES_SIG) { g.gsig = 1; g.zsrc = z; }
     g.h16 = (h16 || hpre) ? 1 : 0;
     g.x16 = gres16 ? 1 : 0;                       // segment 0 = g_res
     if (f16 && am->pb_part) {                     // the latent pull-back of gh in this launch's epilogue

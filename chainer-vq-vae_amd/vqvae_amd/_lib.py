@@ -206,6 +206,7 @@ STORE_X_BF16, STORE_RES_BF16 = 2, 4
 STORE_GX_BF16, STORE_GRES_BF16 = 8, 16
 STORE_GH_BF16 = 1                 # vqvae_resblock_desc.storage bits (VQVAE_STORE_*)
 STORE_GH_F16X2, STORE_X_F16X2, STORE_RES_F16X2 = 32, 64, 128      # matmul mode 3: kept pre-split (fp16 hi | lo dwords)
+STORE_GATES_SIG = 256         # matmul mode 3: the gate kernel saves sigmoid and z only, the backward takes tanh = z / sigmoid
 AMAX_SLOTS = 16                   # uint32 words per absolute maximum (vqvae_absmax, vqvae_resblock_amax)
 EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_FILL, \
     EW_MUL_SCALAR_DEV = range(10)

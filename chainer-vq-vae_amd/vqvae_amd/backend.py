@@ -203,7 +203,8 @@ def join_side(force=True):
 
 def set_presplit(mask):
     """'float32x2' only: which tensors of ResidualNet's chain are kept PRE-SPLIT in HBM (fp16 hi | lo dwords written once
-    by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; default 3
+    by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; bit 2: the
+    gate kernel saves sigmoid and z only (the backward takes tanh = z / sigmoid: VQVAE_STORE_GATES_SIG); default 7
     ($VQVAE_PRESPLIT), 0 = every tensor fp32 and every reader splits for itself (round 4's form, the A/B alternate)."""
     _lib.call('vqvae_set_presplit', int(mask))
 

@@ -225,6 +225,9 @@ class ResidualStackFunction(FunctionNode):
                     sup = _lib.load().vqvae_resblock_f16x2_storage(C.byref(d))
                     if sup & _lib.STORE_RES_F16X2 and sup & _lib.STORE_X_F16X2:
                         d.storage = (0 if last else _lib.STORE_RES_F16X2) | (_lib.STORE_X_F16X2 if i > 0 else 0)
+                    # ... and of tanh, sigmoid, z = tanh * sigmoid only the last two are saved (a third of the gate
+                    # kernel's stores): the backward takes tanh = z / sigmoid
+                    d.storage |= sup & _lib.STORE_GATES_SIG
             res = None if last else DeviceArray((d.B, d.Cr, d.T, 1), np.float32)
             gates = DeviceArray((d.B, d.Cd, d.T), np.float32)
             z = DeviceArray((d.B, d.Cd // 2, d.T), np.float32)
@@ -299,7 +302,8 @@ class ResidualStackFunction(FunctionNode):
         if f16 and self.packed is not None and lat is not None:    # matmul mode 'float32x2': gh kept pre-split
             store = _lib.load().vqvae_resblock_f16x2_storage(C.byref(self.descs[0])) & _lib.STORE_GH_F16X2
         hpre = bool(store & _lib.STORE_GH_F16X2)
-        stream16 = _lib.STORE_X_BF16 | _lib.STORE_RES_BF16 | _lib.STORE_X_F16X2 | _lib.STORE_RES_F16X2       # the forward's choice for the residual stream stays
+        stream16 = (_lib.STORE_X_BF16 | _lib.STORE_RES_BF16 | _lib.STORE_X_F16X2 | _lib.STORE_RES_F16X2       # the forward's choice for the residual stream stays
+                    | _lib.STORE_GATES_SIG)                                                                   # ... and for the saved gate values
         gstream = 0                                              # ... and its counterpart, the gradient stream g_res_l = gx_{l+1}
         if self.packed is not None and lat is not None and BF16_STORAGE:
             sup = _lib.load().vqvae_resblock_bf16_storage(C.byref(self.descs[0]))

@@ -249,10 +249,16 @@ int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 #define VQVAE_STORE_GH_F16X2 32
 #define VQVAE_STORE_X_F16X2 64
 #define VQVAE_STORE_RES_F16X2 128
+/*   GATES_SIG: of the three tensors the gate kernel saves per block -- tanh, sigmoid (`gates`) and z = tanh * sigmoid -- the
+ *   backward needs two: resblock_fwd_packed leaves the tanh half of `gates` UNWRITTEN (a third of the gate launch's 189 MB
+ *   of stores: 106 -> 88 us per launch) and resblock_bwd_packed takes tanh = z / sigmoid from the z it is handed (z is
+ *   fl(tanh * sigmoid): tanh to 2^-23 relative; where sigmoid underflows to 0, z is 0 and both derivatives vanish).
+ *   Same flag in the forward and the backward call of a block.  `gates` keeps its (B, Cd, T) shape.                  */
+#define VQVAE_STORE_GATES_SIG 256
 /* the pre-split bits the library supports for this block shape in the current matmul mode (0 outside mode 3)      */
 int vqvae_resblock_f16x2_storage(const vqvae_resblock_desc* d);
-/* which tensors vqvae_resblock_f16x2_storage may offer: bit 0 = gh, bit 1 = the residual stream (default 3, or
- * $VQVAE_PRESPLIT; 0 = every tensor of the chain stays fp32 -- the A/B switch of the pre-split tests)              */
+/* which tensors vqvae_resblock_f16x2_storage may offer: bit 0 = gh, bit 1 = the residual stream, bit 2 = GATES_SIG
+ * (default 7, or $VQVAE_PRESPLIT; 0 = every tensor of the chain stays fp32 -- the A/B switch of the pre-split tests) */
 int vqvae_set_presplit(int mask);
 
 typedef struct {            /* parameters, Chainer layouts (modules.py:13-22)     */

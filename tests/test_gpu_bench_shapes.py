@@ -123,7 +123,8 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
     every tensor fp32 (backend.set_presplit(0), round 4's form) the only difference is WHERE the split is rounded: every
     output and gradient of a four-block stack (B = 16, T = 7680, dilations 1, 2, 256, 512) agrees to 2e-6 of its scale
     -- fifty times inside the 1e-4 parity bar that test_resstack_b16_vs_oracle holds both forms to -- for gh alone
-    (mask 1), the stream alone (mask 2) and both (mask 3)."""
+    (mask 1), the stream alone (mask 2) and both (mask 3).  Mask bit 2 (VQVAE_STORE_GATES_SIG): the gate kernel saves sigmoid and
+    z = tanh * sigmoid only and the backward takes tanh = z / sigmoid -- alone (4) and with the rest (7, the default)."""
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     from vqvae_amd.wavenet import ResidualStackFunction
@@ -167,8 +168,9 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
     try:
         ref, used0 = run(0)
         assert all(u == 0 for u in used0)
-        for mask in (1, 2, 3):
+        for mask in (1, 2, 3, 4, 7):
             got, used = run(mask)
+            assert all(bool(u & 256) == bool(mask & 4) for u in used), used      # VQVAE_STORE_GATES_SIG on every block
             if mask & 1:
                 assert all(u & 32 for u in used), used                      # VQVAE_STORE_GH_F16X2 on every block
             if mask & 2:
@@ -178,13 +180,13 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
                 assert_close_scaled(got[k], ref[k], 2e-6, 'mask %d: %s' % (mask, k))
         # the latent pull-back inside the gate-derivative launch (vqvae_resblock_amax.pb_part + vqvae_pullback_reduce) against a
         # vqvae_upsample_linear_bwd* launch per block: the same sums in another order
-        unfused, _ = run(3, fuse_pullback=False)
+        unfused, _ = run(7, fuse_pullback=False)
         for k in ref:
             assert_close_scaled(got[k], unfused[k], 2e-6, 'fused pull-back: %s' % k)
     finally:
         import vqvae_amd.wavenet as wn
         wn.FUSE_PULLBACK = True
-        gpu.set_presplit(3)
+        gpu.set_presplit(7)
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
