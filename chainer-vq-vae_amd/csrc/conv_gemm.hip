@@ -1339,6 +1339,17 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // (two-tap launches read their four maxima -- and max |P| -- in straight-line code, once: the loads travel together; a loop
   // over a runtime segment count, and a second read per use, made the prologue a chain of eight dependent L2 round trips)
   [[maybe_unused]] unsigned axb[2] = {0u, 0u}, awb[2] = {0u, 0u}, apb = 0u;
+  [[maybe_unused]] bool fold = EPI == EPI_GATE && a.lerp.fold != 0;
+  [[maybe_unused]] int kp = 0, kc = 0;
+  [[maybe_unused]] int kout = 0;
+  [[maybe_unused]] auto seg_kx = [&](int s) -> int {
+    if constexpr (TAP2) return 14 - emax + amax_expo(awb[s]);
+    else return 14 - emax + amax_expo(amax_load(a.seg[s].wamax));
+  };
+  // (the 256 x 128-tile two-tap loop calls this BEHIND its first fetches: the maxima are L2 hits, but a round trip of
+  // their own in front of the first operand loads was ~3 % of a workgroup's life -- now they travel together)
+  constexpr bool SCALES_LATE = (NB == 1 && NP == 2 && TAP2 && WM == 4 && X3_LEAN);
+  auto read_scales = [&]() {
   if constexpr (NP == 2 && TAP2) {
     const unsigned x0 = a.seg[0].amax ? amax_load(a.seg[0].amax) : __builtin_bit_cast(unsigned, a.seg[0].amax_static);
     const unsigned w0 = amax_load(a.seg[0].wamax);
@@ -1347,10 +1358,6 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     if (EPI == EPI_GATE && a.lerp.fold) apb = amax_load(a.lerp.amax);
     axb[0] = x0; axb[1] = x1; awb[0] = w0; awb[1] = w1;
   }
-  [[maybe_unused]] auto seg_kx = [&](int s) -> int {
-    if constexpr (TAP2) return 14 - emax + amax_expo(awb[s]);
-    else return 14 - emax + amax_expo(amax_load(a.seg[s].wamax));
-  };
   if constexpr (NP == 2) {
     int em = -100000;
     if constexpr (TAP2) em = max(amax_expo(awb[0]) + amax_expo(axb[0]), amax_expo(awb[1]) + amax_expo(axb[1]));
@@ -1368,8 +1375,6 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
   // the condition as a K step (see behind the two-tap loop): P is scaled by 2^kp, its lerp coefficients by 2^kc, kp + kc = the
   // launch's product scale 28 - emax.  A pre-split x pins emax; should max |P| then need kc > 15 (the coefficients would leave
   // fp16's range: lin128_stream_kernel's floor on x's scale rules it out inside ResidualNet's chain) the epilogue lerps as before.
-  [[maybe_unused]] bool fold = EPI == EPI_GATE && a.lerp.fold != 0;
-  [[maybe_unused]] int kp = 0, kc = 0;
   if constexpr (NP == 2 && EPI == EPI_GATE) {
     if (fold) {
       const int ep = amax_expo(TAP2 ? apb : amax_load(a.lerp.amax));
@@ -1378,7 +1383,6 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     }
   }
   // pre-split output (OUT): the power of two gh is stored under, from the a-priori bound sum_seg l1[seg] * max|x_seg|
-  [[maybe_unused]] int kout = 0;
   if constexpr ((OUT & 1) != 0) {
     float bound = 0.f;
     if constexpr (TAP2) bound = a.bound_l1[0] * __builtin_bit_cast(float, axb[0]) + a.bound_l1[1] * __builtin_bit_cast(float, axb[1]);
@@ -1391,6 +1395,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     kout = 14 - amax_expo(__builtin_bit_cast(unsigned, bound));
     scale_publish(a.scale_out, bound);
   }
+  };
+  if constexpr (!SCALES_LATE) read_scales();
   [[maybe_unused]] int kcur = 0, k1 = 0;    // scale exponent of the segment the fetch cursor is in (TAP2: of segment 0 / segment 1)
 
   // ---- staging state of the next step to fetch (advanced once per fetch) ----------------------
@@ -1660,10 +1666,12 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
         for (int p = 0; p < NP; ++p) ad[p * NT + tid] = wa[p];
         stage_b(std::false_type{}, cv, kc, cbuf);
     };
+    if constexpr (SCALES_LATE) { if (nsteps <= 0) read_scales(); }      // (never: every launch of this loop has K steps)
     if (nsteps > 0) {
       LN_FETCH_B(pb, false);                   // step 0
       LN_FETCH_A(false, 0);                    // step 0
       LN_FETCH_B(qb, true);                    // step 1
+      if constexpr (SCALES_LATE) { read_scales(); kcur = seg_kx(0); k1 = seg_kx(1); }
       if constexpr (EPI == EPI_GATE && NBUF == 3) {
         if (fold) stage_cond(std::integral_constant<int, 2>{});     // its loads travel with the first steps'; read after the loop: the loop's barriers order the writes
       }
@@ -1829,23 +1837,6 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
 #pragma unroll
     for (int p = 0; p < NP; ++p) af[s][p] = a.w[((long)(s * NP + p) * 2 + lk) * a.ldw + 32 * wave + li];
   if (tid < 256) reinterpret_cast<float*>(bias_s)[tid] = a.bias ? a.bias[tid] : 0.f;
-  [[maybe_unused]] int kz = 0, ku = 0;             // float32x2: z is scaled by 2^kz, the accumulators come back by 2^ku
-  if constexpr (NP == 2) {
-    const int ew = amax_expo(amax_load(a.wamax)), ez = amax_expo(a.z_amax ? amax_load(a.z_amax) : __builtin_bit_cast(unsigned, a.z_amax_static));
-    kz = 14 - ez; ku = ew + ez - 28;
-  }
-  [[maybe_unused]] int kadd = 0, kout = 0;         // pre-split stream: x_l comes back by 2^kadd, x_{l+1} is stored under 2^kout
-  if constexpr (ADDPRE) kadd = amax_expo(amax_load(a.add_scale)) - 14;
-  if constexpr (YPRE) {
-    float bound = bound_margin(__builtin_bit_cast(float, amax_load(a.add_amax)) + a.l1[0]);
-    if (a.floor_p != nullptr) {
-      const int ef = amax_expo(amax_load(a.floor_p)) - amax_expo(amax_load(a.floor_w)) - 1;
-      bound = fmaxf(bound, __builtin_ldexpf(1.f, min(max(ef, -100), 100)));
-    }
-    kout = 14 - amax_expo(__builtin_bit_cast(unsigned, bound));
-    scale_publish(a.scale_out, bound);
-  }
-  float am = 0.f;
 
   // ---- staging role: CPC consecutive columns x 4 consecutive channels per thread ----
   const int cg = tid & 15, kq = tid >> 4;
@@ -2020,6 +2011,25 @@ __global__ __launch_bounds__(512, 1) void lin128_stream_kernel(const Lin128Args 
   float xa[NCB][16], xb[NCB][16];
   L128_FETCH(tile);
   L128_XLOAD(xa, tile);
+  // the scales, read while the first tile travels (the maxima are L2 hits; this workgroup is alone on its CU, so every
+  // round trip of its prologue is exposed: they used to come one after the other)
+  [[maybe_unused]] int kz = 0, ku = 0;             // float32x2: z is scaled by 2^kz, the accumulators come back by 2^ku
+  if constexpr (NP == 2) {
+    const int ew = amax_expo(amax_load(a.wamax)), ez = amax_expo(a.z_amax ? amax_load(a.z_amax) : __builtin_bit_cast(unsigned, a.z_amax_static));
+    kz = 14 - ez; ku = ew + ez - 28;
+  }
+  [[maybe_unused]] int kadd = 0, kout = 0;         // pre-split stream: x_l comes back by 2^kadd, x_{l+1} is stored under 2^kout
+  if constexpr (ADDPRE) kadd = amax_expo(amax_load(a.add_scale)) - 14;
+  if constexpr (YPRE) {
+    float bound = bound_margin(__builtin_bit_cast(float, amax_load(a.add_amax)) + a.l1[0]);
+    if (a.floor_p != nullptr) {
+      const int ef = amax_expo(amax_load(a.floor_p)) - amax_expo(amax_load(a.floor_w)) - 1;
+      bound = fmaxf(bound, __builtin_ldexpf(1.f, min(max(ef, -100), 100)));
+    }
+    kout = 14 - amax_expo(__builtin_bit_cast(unsigned, bound));
+    scale_publish(a.scale_out, bound);
+  }
+  float am = 0.f;
   L128_STAGE(0);
   __syncthreads();
   L128_FETCH(tile + stride);
