@@ -697,6 +697,28 @@ __global__ void vq_gather_kernel(const float* __restrict__ W, const int32_t* __r
   }
 }
 
+// The same gather through LDS: e is (B, d, T) with time contiguous, a codebook row is d contiguous floats -- the kernel above
+// reads a different row per lane (64 cache lines per wave instruction for 256 bytes of payload: 0.63 ms for the 1 M rows of
+// configs[3]).  A workgroup takes 64 consecutive t of one b: rows arrive coalesced (lanes along the row), go to LDS at pitch
+// d + 1 and leave transposed, lanes along t (both LDS passes conflict-free).  Dynamic LDS: 64 (d + 1) floats.
+__global__ __launch_bounds__(256) void vq_gather_tile_kernel(const float* __restrict__ W, const int32_t* __restrict__ idx,
+                                                             int B, int d, int T, float* __restrict__ e) {
+  extern __shared__ float gt_tile[];
+  __shared__ int rows[64];
+  const int b = blockIdx.y, t0 = blockIdx.x * 64, nt = min(64, T - t0), tid = threadIdx.x;
+  if (tid < 64) rows[tid] = tid < nt ? idx[(long)b * T + t0 + tid] : 0;
+  __syncthreads();
+  const int pitch = d + 1;
+  for (int i = tid; i < nt * d; i += 256) {
+    const int r = i / d, c = i - r * d;
+    gt_tile[r * pitch + c] = W[(long)rows[r] * d + c];
+  }
+  __syncthreads();
+  const int t = tid & 63;
+  if (t < nt)
+    for (int c = tid >> 6; c < d; c += 4) e[((long)b * d + c) * T + t0 + t] = gt_tile[t * pitch + c];
+}
+
 // ---------------------------------------------------------------------------
 // Large-N codebook gradient (B*T' beyond the scan kernel's reach, e.g. the configs[3] stress
 // shape): gW = onehot(idx)^T gy accumulated in float64, rounded once (utils.py:222-229).
@@ -1063,7 +1085,10 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     const long total = (long)B * d * T;
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(vq_gather_kernel, dim3(nb), dim3(256), 0, st, W, idx, B, d, T, e);
+    if ((long)B * T >= 16384 && d <= 512 && B <= 65535)        // (the training shape's 1 920 rows: one launch of the plain kernel is all latency)
+      hipLaunchKernelGGL(vq_gather_tile_kernel, dim3((T + 63) / 64, B), dim3(256), (size_t)64 * (d + 1) * 4, st, W, idx, B, d, T, e);
+    else
+      hipLaunchKernelGGL(vq_gather_kernel, dim3(nb), dim3(256), 0, st, W, idx, B, d, T, e);
     VQ_LAUNCH_CHECK();
   }
   return 0;

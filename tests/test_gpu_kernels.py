@@ -284,6 +284,19 @@ def test_vq_mfma_vs_exact_large(gpu, matmul_mode):
     np.testing.assert_array_equal(idx0[:1], idx_ref)
 
 
+def test_vq_gather_through_lds_equals_row_gather(gpu):
+    """From 16 384 rows on the quantiser's output e = W[idx] is gathered through LDS (vq_gather_tile_kernel: code rows in
+    coalesced, time-contiguous rows out); it must be the codebook rows bit for bit -- d = 128 and a d that is no multiple
+    of 4, T = 120 (a ragged second tile of 56) and T = 64."""
+    rs = np.random.RandomState(3)
+    for (B, d, T, k) in [(150, 128, 120, 512), (300, 66, 64, 97)]:
+        z = rs.standard_normal((B, d, T, 1)).astype(np.float32)
+        W = rs.standard_normal((k, d)).astype(np.float32)
+        e, idx, _, _, _ = _run_vq(gpu, z, W, np.zeros((B, d, T, 1), np.float32), 1)
+        want = np.transpose(W[idx.reshape(B, T)], (0, 2, 1))            # (B, d, T)
+        np.testing.assert_array_equal(e.reshape(B, d, T), want)
+
+
 def test_vq_type_check(gpu):
     from vqvae_amd.core import InvalidType, Variable
     from vqvae_amd.utils import StraightThrough
