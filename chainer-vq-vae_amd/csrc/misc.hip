@@ -62,6 +62,29 @@ __global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ part
   if (threadIdx.x == 0) out[0] = t * scale;
 }
 
+// ---- mean((a - b)^2) as one node (net.py:90-91: the codebook and commitment losses; as Variable arithmetic each was
+// sub, square, two-stage sum forward and fill, scale, mul, scale, negate backward).  Same roundings in the same order as
+// that chain: d = fl(a - b), fl(d d) summed by the two-stage sum; backward fl(fl(fl(fl(1/n) g) d) 2).
+__global__ __launch_bounds__(256) void sqdiff_stage1(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* partial) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = __fsub_rn(a[i], b[i]);
+    acc += __fmul_rn(d, d);
+  }
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ void sqdiff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g, size_t n,
+                                  float invn, float* __restrict__ ga, float* __restrict__ gb) {
+  const float gm = __fmul_rn(invn, g[0]);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = __fmul_rn(__fmul_rn(gm, __fsub_rn(a[i], b[i])), 2.f);
+    if (ga) ga[i] = v;
+    if (gb) gb[i] = -v;
+  }
+}
+
 // ---- up-sampling ---------------------------------------------------------
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, int B, int C, int Tin, int Tout,
                                     const int32_t* __restrict__ v0, const int32_t* __restrict__ v1,
@@ -946,6 +969,16 @@ __global__ void split_kernel(const float* __restrict__ src, const PtrList32 dst,
   }
 }
 
+// ---- many small device-to-device copies in one launch (arena adoption: a copy per parameter and arena was ~900
+// __amd_rocclr_copyBuffer dispatches at start-up) ------------------------------
+struct CopyJobs { float* dst[64]; const float* src[64]; unsigned n[64]; };
+__global__ __launch_bounds__(256) void copy_list_kernel(const CopyJobs j) {
+  float* __restrict__ d = j.dst[blockIdx.y];
+  const float* __restrict__ s = j.src[blockIdx.y];
+  const unsigned n = j.n[blockIdx.y];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // ---- Adam / EMA ------------------------------------------------------------
 // lr_table != nullptr: the step size is lr_table[*step] -- a captured step (hipGraph) is replayed with the next entry
 // every time; step_inc_kernel advances the counter behind the update
@@ -997,6 +1030,23 @@ int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws, size_
   hipLaunchKernelGGL(sum_stage1, dim3(np), dim3(256), 0, (hipStream_t)s, x, n, (float*)ws);
   VQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, scale, out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_sqdiff_mean(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(a && b && out && ws && n > 0, "sqdiff_mean: bad arguments");
+  if (ws_bytes < 4096 * 4) { set_error("sqdiff_mean: workspace too small"); return VQVAE_E_WORKSPACE; }
+  const int np = grid_for(n, 256, 1024);
+  hipLaunchKernelGGL(sqdiff_stage1, dim3(np), dim3(256), 0, (hipStream_t)s, a, b, n, (float*)ws);
+  VQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)ws, np, (float)(1.0 / (double)n), out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+int vqvae_sqdiff_mean_bwd(const float* a, const float* b, const float* gloss, size_t n, float* ga, float* gb, vqvae_stream_t s) {
+  VQ_REQUIRE(a && b && gloss && n > 0 && (ga || gb), "sqdiff_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(sqdiff_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, a, b, gloss, n, (float)(1.0 / (double)n), ga, gb);
   VQ_LAUNCH_CHECK();
   return 0;
 }
@@ -1278,6 +1328,26 @@ int vqvae_concat(float* dst, const float* const* srcs, int n, size_t count, vqva
   for (int i = 0; i < n; ++i) { VQ_REQUIRE(srcs[i], "concat: null source"); pl.p[i] = (float*)srcs[i]; }
   hipLaunchKernelGGL(concat_kernel, dim3(grid_for((size_t)n * count)), dim3(256), 0, (hipStream_t)s, pl, n, (long)count, dst);
   VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+int vqvae_copy_list(int n, float* const* dst, const float* const* src, const size_t* count, vqvae_stream_t s) {
+  VQ_REQUIRE(n >= 0 && (n == 0 || (dst && src && count)), "copy_list: null pointer");
+  for (int lo = 0; lo < n; lo += 64) {
+    CopyJobs j;
+    const int m = n - lo < 64 ? n - lo : 64;
+    size_t mx = 0;
+    for (int i = 0; i < m; ++i) {
+      VQ_REQUIRE(dst[lo + i] && src[lo + i] && count[lo + i] < (1ul << 32), "copy_list: bad job %d", lo + i);
+      j.dst[i] = dst[lo + i]; j.src[i] = src[lo + i]; j.n[i] = (unsigned)count[lo + i];
+      if (count[lo + i] > mx) mx = count[lo + i];
+    }
+    int gx = (int)((mx + 1023) / 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(copy_list_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)s, j);
+    VQ_LAUNCH_CHECK();
+  }
   return 0;
 }
 

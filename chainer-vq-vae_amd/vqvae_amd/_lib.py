@@ -171,6 +171,7 @@ PROTOTYPES = {
     'vqvae_conv1d_bwd_weight_cond': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, c_int, P, c_size_t, P, P]),
     'vqvae_concat': (c_int, [P, PP, c_int, c_size_t, P]),
     'vqvae_split': (c_int, [P, PP, c_int, c_size_t, c_int, P]),
+    'vqvae_copy_list': (c_int, [c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_size_t), P]),
     'vqvae_embed_broadcast_fwd': (c_int, [P, P, c_int, c_int, c_int, P, c_long, P]),
     'vqvae_embed_broadcast_bwd': (c_int, [P, c_long, P, c_int, c_int, c_int, c_int, P, c_int, P,
                                           c_size_t, P]),
@@ -181,6 +182,8 @@ PROTOTYPES = {
     'vqvae_mol_nll_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
     'vqvae_elementwise': (c_int, [c_int, c_size_t, P, P, P, c_float, c_float, P]),
     'vqvae_sum': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
+    'vqvae_sqdiff_mean': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    'vqvae_sqdiff_mean_bwd': (c_int, [P, P, P, c_size_t, P, P, P]),
     'vqvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, P]),
     'vqvae_adam_step_dev': (c_int, [P, P, P, P, c_size_t, P, P, c_double, c_double, c_double, P]),
     'vqvae_ema_step': (c_int, [P, P, c_size_t, c_double, P]),

@@ -455,6 +455,37 @@ def to_device(host, dtype=None):
     return DeviceArray(host.shape, dtype).set(host)
 
 
+def copy_many(pairs):
+    """dst.copy_from(src) for many (dst, src) pairs of float32 DeviceArrays in a handful of launches (vqvae_copy_list:
+    64 copies per launch) -- the arena adoption of a model's ~340 parameters was a copy dispatch per parameter and arena."""
+    pairs = [(d, s) for d, s in pairs if d.size]
+    for d, s in pairs:
+        if d.size != s.size or d.dtype != np.float32 or s.dtype != np.float32:
+            raise ValueError('copy_many: float32 arrays of equal size')
+    n = len(pairs)
+    if not n:
+        return
+    dst = (C.c_void_p * n)(*[d.ptr for d, _ in pairs])
+    src = (C.c_void_p * n)(*[s.ptr for _, s in pairs])
+    cnt = (C.c_size_t * n)(*[d.size for d, _ in pairs])
+    _lib.call('vqvae_copy_list', n, dst, src, cnt, stream())
+
+
+def to_device_many(hosts):
+    """Uploads a list of host float32 arrays in ONE transfer: they are laid end to end (each start 256-byte aligned) in
+    one device buffer and returned as views of it."""
+    hosts = [np.ascontiguousarray(h, np.float32) for h in hosts]
+    offs, off = [], 0
+    for h in hosts:
+        offs.append(off)
+        off += (h.size + 63) & ~63
+    stage = np.zeros(max(off, 1), np.float32)
+    for h, o in zip(hosts, offs):
+        stage[o:o + h.size] = h.ravel()
+    big = to_device(stage, np.float32)
+    return [big.flat_view(o, h.size, h.shape) for h, o in zip(hosts, offs)]
+
+
 def empty(shape, dtype=np.float32):
     return DeviceArray(shape, dtype)
 

@@ -469,8 +469,11 @@ class Link(object):
 
     def to_gpu(self, device=None):
         backend.init(0 if device is None else device)
-        for p in self.params():
-            p.to_gpu()
+        # one transfer for all parameters that are still on the host (they become views of one buffer; the optimizer's
+        # arenas adopt them later): a transfer per parameter was ~530 copy dispatches for this model
+        host = [p for p in self.params() if isinstance(p._data, np.ndarray)]
+        for p, d in zip(host, backend.to_device_many([p._data for p in host]) if host else []):
+            p._data = d
         return self
 
     def addgrads(self, link):

@@ -187,6 +187,35 @@ def mul(a, b):
     return Mul().apply((a, b))[0]
 
 
+class MeanSquaredDifference(FunctionNode):
+    """F.mean((a - b) ** 2) (net.py:90-91) as ONE node: two launches forward, one backward, where the Variable arithmetic
+    took four and five -- with the same roundings in the same order, so the losses and gradients keep their bits."""
+
+    def forward(self, inputs):
+        a, b = inputs
+        backend.require_device(a, b)
+        if a.size != b.size:
+            raise ValueError('shape mismatch in mean_squared_difference: %s vs %s' % (a.shape, b.shape))
+        self.retain_inputs((0, 1))
+        out = DeviceArray((), np.float32)
+        ws = backend.workspace(4096 * 4)
+        _lib.call('vqvae_sqdiff_mean', a.ptr, b.ptr, a.size, out.ptr, ws.ptr, ws.nbytes, _S())
+        return out,
+
+    def backward(self, indexes, gys):
+        a, b = (v.data for v in self.get_retained_inputs())
+        ga = DeviceArray(a.shape, np.float32) if 0 in indexes else None
+        gb = DeviceArray(b.shape, np.float32) if 1 in indexes else None
+        if ga is None and gb is None:
+            return None, None
+        _lib.call('vqvae_sqdiff_mean_bwd', a.ptr, b.ptr, gys[0].data.ptr, a.size, _p(ga), _p(gb), _S())
+        return ga, gb
+
+
+def mean_squared_difference(a, b):
+    return MeanSquaredDifference().apply((a, b))[0]
+
+
 def square(a):
     return Square().apply((a,))[0]
 

@@ -100,8 +100,8 @@ class VAE(Chain):
         y = self.decoder(x_dec, self.condition_embed(e, global_condition))
 
         loss1 = self.loss_func(y, t)
-        loss2 = F.mean((z_const - e_cb) ** 2)
-        loss3 = self.beta * F.mean((z - Variable(e.data)) ** 2)
+        loss2 = F.mean_squared_difference(z_const, e_cb)                    # F.mean((z.data - e_) ** 2), net.py:90
+        loss3 = self.beta * F.mean_squared_difference(z, Variable(e.data))  # beta * F.mean((z - e.data) ** 2), net.py:91
         core.report({'loss1': loss1, 'loss2': loss2, 'loss3': loss3,
                      'loss': loss1 + loss2 + loss3}, self)
         prepack.join()

@@ -72,24 +72,26 @@ class Adam(object):
         v = backend.zeros((n_train,), np.float32)
         layout = []
         off = 0
+        copies = []                           # (dst, src): issued together below (backend.copy_many)
         for n, p in train + shadow:
             view = params.flat_view(off, p.size, p.data.shape)
-            view.copy_from(p.data)            # from the old arena or from the parameter's own buffer
+            copies.append((view, p.data))     # from the old arena or from the parameter's own buffer
             p.data = view
             if not p._shadow:
                 slot = grads.flat_view(off, p.size, view.shape)
                 if p.grad is not None:        # gradient accumulated before adoption / re-layout
-                    slot.copy_from(p.grad.reshape(view.shape) if isinstance(p.grad, DeviceArray)
-                                   else p.grad.data.reshape(view.shape))
+                    copies.append((slot, p.grad.reshape(view.shape) if isinstance(p.grad, DeviceArray)
+                                   else p.grad.data.reshape(view.shape)))
                     p.grad = slot
                 p._grad_slot = slot
                 if n in old and old[n][0] + old[n][1] <= old_n_train:
                     o, sz = old[n]
-                    m.flat_view(off, sz).copy_from(old_m.flat_view(o, sz))
-                    v.flat_view(off, sz).copy_from(old_v.flat_view(o, sz))
+                    copies.append((m.flat_view(off, sz), old_m.flat_view(o, sz)))
+                    copies.append((v.flat_view(off, sz), old_v.flat_view(o, sz)))
             p._owner_step = self._step_count        # lets caches notice parameter updates
             layout.append((n, off, p.size))
             off += p.size
+        backend.copy_many(copies)
         self.params, self.grads, self.m, self.v = params, grads, m, v
         self._layout = layout
         self.n_train = n_train

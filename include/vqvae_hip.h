@@ -511,6 +511,11 @@ int vqvae_elementwise(int op, size_t n, const float* a, const float* b, float* o
 /* out[0] = scale * sum(x[0..n)) (deterministic two-stage); ws >= 4096 floats     */
 int vqvae_sum(const float* x, size_t n, float scale, float* out, void* ws,
               size_t ws_bytes, vqvae_stream_t s);
+/* out[0] = mean((a - b)^2) over n elements (net.py:90-91: codebook / commitment loss), with the roundings of the
+ * Variable-arithmetic chain it replaces (sub, square, two-stage sum); ws >= 4096 floats.  _bwd: ga = 2 (a - b) gloss[0] / n,
+ * gb = -ga (either may be NULL)                                                                              */
+int vqvae_sqdiff_mean(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, vqvae_stream_t s);
+int vqvae_sqdiff_mean_bwd(const float* a, const float* b, const float* gloss, size_t n, float* ga, float* gb, vqvae_stream_t s);
 
 /* ---- device-side input pipeline (the step right before the hot path; utils.py:18-23, 85-110).
  *      mulaw_bins: q[i] = MuLaw(mu).transform(x[i]) by searching host-computed thresholds
@@ -550,6 +555,9 @@ int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* 
 int vqvae_concat(float* dst, const float* const* srcs, int n, size_t count, vqvae_stream_t s);
 int vqvae_split(const float* src, float* const* dsts, int n, size_t count, int accumulate,
                 vqvae_stream_t s);
+/* dst[i][0 .. count[i]) = src[i][...] for n independent fp32 arrays (non-overlapping), 64 per launch: the arena adoption of
+ * a model's parameters without a copy dispatch per parameter                                                      */
+int vqvae_copy_list(int n, float* const* dst, const float* const* src, const size_t* count, vqvae_stream_t s);
 
 /* ---- chainer.optimizers.Adam update rule (train.py:101-102) over a flat arena:
  *      m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m/(sqrt(v)+eps)

@@ -1218,3 +1218,23 @@ def test_conv1d_pack_ahead_equals_inline_pack(gpu, mode):
     finally:
         gpu.set_f32x2_min_gflop(8.0)
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
+
+
+def test_mean_squared_difference_keeps_the_bits_of_the_arithmetic_chain(gpu):
+    """F.mean_squared_difference(a, b) (net.py:90-91 as one node) against F.mean((a - b) ** 2) built from Variable arithmetic:
+    the loss and both gradients bit for bit, also behind a scalar factor (beta * ...)."""
+    from vqvae_amd import functions as F
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(8)
+    for shape in [(3, 64, 120, 1), (16, 64, 120, 1), (2, 7, 5, 1)]:
+        a = rs.standard_normal(shape).astype(np.float32)
+        b = (a + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        out = []
+        for fused in (False, True):
+            va, vb = Variable(_dev(gpu, a)), Variable(_dev(gpu, b))
+            l = F.mean_squared_difference(va, vb) if fused else F.mean((va - vb) ** 2)
+            l = 0.25 * l
+            l.backward()
+            out.append((l.data.get().copy(), va.grad.get().copy(), vb.grad.get().copy()))
+        for x, y in zip(*out):
+            np.testing.assert_array_equal(x, y)
