@@ -443,9 +443,13 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__
 
 __global__ void xent_bwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ tg,
                                 const float* __restrict__ lse, const float* __restrict__ gloss,
-                                int B, int q, int T, float scale, float* __restrict__ gy) {
+                                int B, int q, int T, float scale, float* __restrict__ gy, uint32_t* __restrict__ amax_out) {
   const long total = (long)B * q * T;
   const float gs = (gloss ? gloss[0] : 1.f) * scale;
+  // |gy| = |softmax - onehot| |gs| <= |gs|: an upper bound is all a float32x2 scale needs, and this one is within a few 1e-3
+  // of the maximum (some position always has a small target probability) -- it saves the consumer a scan of 126 MB
+  if (amax_out != nullptr && blockIdx.x == 0 && threadIdx.x < 16)
+    amax_out[threadIdx.x] = threadIdx.x == 0 ? __float_as_uint(fmaxf(fabsf(gs) * 1.001f, 1e-30f)) : 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % T);
@@ -1162,13 +1166,17 @@ int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T
   return 0;
 }
 
-int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse, const float* gloss,
-                           int B, int q, int T, float* gy, vqvae_stream_t s) {
+int vqvae_softmax_xent_bwd_amax(const float* y, const int32_t* t, const float* lse, const float* gloss,
+                                int B, int q, int T, float* gy, uint32_t* amax_out, vqvae_stream_t s) {
   VQ_REQUIRE(y && t && lse && gy, "softmax_xent_bwd: null pointer");
   const size_t n = (size_t)B * q * T;
-  hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, y, t, lse, gloss, B, q, T, (float)(1.0 / ((double)B * T)), gy);
+  hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)s, y, t, lse, gloss, B, q, T, (float)(1.0 / ((double)B * T)), gy, amax_out);
   VQ_LAUNCH_CHECK();
   return 0;
+}
+int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse, const float* gloss,
+                           int B, int q, int T, float* gy, vqvae_stream_t s) {
+  return vqvae_softmax_xent_bwd_amax(y, t, lse, gloss, B, q, T, gy, nullptr, s);
 }
 
 int vqvae_mol_nll_fwd(const float* y, const float* t, int B, int n_mixture, int T, int quantize,
@@ -1212,6 +1220,41 @@ int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, floa
                  vqvae_stream_t s) {
   VQ_REQUIRE(idx && out && B > 0 && q > 0 && T > 0, "onehot: bad arguments");
   hipLaunchKernelGGL(onehot_kernel, dim3(grid_for((size_t)B * q * T, 256, 4096)), dim3(256), 0, (hipStream_t)s, idx, idx_bstride, B, q, T, out);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// An upper bound of max |y| of the embed conv over index input, from the weights alone: every output is b[co] plus ONE entry
+// of W[co, :, tap] per tap, so |y[., co, .]| <= |b[co]| + sum_tap max_q |W[co, q, tap]|.  16 waves, a wave per output channel
+// at a time (lanes along the contiguous (q, tap) axis).  What matmul mode 3 needs of the first gate GEMM's operand -- instead of
+// a scan of the (B, Cout, T) tensor (126 MB at configs[1]).
+__global__ __launch_bounds__(1024) void embed_bound_kernel(const float* __restrict__ W, const float* __restrict__ b, int Cout, int q, int K,
+                                                           uint32_t* __restrict__ amax_out) {
+  __shared__ float red[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float best = 0.f;
+  for (int co = wave; co < Cout; co += 16) {
+    const float* w = W + (long)co * q * K;
+    float bound = b ? fabsf(b[co]) : 0.f;
+    for (int tap = 0; tap < K; ++tap) {
+      float m = 0.f;
+      for (int i = lane; i < q; i += 64) m = fmaxf(m, fabsf(w[(long)i * K + tap]));
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      bound += m;
+    }
+    best = fmaxf(best, bound);
+  }
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float m = 0.f;
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+    amax_out[threadIdx.x] = threadIdx.x == 0 ? __float_as_uint(fmaxf(m * 1.001f, 1e-30f)) : 0u;
+  }
+}
+int vqvae_embed_gather_bound(const float* W, const float* b, int Cout, int q, int K, uint32_t* amax_out, vqvae_stream_t s) {
+  VQ_REQUIRE(W && amax_out && Cout > 0 && q > 0 && K >= 1, "embed_gather_bound: bad arguments");
+  hipLaunchKernelGGL(embed_bound_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, W, b, Cout, q, K, amax_out);
   VQ_LAUNCH_CHECK();
   return 0;
 }

@@ -163,6 +163,7 @@ PROTOTYPES = {
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
     'vqvae_onehot': (c_int, [P, c_long, c_int, c_int, c_int, P, P]),
     'vqvae_embed_gather_fwd': (c_int, [P, c_long, c_int, c_int, P, P, c_int, c_int, c_int, P, P]),
+    'vqvae_embed_gather_bound': (c_int, [P, P, c_int, c_int, c_int, P, P]),
     'vqvae_embed_onehot_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'vqvae_embed_onehot_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     'vqvae_embed_onehot_wgrad': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P,
@@ -178,6 +179,7 @@ PROTOTYPES = {
     'vqvae_softmax_xent_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vqvae_softmax_xent_fwd': (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     'vqvae_softmax_xent_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P]),
+    'vqvae_softmax_xent_bwd_amax': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P]),
     'vqvae_mol_nll_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
     'vqvae_mol_nll_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
     'vqvae_elementwise': (c_int, [c_int, c_size_t, P, P, P, c_float, c_float, P]),

@@ -535,8 +535,16 @@ class SoftmaxCrossEntropy(FunctionNode):
         y, t, lse = self._saved
         B, q, T = y.shape[:3]
         gy = DeviceArray(y.shape, np.float32)
-        _lib.call('vqvae_softmax_xent_bwd', y.ptr, t.ptr, lse.ptr, gys[0].data.ptr, B, q, T, gy.ptr,
-                  _S())
+        if _lib.load().vqvae_get_matmul_dtype() == 3:
+            # 'float32x2': the kernel also leaves an upper bound of max |gy| (|g| / (B T)) where the conv that reads gy
+            # looks for its operand's maximum -- no scan of the 126 MB gradient
+            am = DeviceArray((_lib.AMAX_SLOTS,), np.uint32)      # (every word is written by the kernel)
+            _lib.call('vqvae_softmax_xent_bwd_amax', y.ptr, t.ptr, lse.ptr, gys[0].data.ptr, B, q, T, gy.ptr,
+                      am.ptr, _S())
+            gy.amax = am
+        else:
+            _lib.call('vqvae_softmax_xent_bwd', y.ptr, t.ptr, lse.ptr, gys[0].data.ptr, B, q, T, gy.ptr,
+                      _S())
         return gy, None
 
 
@@ -611,6 +619,11 @@ class EmbedConvFromIndices(FunctionNode):
         Cout, q, K = W.shape[:3]
         y = DeviceArray((B, Cout, T, 1), np.float32)
         _lib.call('vqvae_embed_gather_fwd', idx.ptr, T, B, T, W.ptr, _p(b), Cout, q, K, y.ptr, _S())
+        if _lib.load().vqvae_get_matmul_dtype() == 3:
+            # 'float32x2': the first gate GEMM wants max |y|; a bound from the weights (one small launch) instead of a
+            # scan of the (B, Cout, T) tensor
+            y.amax = DeviceArray((_lib.AMAX_SLOTS,), np.uint32)
+            _lib.call('vqvae_embed_gather_bound', W.ptr, _p(b), Cout, q, K, y.amax.ptr, _S())
         self._saved = (idx, B, T, Cout, q, K, b is not None)
         return y,
 

@@ -483,6 +483,11 @@ int vqvae_softmax_xent_fwd(const float* y, const int32_t* t, int B, int q, int T
 int vqvae_softmax_xent_bwd(const float* y, const int32_t* t, const float* lse,
                            const float* gloss, int B, int q, int T, float* gy,
                            vqvae_stream_t s);
+/* the same, and amax_out (VQVAE_AMAX_SLOTS words, matmul mode 3) receives an upper bound of max |gy|: |*gloss| / (B*T), within
+ * a few 1e-3 of the maximum -- the conv that reads gy then needs no scan of it                                   */
+int vqvae_softmax_xent_bwd_amax(const float* y, const int32_t* t, const float* lse,
+                                const float* gloss, int B, int q, int T, float* gy, uint32_t* amax_out,
+                                vqvae_stream_t s);
 
 /* ---- WaveNet.calculate_logistic_loss (WaveNet/modules.py:169-230): discretised
  *      mixture-of-logistics NLL.  y (B, 3*n_mixture, T) = [logit_probs | means |
@@ -531,6 +536,11 @@ int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, floa
                  vqvae_stream_t s);
 int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, const float* W,
                            const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s);
+/*      embed_gather_bound: amax_out (VQVAE_AMAX_SLOTS words) = an upper bound of max |y| of embed_gather_fwd from the
+ *                  weights alone, max_co (|b[co]| + sum_tap max_q |W[co, q, tap]|): the scale of the first gate GEMM's
+ *                  operand in matmul mode 3 without a scan of y.                                               */
+int vqvae_embed_gather_bound(const float* W, const float* b, int Cout, int q, int K, uint32_t* amax_out,
+                             vqvae_stream_t s);
 /*      embed_onehot_fwd / _wgrad: the SAME conv applied to the reference's one-hot float input
  *                  x (B,q,T) (utils.py:85-87, modules.py:151-152).  fwd scans x on the device
  *                  (idx (B,T) int32 out; *flag = 1 iff every column is exactly one 1.0 and q-1 zeros),
