@@ -241,9 +241,12 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
     const float* __restrict__ gy, long gy_bstride, int B, int C, int Tin, int Tout,
     const float* __restrict__ w0, const float* __restrict__ w1, const int32_t* __restrict__ lo0,
     const int32_t* __restrict__ hi0, const int32_t* __restrict__ lo1,
-    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride, const uint32_t* __restrict__ scale) {
+    const int32_t* __restrict__ hi1, float* __restrict__ gx, long gx_bstride, const uint32_t* __restrict__ scale,
+    int L, long gy_lstride, long gx_lstride) {
+  // L > 1: the rows of L tensors in one launch (vqvae_upsample_linear_bwd_blocks: every block's gh of a ResidualNet at
+  // once); tensor l starts gy_lstride elements (of gy's element type) / gx_lstride floats behind tensor l - 1
   __shared__ float S[2][4][UPS_PITCH];       // [row parity][w0 lo, w0 hi, w1 lo, w1 hi][q + (q >> 4)]
-  const int tid = threadIdx.x, n4 = Tout >> 2, rows = B * C;
+  const int tid = threadIdx.x, n4 = Tout >> 2, rows = L * B * C;
   // phase-1 constants: weights and the lo / hi split point of this thread's column groups q = tid, tid + 1024
   float4 wa[2], wb[2];
   int ks[2];
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
 #define UPS_FETCH(V, R)                                                                        \
   {                                                                                            \
     const int rr_ = min((R), rows - 1);           /* past the end: re-read the last row, unused */ \
-    const long e_ = (long)(rr_ / C) * gy_bstride + (long)(rr_ % C) * Tout;                     \
+    const int lb_ = rr_ / C;                                                                   \
+    const long e_ = (long)(lb_ / B) * gy_lstride + (long)(lb_ % B) * gy_bstride + (long)(rr_ % C) * Tout; \
     const float* g_ = gy + e_;                                                                 \
     const unsigned short* h_ = reinterpret_cast<const unsigned short*>(gy) + e_;               \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
@@ -300,7 +304,8 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
   }
 #define UPS_ROW(V, PAR)                                                                        \
   {                                                                                            \
-    const int b = r / C, c = r % C;                                                            \
+    const int lb = r / C, c = r % C;                                                           \
+    const long gxo = (long)(lb / B) * gx_lstride + (long)(lb % B) * gx_bstride + (long)c * Tin; \
     float (*Sp)[UPS_PITCH] = S[PAR];                                                           \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                            \
       const int q = k * UPS_NT + tid;                                                          \
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(UPS_NT, 8) void upsample_bwd_seg_kernel(
       acc += __shfl_xor(acc, 1, 64);                                                           \
       acc += __shfl_xor(acc, 2, 64);                                                           \
       acc += __shfl_xor(acc, 4, 64);              /* w1-range sum + w0-range sum */            \
-      if (ok && (tid & 7) == 0) gx[(long)b * gx_bstride + (long)c * Tin + vi] = acc;           \
+      if (ok && (tid & 7) == 0) gx[gxo + vi] = acc;                                            \
     }                                                                                          \
     /* no second barrier: the next row writes the other parity, and nobody can reach the row after  \
        that (which overwrites this parity) before every thread has passed the next row's barrier */ \
@@ -1076,7 +1081,7 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
       ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0) {
     int nb = B * C;
     if (nb > 512) nb = 512;                      // persistent: 2 workgroups per CU
-    hipLaunchKernelGGL(upsample_bwd_seg_kernel<0>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr);
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel<0>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, gy, gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr, 1, 0L, 0L);
     VQ_LAUNCH_CHECK();
     return 0;
   }
@@ -1108,7 +1113,28 @@ int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C
              "upsample_bwd_bf16: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
   int nb = B * C;
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(upsample_bwd_seg_kernel<1>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr);
+  hipLaunchKernelGGL(upsample_bwd_seg_kernel<1>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr, 1, 0L, 0L);
+  VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// The pull-back of L equally shaped tensors in ONE launch (every block's gh of a ResidualNet once the chain has run: a launch
+// per block was 20-40 launches of ~30 us on data the chain had left in the Infinity Cache; this one streams them from HBM
+// at a higher rate and leaves the chain alone).  bf16 != 0: gy holds bf16 (2-byte elements, strides in those elements).
+int vqvae_upsample_linear_bwd_blocks(const void* gy, int bf16, long gy_lstride, long gy_bstride, int L, int B, int C, int Tin, int Tout,
+                                     const float* w0, const float* w1, const int32_t* lo0, const int32_t* hi0,
+                                     const int32_t* lo1, const int32_t* hi1, float* gx, long gx_lstride, long gx_bstride,
+                                     vqvae_stream_t s) {
+  VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx && L >= 1, "upsample_bwd_blocks: null pointer");
+  VQ_REQUIRE(Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 && gy_lstride % 4 == 0 &&
+             ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0 && (long)L * B * C < (1L << 31),
+             "upsample_bwd_blocks: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
+  long nb = (long)L * B * C;
+  if (nb > 512) nb = 512;
+  if (bf16)
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel<1>, dim3((unsigned)nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr, L, gy_lstride, gx_lstride);
+  else
+    hipLaunchKernelGGL(upsample_bwd_seg_kernel<0>, dim3((unsigned)nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, nullptr, L, gy_lstride, gx_lstride);
   VQ_LAUNCH_CHECK();
   return 0;
 }
@@ -1125,7 +1151,7 @@ int vqvae_upsample_linear_bwd_f16x2(const void* gy, long gy_bstride, int B, int 
              "upsample_bwd_f16x2: serves ratios >= 8 with Tout %% 4 == 0, Tout <= %d", 8 * UPS_NT);
   int nb = B * C;
   if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(upsample_bwd_seg_kernel<2>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, scale);
+  hipLaunchKernelGGL(upsample_bwd_seg_kernel<2>, dim3(nb), dim3(UPS_NT), 0, (hipStream_t)s, reinterpret_cast<const float*>(gy), gy_bstride, B, C, Tin, Tout, w0, w1, lo0, hi0, lo1, hi1, gx, gx_bstride, scale, 1, 0L, 0L);
   VQ_LAUNCH_CHECK();
   return 0;
 }

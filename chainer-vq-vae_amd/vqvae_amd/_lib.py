@@ -152,6 +152,7 @@ PROTOTYPES = {
     'vqvae_upsample_linear_fwd': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_long, P]),
     'vqvae_upsample_linear_bwd': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                           P, c_long, P]),
+    'vqvae_upsample_linear_bwd_blocks': (c_int, [P, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_long, c_long, P]),
     'vqvae_upsample_linear_bwd_bf16': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                P, c_long, P]),
     'vqvae_resblock_bf16_storage': (c_int, [C.POINTER(ResblockDesc)]),

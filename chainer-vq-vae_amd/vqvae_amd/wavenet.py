@@ -112,6 +112,7 @@ def _pack_stack(params, d0, nb, stream):
 
 FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
 DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
+BATCH_PULLBACK = os.environ.get('VQVAE_BATCH_PULLBACK', '1') != '0'
 PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
 # 'bfloat16' mode: the chain's tensors the caller may keep in HBM as bf16 (x_l, gh_l, g_res_l: vqvae_resblock_desc.storage) are
 # taken whenever the library offers them; VQVAE_BF16_STORAGE=0 leaves every one fp32 (operand rounding only: ADVICE r4)
@@ -337,6 +338,14 @@ class ResidualStackFunction(FunctionNode):
         if (f16 and lat is not None and self.packed is not None and FUSE_PULLBACK and d0.Cd == 256
                 and d0.T % 128 == 0 and d0.T >= 64 * Tl):
             pb_part = DeviceArray((nb, d0.B, d0.T // 128, d0.Cd, 4), np.float32)
+        # where the pull-back stays a kernel of its own (bf16 mode, float32x3, fp32 MFMA): ONE launch over all blocks' gh when
+        # the chain is done (vqvae_upsample_linear_bwd_blocks) instead of a launch per block -- the gh_l then are the
+        # slices of one array.  VQVAE_BATCH_PULLBACK=0: a launch per block, as before (same sums in the same order)
+        gh_all = None
+        if (BATCH_PULLBACK and pb_part is None and lat is not None and self.packed is not None and not overlap
+                and not (store & _lib.STORE_GH_F16X2) and Tl >= 3 and d0.T >= 8 * Tl and d0.T % 4 == 0 and d0.T // 4 <= 2048
+                and all((dd.B, dd.Cd, dd.T) == (d0.B, d0.Cd, d0.T) for dd in self.descs)):
+            gh_all = DeviceArray((nb, d0.B, d0.Cd, d0.T), np.float32)
         # side-stream scratch, sized once for everything it will run (never regrown mid-flight)
         # res-conv weight gradients: one batched launch on the MAIN stream after the chain (it
         # then overlaps with whatever the side stream still has queued); balances the two queues
@@ -436,7 +445,8 @@ class ResidualStackFunction(FunctionNode):
             gx = DeviceArray(h.shape, np.float32) if need_gx else None
             gp = [_grad_out(in_vars[2 + 8 * i + j], ins[2 + 8 * i + j].shape) for j in range(4)]
             g_ress[i] = g_res                  # None for the last block: residual unused
-            gh = DeviceArray((d.B, d.Cd, d.T), np.float32)
+            gh = (DeviceArray((d.B, d.Cd, d.T), np.float32) if gh_all is None else
+                  gh_all.flat_view(i * d.B * d.Cd * d.T, d.B * d.Cd * d.T, (d.B, d.Cd, d.T)))
             ws = _rb_workspace(d)
             if lat is not None:
                 # chain on the main stream: gz, gate derivative -> gh, then gx
@@ -465,8 +475,8 @@ class ResidualStackFunction(FunctionNode):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
-                if pb_part is not None:
-                    pass                       # done in the gate-derivative launch's epilogue; reduced below
+                if pb_part is not None or gh_all is not None:
+                    pass                       # done in the gate-derivative launch's epilogue and reduced below / one launch below
                 elif hpre:
                     _lib.call('vqvae_upsample_linear_bwd_f16x2', gh.ptr, d.Cd * d.T, d.B, d.Cd, Tl, d.T,
                               tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr,
@@ -504,6 +514,12 @@ class ResidualStackFunction(FunctionNode):
             backend.wait_event(_S(), backend.Event().record(side))
         if pb_part is not None:
             _lib.call('vqvae_pullback_reduce', pb_part.ptr, tb['v0'].ptr, nb, d.B, d.T, d.Cd, Tl, gP.ptr, _S())
+        elif gh_all is not None:
+            bf = 1 if store & _lib.STORE_GH_BF16 else 0
+            n = d.B * d.Cd * d.T
+            _lib.call('vqvae_upsample_linear_bwd_blocks', gh_all.ptr, bf, n * (2 if bf else 1), d.Cd * d.T, nb, d.B, d.Cd, Tl, d.T,
+                      tb['w0'].ptr, tb['w1'].ptr, tb['lo0'].ptr, tb['hi0'].ptr, tb['lo1'].ptr, tb['hi1'].ptr,
+                      gP.ptr, d.Cd * Tl, nb * d.Cd * Tl, _S())
         if lat is not None:
             # every block's gh has been pulled back to the latent rate (adjoint of the epilogue
             # lerp) on the side stream; the (nb*Cd, Cc) 1x1 conv's own backward then gives

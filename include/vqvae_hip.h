@@ -451,6 +451,13 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               const int32_t* lo0, const int32_t* hi0,
                               const int32_t* lo1, const int32_t* hi1,
                               float* gx, long gx_bstride, vqvae_stream_t s);
+/* the pull-back of L equally shaped tensors in one launch (ratios Tout >= 8 Tin only): tensor l starts gy_lstride elements
+ * behind tensor l - 1 (bf16 != 0: 2-byte elements), its result gx_lstride floats behind the previous one -- every block's gh
+ * of a ResidualNet once its backward chain has run, instead of a launch per block                                  */
+int vqvae_upsample_linear_bwd_blocks(const void* gy, int bf16, long gy_lstride, long gy_bstride, int L, int B, int C,
+                                     int Tin, int Tout, const float* w0, const float* w1, const int32_t* lo0,
+                                     const int32_t* hi0, const int32_t* lo1, const int32_t* hi1, float* gx,
+                                     long gx_lstride, long gx_bstride, vqvae_stream_t s);
 /* the same with gy stored as bf16 (VQVAE_STORE_GH_BF16; gy_bstride in elements): ratios Tout >= 8 Tin only */
 int vqvae_upsample_linear_bwd_bf16(const void* gy, long gy_bstride, int B, int C, int Tin,
                                    int Tout, const float* w0, const float* w1,
