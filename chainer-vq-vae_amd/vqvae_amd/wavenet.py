@@ -99,6 +99,25 @@ def _pack_key(params, d0):
             _lib.load().vqvae_get_matmul_dtype())
 
 
+def _build_cproj(params, nb, stream):
+    """The latent-rate condition projection of all blocks as ONE conv: its weight (nb * Cd, Cc, 1, 1) and its bias, which
+    also carries the dilated convs' biases (the lerp weights of a column sum to one, so they can ride in the projection:
+    vqvae_resblock_cproj::P_has_bd).  ``params``: 8 arrays per block (ResidualBlock.param_list order)."""
+    Cd, Cc = params[2].shape[0], params[2].shape[1]
+    Wc_all = DeviceArray((nb * Cd, Cc, 1, 1), np.float32)
+    bc_all = DeviceArray((nb * Cd,), np.float32)
+    bd_all = DeviceArray((nb * Cd,), np.float32)
+    for lo, hi in _groups(nb):
+        _lib.call('vqvae_concat', Wc_all.ptr + lo * Cd * Cc * 4, _lib.ptr_array([params[8 * i + 2] for i in range(lo, hi)]),
+                  hi - lo, Cd * Cc, stream)
+        _lib.call('vqvae_concat', bc_all.ptr + lo * Cd * 4, _lib.ptr_array([params[8 * i + 3] for i in range(lo, hi)]),
+                  hi - lo, Cd, stream)
+        _lib.call('vqvae_concat', bd_all.ptr + lo * Cd * 4, _lib.ptr_array([params[8 * i + 1] for i in range(lo, hi)]),
+                  hi - lo, Cd, stream)
+    _lib.call('vqvae_elementwise', 0, nb * Cd, bc_all.ptr, bd_all.ptr, bc_all.ptr, 1.0, 1.0, stream)
+    return Wc_all, bc_all, bd_all        # (bd_all: kept alive until the add has run)
+
+
 def _pack_stack(params, d0, nb, stream):
     """Every block's weight slabs (forward and backward forms) re-laid for this step (vqvae_resstack_pack)."""
     per = _lib.load().vqvae_resstack_packed_bytes(C.byref(d0))
@@ -162,29 +181,26 @@ class ResidualStackFunction(FunctionNode):
             self.lat = lat = cond.latent                       # (B, Cc, Tl)
             B, Cc, Tl = lat.shape
             Cd = inputs[2].shape[0]
-            self.Wc_all = DeviceArray((nb * Cd, Cc, 1, 1), np.float32)
-            bc_all = DeviceArray((nb * Cd,), np.float32)
-            bd_all = DeviceArray((nb * Cd,), np.float32)
-            for lo, hi in _groups(nb):
-                _lib.call('vqvae_concat', self.Wc_all.ptr + lo * Cd * Cc * 4,
-                          _lib.ptr_array([inputs[2 + 8 * i + 2] for i in range(lo, hi)]),
-                          hi - lo, Cd * Cc, _S())
-                _lib.call('vqvae_concat', bc_all.ptr + lo * Cd * 4,
-                          _lib.ptr_array([inputs[2 + 8 * i + 3] for i in range(lo, hi)]),
-                          hi - lo, Cd, _S())
-                _lib.call('vqvae_concat', bd_all.ptr + lo * Cd * 4,
-                          _lib.ptr_array([inputs[2 + 8 * i + 1] for i in range(lo, hi)]),
-                          hi - lo, Cd, _S())
-            # the dilated convs' biases ride in the projection's bias (the lerp weights of a column sum to one): the gate
-            # kernels then add no bias, and their condition term is one more step of the contraction
-            # (vqvae_resblock_cproj::P_has_bd / P_amax)
-            _lib.call('vqvae_elementwise', 0, nb * Cd, bc_all.ptr, bd_all.ptr, bc_all.ptr, 1.0, 1.0, _S())
+            self.cproj_shape = (B, Cc, Tl)
+            # the projection's weight / bias (the dilated convs' biases ride in the latter: the gate kernels then add no
+            # bias, and their condition term is one more step of the contraction -- vqvae_resblock_cproj::P_has_bd /
+            # P_amax) and its packed slabs: built on the side stream by ResidualNet.prepack_async when the step started, if
+            # the parameters are the ones it saw; else here
+            pre = self.prepacked
+            cp = pre[4] if (pre is not None and pre[0][0] == tuple(p.ptr for p in inputs[2:])) else None
+            self._cslab_b = None
+            if cp is not None:
+                self.Wc_all, bc_all = cp[0], cp[1]
+                slab_f, self._cslab_b = (cp[3], cp[4]) if cp[5] == (B, Cc, Tl) else (None, None)
+            else:
+                self.Wc_all, bc_all, _bd = _build_cproj(inputs[2:], nb, _S())
+                slab_f = None
             self.pdesc = _lib.Conv1dDesc(B, Cc, Tl, nb * Cd, Tl, 1, 1, 0, 1, 0)
             P_all = DeviceArray((B, nb * Cd, Tl), np.float32)
             P_amax = backend.new_amax()
             ws = backend.workspace(_lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))
             _lib.call('vqvae_conv1d_fwd_amax', C.byref(self.pdesc), lat.ptr, self.Wc_all.ptr, bc_all.ptr,
-                      P_all.ptr, ws.ptr, ws.nbytes, C.byref(_lib.Conv1dAmax(None, None, P_amax.ptr)), _S())
+                      P_all.ptr, ws.ptr, ws.nbytes, C.byref(_lib.Conv1dAmax(None, None, P_amax.ptr, _p(slab_f))), _S())
             tb = F.resize_tables(Tl, x.shape[2])
         self.packed = None
         self.amax = None
@@ -530,8 +546,9 @@ class ResidualStackFunction(FunctionNode):
             # for; the projection's own weight gradient is a leaf -- on the side stream behind the other deferred ones
             if 1 in indexes:
                 glat = DeviceArray(lat.shape, np.float32)
-                _lib.call('vqvae_conv1d_bwd_data', C.byref(self.pdesc), self.Wc_all.ptr, gP.ptr,
-                          glat.ptr, 0, wsc.ptr, wsc.nbytes, _S())
+                _lib.call('vqvae_conv1d_bwd_data_amax', C.byref(self.pdesc), self.Wc_all.ptr, gP.ptr,
+                          glat.ptr, 0, wsc.ptr, wsc.nbytes,
+                          C.byref(_lib.Conv1dAmax(None, None, None, _p(getattr(self, '_cslab_b', None)))), _S())
                 grads[1] = F.LatentGrad(cond.shape, glat)
             sw, wsw = _S(), wsc
             if defer:
@@ -631,7 +648,10 @@ class ResidualNet(ChainList):
         for b in blocks:
             args += b.param_list()
         pre, self._prepacked = getattr(self, '_prepacked', None), None
-        return ResidualStackFunction([b.dilation for b in blocks], relu_out=relu, prepacked=pre).apply(args)[0]
+        fn = ResidualStackFunction([b.dilation for b in blocks], relu_out=relu, prepacked=pre)
+        out = fn.apply(args)[0]
+        self._cproj_shape = getattr(fn, 'cproj_shape', None)     # (B, Cc, Tl) of the latent-rate projection: the next prepack_async packs for it
+        return out
 
     def prepack_async(self, B, T):
         """The chain's weight slabs for an upcoming forward over (B, ., T), packed on the SIDE stream now -- VAE.__call__ calls
@@ -649,7 +669,24 @@ class ResidualNet(ChainList):
         side = backend.side_stream()
         backend.wait_event(side, backend.Event().record(_S()))       # the optimizer's last write of the parameters
         packed, per = _pack_stack(params, d0, len(blocks), side)
-        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side))
+        # ... and, when the last forward projected the condition at the latent rate, that projection's weight / bias
+        # (three concats and an add over the blocks' parameters) and its packed slabs for both directions
+        cp, shape = None, getattr(self, '_cproj_shape', None)
+        if shape is not None:
+            nb, Cd = len(blocks), Wc.shape[0]
+            Wc_all, bc_all, bd_all = _build_cproj(params, nb, side)
+            slab_f = slab_b = None
+            if shape[0] == B and shape[1] == Wc.shape[1]:
+                lib = _lib.load()
+                descs = (_lib.Conv1dDesc * 2)()
+                for i in range(2):
+                    C.pointer(descs[i])[0] = _lib.Conv1dDesc(B, shape[1], shape[2], nb * Cd, shape[2], 1, 1, 0, 1, 0)
+                slab_f = DeviceArray((int(lib.vqvae_conv1d_packed_bytes(C.byref(descs[0]), 0)) // 4,), np.float32)
+                slab_b = DeviceArray((int(lib.vqvae_conv1d_packed_bytes(C.byref(descs[1]), 1)) // 4,), np.float32)
+                _lib.call('vqvae_conv1d_pack', 2, descs, (C.c_void_p * 2)(Wc_all.ptr, Wc_all.ptr), (C.c_int * 2)(0, 1),
+                          (C.c_void_p * 2)(slab_f.ptr, slab_b.ptr), side)
+            cp = (Wc_all, bc_all, bd_all, slab_f, slab_b, tuple(shape) if slab_f is not None else None)
+        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side), cp)
 
 
 class WaveNet(Chain):

@@ -543,7 +543,8 @@ def test_prepacked_conv_slabs_give_the_same_step_bitwise(gpu, min_gflop):
     """prepack.py: from the second step on, VAE.__call__ packs the weight slabs of the step's generic convs (encoder,
     condition embed, proj1 / proj2; forward and backward-data forms) on the side stream in a few batched launches
     (vqvae_conv1d_pack) and every conv finds its slab ready (vqvae_conv1d_amax::packed).  The same pack kernels write the
-    same slabs, so losses, parameters and Adam moments are bit-identical to the step that packs in line -- eager and
+    same slabs (ResidualNet.prepack_async likewise: the chain's slabs and the latent-rate condition projection's weight, bias
+    and slabs), so losses, parameters and Adam moments are bit-identical to the step that packs in line -- eager and
     recorded, with every conv on the three-product kernels (threshold 0: format-3 slabs + their maxima) and at the
     default threshold -- and the slabs really are used (every lookup of steps 2.. hits)."""
     import vqvae_amd as V
@@ -554,9 +555,12 @@ def test_prepacked_conv_slabs_give_the_same_step_bitwise(gpu, min_gflop):
     backend.set_f32x2_min_gflop(min_gflop)
     enabled = prepack.ENABLED
     try:
+        import vqvae_amd.wavenet as wn
+
         def run(on, graph):
             prepack.reset()
             prepack.ENABLED = on
+            wn.PREPACK_ASYNC = on          # (ResidualNet.prepack_async: the chain's slabs, the condition projection's weight / bias / slabs)
             _, model = H.build_model(cfg, seed=9)
             model.to_gpu()
             opt = Adam(2e-4)
@@ -594,5 +598,6 @@ def test_prepacked_conv_slabs_give_the_same_step_bitwise(gpu, min_gflop):
                     assert h == (n, 0, n, n), got[4]
     finally:
         prepack.ENABLED = enabled
+        wn.PREPACK_ASYNC = True
         prepack.reset()
         backend.set_f32x2_min_gflop(8.0)
