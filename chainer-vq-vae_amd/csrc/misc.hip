@@ -1251,36 +1251,37 @@ int vqvae_onehot(const int32_t* idx, long idx_bstride, int B, int q, int T, floa
 }
 
 // An upper bound of max |y| of the embed conv over index input, from the weights alone: every output is b[co] plus ONE entry
-// of W[co, :, tap] per tap, so |y[., co, .]| <= |b[co]| + sum_tap max_q |W[co, q, tap]|.  16 waves, a wave per output channel
-// at a time (lanes along the contiguous (q, tap) axis).  What matmul mode 3 needs of the first gate GEMM's operand -- instead of
+// of W[co, :, tap] per tap, so |y[., co, .]| <= |b[co]| + sum_tap max_q |W[co, q, tap]|.  A wave per output channel
+// (lanes along q).  What matmul mode 3 needs of the first gate GEMM's operand -- instead of
 // a scan of the (B, Cout, T) tensor (126 MB at configs[1]).
-__global__ __launch_bounds__(1024) void embed_bound_kernel(const float* __restrict__ W, const float* __restrict__ b, int Cout, int q, int K,
-                                                           uint32_t* __restrict__ amax_out) {
-  __shared__ float red[16];
+__global__ __launch_bounds__(256) void embed_bound_kernel(const float* __restrict__ W, const float* __restrict__ b, int Cout, int q, int K,
+                                                          uint32_t* __restrict__ amax_out) {
+  // a wave per output channel (lanes along q), four channels per workgroup; amax_out was zeroed by the caller
+  __shared__ float red[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float best = 0.f;
-  for (int co = wave; co < Cout; co += 16) {
+  const int co = blockIdx.x * 4 + wave;
+  float bound = 0.f;
+  if (co < Cout) {
     const float* w = W + (long)co * q * K;
-    float bound = b ? fabsf(b[co]) : 0.f;
+    bound = b ? fabsf(b[co]) : 0.f;
     for (int tap = 0; tap < K; ++tap) {
       float m = 0.f;
       for (int i = lane; i < q; i += 64) m = fmaxf(m, fabsf(w[(long)i * K + tap]));
       for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
       bound += m;
     }
-    best = fmaxf(best, bound);
   }
-  if (lane == 0) red[wave] = best;
+  if (lane == 0) red[wave] = bound;
   __syncthreads();
-  if (threadIdx.x < 16) {
-    float m = 0.f;
-    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
-    amax_out[threadIdx.x] = threadIdx.x == 0 ? __float_as_uint(fmaxf(m * 1.001f, 1e-30f)) : 0u;
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(amax_out + (blockIdx.x & 15), __float_as_uint(fmaxf(m * 1.001f, 1e-30f)));
   }
 }
 int vqvae_embed_gather_bound(const float* W, const float* b, int Cout, int q, int K, uint32_t* amax_out, vqvae_stream_t s) {
   VQ_REQUIRE(W && amax_out && Cout > 0 && q > 0 && K >= 1, "embed_gather_bound: bad arguments");
-  hipLaunchKernelGGL(embed_bound_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, W, b, Cout, q, K, amax_out);
+  VQ_CHECK_HIP(hipMemsetAsync(amax_out, 0, 16 * sizeof(uint32_t), (hipStream_t)s));
+  hipLaunchKernelGGL(embed_bound_kernel, dim3((Cout + 3) / 4), dim3(256), 0, (hipStream_t)s, W, b, Cout, q, K, amax_out);
   VQ_LAUNCH_CHECK();
   return 0;
 }
