@@ -47,6 +47,27 @@ __global__ void vq_wnorm_elt_kernel(const float* __restrict__ W, int k, int d, f
   atomicMax(wmax_bits + 1, __float_as_int(m));
 }
 
+// the same values in the same order (s = fma(w_c, w_c, s), c ascending), rows arriving coalesced through LDS: a thread per code
+// reading its row from global memory was 64 cache lines per wave instruction and 20 us for the training shape's 512 x 64
+// codebook, in front of the quantiser on the step's critical path.  64 codes per workgroup, dynamic LDS 64 (d + 1) floats.
+__global__ __launch_bounds__(64) void vq_wnorm_elt_lds_kernel(const float* __restrict__ W, int k, int d, float* wn, int* wmax_bits) {
+  extern __shared__ float wn_tile[];
+  const int j0 = blockIdx.x * 64, pitch = d + 1;
+  const int nj = min(64, k - j0);
+  for (int i = threadIdx.x; i < nj * d; i += 64) {
+    const int r = i / d, c = i - r * d;
+    wn_tile[r * pitch + c] = W[(long)j0 * d + i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= nj) return;
+  const float* w_ = wn_tile + threadIdx.x * pitch;
+  float s = 0.f, m = 0.f;
+  for (int c = 0; c < d; ++c) { const float w = w_[c]; s = fmaf(w, w, s); m = fmaxf(m, fabsf(w)); }
+  wn[j0 + threadIdx.x] = s;
+  atomicMax(wmax_bits, __float_as_int(s));
+  atomicMax(wmax_bits + 1, __float_as_int(m));
+}
+
 // block: NW wavefronts, each owning 32 latent columns; Zs[d][32*NW], Ws[32][d+1]
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void vq_mfma_kernel(
@@ -995,7 +1016,8 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     // mode 3: three fp16 products (VQVAE_VQ_X2=0: mode 2's six bf16 products, the A/B alternate)
     static const int x2_on = getenv("VQVAE_VQ_X2") ? atoi(getenv("VQVAE_VQ_X2")) : 1;
     const bool x2 = x2_on && (d == 64 || d == 128) && vqvae_get_matmul_dtype() == 3;
-    if (x2) hipLaunchKernelGGL(vq_wnorm_elt_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
+    if (x2 && d <= 240) hipLaunchKernelGGL(vq_wnorm_elt_lds_kernel, dim3(cdiv(k, 64)), dim3(64), (size_t)64 * (d + 1) * 4, st, W, k, d, wn, wmax_bits);
+    else if (x2) hipLaunchKernelGGL(vq_wnorm_elt_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     else hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
     if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() >= 2) {      // modes 2 and 3: the sweep on the 16-bit matrix pipe
@@ -1062,9 +1084,20 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
       VQ_LAUNCH_CHECK();
       list = overflow; nlist = noverflow;
     }
-    {
+    if (N > 8192) {
       // exact re-check of the queued rows, 8 rows per workgroup pass
       constexpr int R = 8;
+      const size_t lds2 = ((size_t)R * d + 256 * 33 + 512) * 4;
+      VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_exact_batched_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const long maxb = (N + R - 1) / R;
+      unsigned g2 = (unsigned)(maxb < 2048 ? maxb : 2048);
+      hipLaunchKernelGGL(vq_exact_batched_kernel<R>, dim3(g2), dim3(256), lds2, st, z, W, B, d, T, k, list, nlist, idx);
+      VQ_LAUNCH_CHECK();
+    } else {
+      // the training shapes (a few thousand rows, a few dozen of them queued): the launch is one workgroup's chain of 64 d
+      // dependent roundings per row set -- two rows per workgroup spread it over four times the workgroups (38 -> ~12 us at
+      // configs[1], in front of the condition embed); the per-row arithmetic, hence the index, is the same
+      constexpr int R = 2;
       const size_t lds2 = ((size_t)R * d + 256 * 33 + 512) * 4;
       VQ_CHECK_HIP(hipFuncSetAttribute((const void*)vq_exact_batched_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       const long maxb = (N + R - 1) / R;
