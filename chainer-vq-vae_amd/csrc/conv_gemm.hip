@@ -4571,13 +4571,35 @@ extern "C" size_t vqvae_resstack_workspace_bytes(const vqvae_resblock_desc* d, i
   return m * sizeof(float) + 1024 + MAXSEG * AMAX_SLOTS * sizeof(unsigned);     // (+ the weights' maxima of a float32x2 skip sum)
 }
 
+// stage: 1 = pack the slabs / sum the biases into ws only (vqvae_resstack_skip_prepare), 2 = the GEMM only, over a ws that was
+// prepared (vqvae_resstack_skip_fwd_prepared), 3 = both (vqvae_resstack_skip_fwd)
+static int resstack_skip_impl(const vqvae_resblock_desc* d, int nblocks, const float* const* Ws, const float* const* bs,
+                              const float* const* z, float* skip, int accumulate, int relu, void* ws, size_t ws_bytes,
+                              uint32_t* skip_amax_out, vqvae_stream_t s, int stage);
 extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                                        const float* const* Ws, const float* const* bs,
                                        const float* const* z, float* skip, int accumulate, int relu,
                                        void* ws, size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s) {
+  VQ_REQUIRE(Ws && bs && z && skip, "resstack_skip_fwd: null pointer");
+  return resstack_skip_impl(d, nblocks, Ws, bs, z, skip, accumulate, relu, ws, ws_bytes, skip_amax_out, s, 3);
+}
+extern "C" int vqvae_resstack_skip_prepare(const vqvae_resblock_desc* d, int nblocks, const float* const* Ws,
+                                           const float* const* bs, void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(Ws && bs, "resstack_skip_prepare: null pointer");
+  return resstack_skip_impl(d, nblocks, Ws, bs, nullptr, nullptr, 0, 0, ws, ws_bytes, nullptr, s, 1);
+}
+extern "C" int vqvae_resstack_skip_fwd_prepared(const vqvae_resblock_desc* d, int nblocks, const float* const* z, float* skip,
+                                                int accumulate, int relu, const void* ws, size_t ws_bytes,
+                                                uint32_t* skip_amax_out, vqvae_stream_t s) {
+  VQ_REQUIRE(z && skip, "resstack_skip_fwd_prepared: null pointer");
+  return resstack_skip_impl(d, nblocks, nullptr, nullptr, z, skip, accumulate, relu, const_cast<void*>(ws), ws_bytes, skip_amax_out, s, 2);
+}
+static int resstack_skip_impl(const vqvae_resblock_desc* d, int nblocks, const float* const* Ws, const float* const* bs,
+                              const float* const* z, float* skip, int accumulate, int relu, void* ws, size_t ws_bytes,
+                              uint32_t* skip_amax_out, vqvae_stream_t s, int stage) {
   if (int e = check_rb(d)) return e;
   VQ_REQUIRE(nblocks >= 1 && nblocks <= MAXSEG, "resstack_skip_fwd: 1..%d blocks", MAXSEG);
-  VQ_REQUIRE(Ws && bs && z && skip && ws, "resstack_skip_fwd: null pointer");
+  VQ_REQUIRE(ws, "resstack_skip_fwd: null pointer");
   if (ws_bytes < vqvae_resstack_workspace_bytes(d, nblocks)) { set_error("resstack_skip_fwd: workspace too small"); return VQVAE_E_WORKSPACE; }
   hipStream_t st = (hipStream_t)s;
   const int Ch = d->Cd / 2, T = d->T;
@@ -4588,16 +4610,19 @@ extern "C" int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks
   // (one per block, behind the bias sums) have to be found
   const bool f16 = g_matmul_dtype == 3;
   unsigned* wam = reinterpret_cast<unsigned*>(bsum + pad128(d->Cs));
-  PackArgs pa; pa.njob = 0;
-  PtrList bl;
-  for (int l = 0; l < nblocks; ++l) {
-    pa.job[pa.njob] = pack_fwd_job(w + (size_t)l * rp * ld, Ws[l], d->Cs, Ch, 1, 0, ld, 0, ld);
-    pa.job[pa.njob++].amax = f16 ? wam + l * AMAX_SLOTS : nullptr;
-    bl.p[l] = bs[l];
+  if (stage & 1) {
+    PackArgs pa; pa.njob = 0;
+    PtrList bl;
+    for (int l = 0; l < nblocks; ++l) {
+      pa.job[pa.njob] = pack_fwd_job(w + (size_t)l * rp * ld, Ws[l], d->Cs, Ch, 1, 0, ld, 0, ld);
+      pa.job[pa.njob++].amax = f16 ? wam + l * AMAX_SLOTS : nullptr;
+      bl.p[l] = bs[l];
+    }
+    if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
+    hipLaunchKernelGGL(bias_sum_list_kernel, dim3(cdiv(d->Cs, 256)), dim3(256), 0, st, bl, nblocks, d->Cs, bsum);
+    VQ_LAUNCH_CHECK();
   }
-  if (int e = launch_pack(pa, st, f16 ? 3 : -1)) return e;
-  hipLaunchKernelGGL(bias_sum_list_kernel, dim3(cdiv(d->Cs, 256)), dim3(256), 0, st, bl, nblocks, d->Cs, bsum);
-  VQ_LAUNCH_CHECK();
+  if (!(stage & 2)) return 0;
   GemmArgs g; memset(&g, 0, sizeof(g));
   g.nseg = nblocks;
   for (int l = 0; l < nblocks; ++l) {

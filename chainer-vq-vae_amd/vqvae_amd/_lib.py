@@ -135,6 +135,8 @@ PROTOTYPES = {
     'vqvae_resstack_workspace_bytes': (c_size_t, [C.POINTER(ResblockDesc), c_int]),
     'vqvae_resstack_skip_fwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, PP, P, c_int, c_int, P,
                                         c_size_t, P, P]),
+    'vqvae_resstack_skip_prepare': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_size_t, P]),
+    'vqvae_resstack_skip_fwd_prepared': (c_int, [C.POINTER(ResblockDesc), c_int, PP, P, c_int, c_int, P, c_size_t, P, P]),
     'vqvae_conv1d_bwd_data_relu': (c_int, [C.POINTER(Conv1dDesc), P, P, P, P, P, c_size_t, C.POINTER(Conv1dAmax), P]),
     'vqvae_resstack_gcond_bwd': (c_int, [C.POINTER(ResblockDesc), c_int, PP, PP, P, c_int, P,
                                          c_size_t, P]),

@@ -219,9 +219,11 @@ class ResidualStackFunction(FunctionNode):
             # every block's weight slabs (forward and backward forms), re-laid once for this step
             d0 = _rb_desc(x, cond, inputs[2], inputs[8], self.dilations[0])
             pre = self.prepacked
+            self._skipws = None
             if pre is not None and pre[0] == _pack_key(inputs[2:], d0):
                 # packed on the side stream while the encoder / quantiser / condition embed ran (ResidualNet.prepack_async)
                 self.packed, self.packed_stride = pre[1], pre[2]
+                self._skipws = pre[5]            # ... and the skip sum's slabs / bias sums (vqvae_resstack_skip_prepare)
             else:
                 self.packed, self.packed_stride = _pack_stack(inputs[2:], d0, nb, _S())
         for i, dil in enumerate(self.dilations):
@@ -276,12 +278,17 @@ class ResidualStackFunction(FunctionNode):
         skip = DeviceArray((d.B, d.Cs, d.T, 1), np.float32)
         if self.amax is not None:
             skip.amax = backend.new_amax()       # published by the skip sum's epilogue: the next conv's operand scale
+        skipws = getattr(self, '_skipws', None)
         for lo, hi in _groups(nb):
             n = hi - lo
+            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
+            if skipws is not None and n == nb:       # slabs and bias sums were prepared ahead (prepack_async): the GEMM only
+                _lib.call('vqvae_resstack_skip_fwd_prepared', C.byref(d), n, zs, skip.ptr, 0, 1 if self.relu_out else 0,
+                          skipws.ptr, skipws.nbytes, _p(skip.amax), _S())
+                continue
             ws = backend.workspace(_lib.load().vqvae_resstack_workspace_bytes(C.byref(d), n))
             Ws = _lib.ptr_array([inputs[2 + 8 * i + 6] for i in range(lo, hi)])
             bs = _lib.ptr_array([inputs[2 + 8 * i + 7] for i in range(lo, hi)])
-            zs = _lib.ptr_array([self.saved[i][2] for i in range(lo, hi)])
             _lib.call('vqvae_resstack_skip_fwd', C.byref(d), n, Ws, bs, zs, skip.ptr,
                       0 if lo == 0 else 1, 1 if (self.relu_out and hi == nb) else 0, ws.ptr, ws.nbytes, _p(skip.amax), _S())
         skip.relu_out = self.relu_out
@@ -686,7 +693,15 @@ class ResidualNet(ChainList):
                 _lib.call('vqvae_conv1d_pack', 2, descs, (C.c_void_p * 2)(Wc_all.ptr, Wc_all.ptr), (C.c_int * 2)(0, 1),
                           (C.c_void_p * 2)(slab_f.ptr, slab_b.ptr), side)
             cp = (Wc_all, bc_all, bd_all, slab_f, slab_b, tuple(shape) if slab_f is not None else None)
-        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side), cp)
+        # ... and the skip sum's weight slabs and bias sums (one contraction over all blocks: vqvae_resstack_skip_prepare)
+        skipws = None
+        if len(blocks) <= _lib.MAX_STACK_GROUP:
+            nbytes = _lib.load().vqvae_resstack_workspace_bytes(C.byref(d0), len(blocks))
+            skipws = DeviceArray((int(nbytes) // 4 + 1,), np.float32)
+            _lib.call('vqvae_resstack_skip_prepare', C.byref(d0), len(blocks),
+                      _lib.ptr_array([params[8 * i + 6] for i in range(len(blocks))]),
+                      _lib.ptr_array([params[8 * i + 7] for i in range(len(blocks))]), skipws.ptr, skipws.nbytes, side)
+        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side), cp, skipws)
 
 
 class WaveNet(Chain):

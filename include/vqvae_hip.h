@@ -389,6 +389,14 @@ int vqvae_resstack_skip_fwd(const vqvae_resblock_desc* d, int nblocks,
                             const float* const* Ws, const float* const* bs,
                             const float* const* z, float* skip, int accumulate, int relu, void* ws,
                             size_t ws_bytes, uint32_t* skip_amax_out, vqvae_stream_t s);
+/* the same in two halves: _prepare re-lays the skip weights and sums the biases into ws (parameters only: a caller may run
+ * it ahead, on another stream, as soon as the optimizer is done), _fwd_prepared runs the GEMM over a ws so prepared for the
+ * same desc, nblocks and matmul mode                                                                               */
+int vqvae_resstack_skip_prepare(const vqvae_resblock_desc* d, int nblocks, const float* const* Ws,
+                                const float* const* bs, void* ws, size_t ws_bytes, vqvae_stream_t s);
+int vqvae_resstack_skip_fwd_prepared(const vqvae_resblock_desc* d, int nblocks, const float* const* z, float* skip,
+                                     int accumulate, int relu, const void* ws, size_t ws_bytes,
+                                     uint32_t* skip_amax_out, vqvae_stream_t s);
 /*      relu != 0: skip = max(skip (+ old skip), 0) -- WaveNet's F.relu(resnet(...)) (modules.py:158) in this epilogue; with
  *      more than one group of blocks pass it with the LAST group only                                                   */
 int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
