@@ -20,10 +20,14 @@ a "step" is one nearest-codebook search + gather over N latent rows; the line
 reports the expansion-form MFMA rate and the algorithmic HBM GB/s side by side.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- the dominant kernel (ResidualBlock forward: dilated conv +
-                  condition projection + gate, MFMA fp32), algorithmic FLOPs per
-                  launch / average launch time measured with HIP events on the
-                  launch stream during the timed steps.
+  roofline     -- the north star's kernel (ResidualBlock forward: dilated conv +
+                  condition step + gate): algorithmic FLOPs per launch / its mean
+                  launch time from the dispatch's own HIP events.  It is no longer
+                  the largest consumer of the step: roofline.kernels lists EVERY
+                  kernel family of ResidualNet's chain (gate, res 1x1, skip sum,
+                  gate derivative, backward-data, both weight-gradient families)
+                  with launches per step, mean launch time, algorithmic work per
+                  launch, its bound (mfma / hbm) and fraction, sorted by time per step.
   cpu_baseline -- the NumPy oracle (a port of the Chainer-CPU algorithm) timed on
                   this box's host cores on a bounded sample (N=1, rank 0 only).
 """
@@ -43,7 +47,7 @@ CFG = dict(d=64, k=512, n_loop=2, n_layer=10, filter_size=2, input_dim=256, quan
            length=7680, beta=0.25, lr=2e-4, ema_mu=0.9999, batch_per_gpu=16)
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md chip table
 
-# The dominant kernel and what one launch of it computes.  While the
+# The north star's kernel (`roofline`) and what one launch of it computes.  While the
 # residual 1x1 conv is a separate launch the extra term is 0.
 ROOFLINE_KERNEL = ('conv_gemm_kernel<EPI_GATE> (ResidualBlock fwd: dilated causal conv k=2 as MFMA GEMM '
                    '+ latent-rate condition lerp + tanh*sigmoid gate)')
@@ -69,6 +73,75 @@ PRODUCTS_PER_FP32 = {'float32x3': 6, 'float32x2': 3}     # 16-bit MFMA products 
 
 def FUSED_RES_FLOP_PER_POS(cfg):
     return 0.0
+
+
+def kernel_roofline_table(upd, backend, cfg, B, mode, k_eager):
+    """SURVEY 8(d) for every kernel family of ResidualNet's chain, not only the gate kernel: `k_eager` eager steps of the
+    same job with the library's per-launch profiler on for every chain tag (dispatch events for the GEMM launches,
+    stream events around a weight-gradient launch and its fixed-order reduce), then per family: launches per step, mean
+    launch time, ALGORITHMIC work per launch (family total per step / launches per step, so a family whose launches
+    differ -- the first / last block -- is averaged, not idealised), the roofline that bounds it and the fraction.
+    Runs outside the timed region."""
+    import ctypes as C
+    from vqvae_amd import _lib
+    lib = _lib.load()
+    T = cfg['length']
+    N = float(B * T)
+    nb = cfg['n_loop'] * cfg['n_layer']
+    Cr, Cd, Cs, Kf = cfg['residual'], cfg['dilated'], cfg['skip'], cfg['filter_size']
+    Ch = Cd // 2
+    mfma_peak = (PEAK_BF16_MFMA_TFLOPS / PRODUCTS_PER_FP32[mode]) if mode in PRODUCTS_PER_FP32 else PEAK_FP32_MFMA_TFLOPS
+    fam = [
+        # (name, tag, bound, family total per step [FLOP or bytes], what the total is)
+        ('ResidualBlock fwd: dilated conv + condition step + gate (conv_gemm_x3_kernel<EPI_GATE>)', _lib.PROF_RESBLOCK_GATE, 'mfma',
+         nb * 2.0 * N * Cd * Cr * Kf, 'n_blocks * 2 N Cd Cr K'),
+        ('ResidualBlock fwd: res 1x1 + residual add (lin128_stream_kernel)', _lib.PROF_RESBLOCK_OUT, 'hbm',
+         (nb - 1) * 4.0 * N * (Ch + Cr + Cr), '(n_blocks - 1) * 4 N (Ch + Cr + Cr): z and x_l read, x_{l+1} written'),
+        ('ResidualNet fwd: skip sum over all blocks as one GEMM (conv_gemm_x3_kernel<EPI_LINEAR>)', _lib.PROF_RESSTACK_SKIP, 'mfma',
+         2.0 * N * Cs * Ch * nb, '2 N Cs Ch n_blocks'),
+        ('ResidualBlock bwd: gz = Wr^T g_res + Ws^T g_skip, gate derivative -> gh, latent pull-back (conv_gemm_x3_kernel<EPI_GATE_BWD>)',
+         _lib.PROF_RESBLOCK_BWD_GZ, 'hbm',
+         4.0 * N * (nb * (Cs + Ch + Ch + Cd) + (nb - 1) * Cr),
+         '4 N (n_blocks (Cs + Ch + Ch + Cd) + (n_blocks - 1) Cr): g_skip, sigmoid, z read, gh written; g_res read by all but the last block'),
+        ('ResidualBlock bwd: backward-data of the dilated conv + g_res (conv_gemm_x3_kernel<EPI_LINEAR>, two taps)', _lib.PROF_RESBLOCK_BWD_GX, 'mfma',
+         nb * 2.0 * N * Cr * Cd * Kf, 'n_blocks * 2 N Cr Cd K'),
+        ('ResidualNet bwd: weight gradients of the dilated convs, several blocks per launch, incl. the fixed-order reduce (wgrad3_kernel)',
+         _lib.PROF_WGRAD_DIL, 'mfma', nb * 2.0 * N * Cd * Cr * Kf, 'n_blocks * 2 N Cd Cr K'),
+        ('ResidualNet bwd: weight gradients of the res / skip 1x1 convs, incl. the reduce (wgrad3_kernel)', _lib.PROF_WGRAD_RES_SKIP, 'mfma',
+         (2 * nb - 1) * 2.0 * N * Cr * Ch, '(2 n_blocks - 1) * 2 N 256 Ch'),
+    ]
+    mask = 0
+    for f in fam:
+        mask |= 1 << f[1]
+    lib.vqvae_prof_reset()
+    lib.vqvae_prof_enable(mask)
+    t0 = time.perf_counter()
+    for _ in range(k_eager):
+        upd.update()
+    backend.synchronize()
+    ms_step = 1e3 * (time.perf_counter() - t0) / k_eager
+    lib.vqvae_prof_enable(0)
+    rows = []
+    for name, tag, bound, total, what in fam:
+        tot, cnt = C.c_double(0), C.c_int(0)
+        _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
+        if not cnt.value:
+            continue
+        per_step = cnt.value / float(k_eager)
+        avg_ms = tot.value / cnt.value
+        work = total / per_step
+        if bound == 'mfma':
+            ach = work / (avg_ms * 1e-3) / 1e12
+            row = {'flop_per_launch': work, 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': ach / mfma_peak}
+        else:
+            ach = work / (avg_ms * 1e-3) / 1e9
+            row = {'bytes_per_launch': work, 'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0}
+        row.update({'name': name, 'bound': bound, 'launches_per_step': per_step, 'avg_launch_ms': avg_ms,
+                    'ms_per_step': avg_ms * per_step, 'share_of_eager_step': avg_ms * per_step / ms_step, 'work_is': what})
+        rows.append(row)
+    lib.vqvae_prof_reset()
+    rows.sort(key=lambda r: -r['ms_per_step'])
+    return rows, ms_step
 
 
 def synth_examples(B, cfg, seed):
@@ -237,7 +310,7 @@ def GATE_BYTES(cfg, B, bf16=False):
 
 
 def measured_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    """HBM bytes per launch of the gate kernel from the committed rocprofv3 --pmc summary
     (profiles/roofline_traffic.json, written by tools/pmc_traffic.py from the counter CSVs of
     THIS command).  PMC counters cannot be read from inside the process, so the figure is only
     reported while the summary was taken on the same kernel sources (hash stamp); otherwise null."""
@@ -447,6 +520,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches every step')
     ap.add_argument('--no-fresh-input', action='store_true',
                     help='skip the second timed region (ms_per_step_with_input: a fresh host minibatch every step)')
+    ap.add_argument('--no-kernel-table', action='store_true', help='skip roofline.kernels (the eager pass with every chain kernel timed)')
     ap.add_argument('--no-overlap', action='store_true',
                     help='single stream (the default since the float32x3 kernels; kept for the profile scripts)')
     ap.add_argument('--overlap', action='store_true',
@@ -582,7 +656,7 @@ def main():
     lib.vqvae_prof_enable(0)
     roofline_pass = 'the timed steps'
     if use_graph:
-        # per-launch time of the dominant kernel: the same job, the same kernels, launched eagerly with the dispatch's own
+        # per-launch time of the gate kernel: the same job, the same kernels, launched eagerly with the dispatch's own
         # start / stop events (hipExtLaunchKernelGGL) right after the timed region
         upd.graph = False
         upd.update()
@@ -612,6 +686,14 @@ def main():
     _lib.call('vqvae_prof_read', tag, C.byref(tot), C.byref(cnt))
     losses = [float(l.data.get()) for l in upd.last_losses]
     seen = comm.ranks_seen()
+    # every kernel family of the chain against ITS roofline (same job, eager, per-launch events; outside the timed region)
+    ktable = None
+    if rank == 0 and n == 1 and not args.bf16 and not args.no_kernel_table:
+        upd.graph = False
+        upd.update()
+        backend.synchronize()
+        ktable = kernel_roofline_table(upd, backend, cfg, B, mode, min(args.steps, 10))
+        upd.graph = use_graph
     # The same job with the input leg INSIDE the step (updaters.py:8): every step consumes a minibatch that was in host
     # memory when the previous step started -- page-locked double buffer, copy stream, binning on the device
     # (inputs.StreamingInputIterator).  Timed like the main region, reported beside it, never as `value`.
@@ -659,7 +741,7 @@ def main():
         T = cfg['length']
         samples = n * B * T * args.steps
         value = samples / dt
-        # algorithmic FLOPs of one launch of the dominant kernel (ResidualBlock forward), SURVEY 8(d):
+        # algorithmic FLOPs of one launch of the gate kernel (ResidualBlock forward), SURVEY 8(d):
         # `dilconv1d` fwd = 2*B*T*Cout*Cin*K, plus -- now that the residual 1x1 conv runs inside the
         # same launch -- its 2*B*T*Cr*(Cd/2); the condition projection is not in this kernel's
         # contraction (computed once at the latent rate and lerped in the epilogue)
@@ -748,7 +830,13 @@ def main():
                                  'note': 'x read once, the saved gate values + z written once (float32x2: sigmoid and z, the backward takes tanh = z / sigmoid; other fp32 modes: tanh, sigmoid, z; --bf16: all as bf16), weights, latent-rate condition slice (DESIGN.md sections 3, 3a, 3c)'},
                          'traffic': traffic, 'traffic_source': tsrc,
                          'launches': cnt.value, 'avg_launch_ms': avg_ms, 'avg_launch_ms_measured_over': roofline_pass,
-                         'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv},
+                         'flop_per_launch': flop, 'flop_per_launch_dilconv1d_only': flop_conv,
+                         'kernels': None if ktable is None else ktable[0],
+                         'kernels_measured_over': None if ktable is None else (
+                             '%d eager steps of the same job (%.3f ms per step with the per-launch events on), outside the timed region; '
+                             'dispatch events per GEMM launch, stream events around a weight-gradient launch + its reduce; '
+                             'mfma peak as in roofline.peak_is, hbm peak 8000 GB/s; work = algorithmic FLOPs / bytes (SURVEY 8d)'
+                             % (min(args.steps, 10), ktable[1]))},
         }
         if ref_ms is not None:
             out['fp32_mfma_reference'] = {'ms_per_step': ref_ms, 'value': B * T / (ref_ms * 1e-3), 'unit': 'samples/s',

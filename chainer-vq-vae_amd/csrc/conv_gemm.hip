@@ -4640,7 +4640,7 @@ static int resstack_skip_impl(const vqvae_resblock_desc* d, int nblocks, const f
   g.out[0].amax_out = skip_amax_out;
   g.z16 = z_bf16(d) ? 1 : 0;
   g.x_nt = X3_SKIP_X_NT;
-  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESBLOCK_OUT, st);
+  return launch_gemm<EPI_LINEAR>(g, VQVAE_PROF_RESSTACK_SKIP, st);
 }
 
 extern "C" int vqvae_resstack_gcond_bwd(const vqvae_resblock_desc* d, int nblocks,
@@ -4701,7 +4701,7 @@ extern "C" int vqvae_resstack_skip_wgrad(const vqvae_resblock_desc* d, int nbloc
   wa.accumulate = accumulate;
   wa.x16 = z_bf16(d) ? 1 : 0;
   if (g_matmul_dtype == 3 && g_skip_amax) { wa.f16x2 = 1; wa.amax_gy = g_skip_amax; }
-  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_WGRAD_RES_SKIP, st);
 }
 
 // gWr_l (+)= g_res_l z_l^T, gbr_l (+)= rowsum(g_res_l) for every block whose g_res_l
@@ -4741,7 +4741,7 @@ extern "C" int vqvae_resstack_res_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.accumulate = accumulate;
   wa.x16 = z_bf16(d) ? 1 : 0;
   wa.g16 = (d->storage & VQVAE_STORE_GRES_BF16) ? 1 : 0;      // every g_res of this launch
-  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_WGRAD_RES_SKIP, st);
 }
 
 extern "C" int vqvae_resblock_wgrad(const vqvae_resblock_desc* d, const float* x, const float* gh,
@@ -4812,7 +4812,7 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
   wa.x16 = (d->storage & (VQVAE_STORE_X_BF16 | VQVAE_STORE_X_F16X2)) ? 1 : 0;        // every block of this launch (the caller groups them accordingly)
   if (d->storage & (VQVAE_STORE_GH_F16X2 | VQVAE_STORE_X_F16X2))
     VQ_REQUIRE(wa.f16x2, "resstack_dil_wgrad: pre-split operands (desc.storage) need the float32x2 launch: every block's scale words");
-  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_RESBLOCK_WGRAD, st);
+  return launch_wgrad(wa, p, (float*)ws, VQVAE_PROF_WGRAD_DIL, st);
 }
 
 extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_desc* d, int nblocks) {

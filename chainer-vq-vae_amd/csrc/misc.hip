@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256) void copy_list_kernel(const CopyJobs j) {
   float* __restrict__ d = j.dst[blockIdx.y];
   const float* __restrict__ s = j.src[blockIdx.y];
   const unsigned n = j.n[blockIdx.y];
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];      // (size_t: a 32-bit index wraps for n within one grid stride of 2^32)
 }
 
 // ---- Adam / EMA ------------------------------------------------------------
@@ -1013,6 +1013,25 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ tg
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     ema[i] = __fadd_rn(__fmul_rn(d, tgt[i]), __fmul_rn(om, ema[i]));
+}
+
+// float32x2's pre-split storage contract, checked where the numbers are (vqvae_f32x2_contract_check): pair i = (scale words,
+// maximum words) of one pre-split tensor -- the BOUND it was split under (word 0 of its scale group) against the ACTUAL
+// maximum its producer published (the maximum over the group).  A bound 2^m above the maximum costs m bits of the mode's
+// 2^-39 absolute floor; beyond `log2_limit` the tensor is outside what the mode promises.  One thread per pair.
+struct ContractPairs { const uint32_t* scale[64]; const uint32_t* amax[64]; };
+__global__ void f32x2_contract_kernel(const ContractPairs cp, int n, int log2_limit, uint32_t* report) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || cp.scale[i] == nullptr || cp.amax[i] == nullptr) return;
+  const float bound = __builtin_bit_cast(float, cp.scale[i][0]);
+  uint32_t mx = 0;
+  for (int j = 0; j < VQVAE_AMAX_SLOTS; ++j) mx = max(mx, cp.amax[i][j]);
+  const float amax = __builtin_bit_cast(float, mx);
+  if (!(bound > 0.f) || !(amax > 0.f)) return;            // nothing was split under this group / an all-zero tensor has no precision to lose
+  atomicAdd(report + 2, 1u);
+  const float ratio = bound / amax;                        // >= 1 by construction of the bounds; < 1 would itself be a violation (overflow of the split)
+  atomicMax(report + 1, __builtin_bit_cast(uint32_t, fmaxf(ratio, 0.f)));
+  if (ratio > __builtin_ldexpf(1.f, log2_limit) || ratio < 0.999f) atomicAdd(report, 1u);
 }
 
 }  // namespace vq
@@ -1416,6 +1435,19 @@ int vqvae_copy_list(int n, float* const* dst, const float* const* src, const siz
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(copy_list_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)s, j);
+    VQ_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int vqvae_f32x2_contract_check(int n, const uint32_t* const* scale, const uint32_t* const* amax, int log2_limit,
+                               uint32_t* report, vqvae_stream_t s) {
+  VQ_REQUIRE(n >= 0 && (n == 0 || (scale && amax)) && report && log2_limit >= 0 && log2_limit <= 60, "f32x2_contract_check: bad arguments");
+  for (int lo = 0; lo < n; lo += 64) {
+    ContractPairs cp;
+    const int m = n - lo < 64 ? n - lo : 64;
+    for (int i = 0; i < 64; ++i) { cp.scale[i] = i < m ? scale[lo + i] : nullptr; cp.amax[i] = i < m ? amax[lo + i] : nullptr; }
+    hipLaunchKernelGGL(f32x2_contract_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, cp, m, log2_limit, report);
     VQ_LAUNCH_CHECK();
   }
   return 0;

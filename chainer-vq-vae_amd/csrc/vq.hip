@@ -36,17 +36,8 @@ __global__ void vq_wnorm_kernel(const float* __restrict__ W, int k, int d, float
   wn[j] = s;
   atomicMax(wmax_bits, __float_as_int(s));   // s >= 0: int order == float order
 }
-// the same, plus max_ij |W_ij| in wmax_bits[1] (the two-piece fp16 sweep scales the codebook by a power of two from it)
-__global__ void vq_wnorm_elt_kernel(const float* __restrict__ W, int k, int d, float* wn, int* wmax_bits) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= k) return;
-  float s = 0.f, m = 0.f;
-  for (int c = 0; c < d; ++c) { const float w = W[(long)j * d + c]; s = fmaf(w, w, s); m = fmaxf(m, fabsf(w)); }
-  wn[j] = s;
-  atomicMax(wmax_bits, __float_as_int(s));
-  atomicMax(wmax_bits + 1, __float_as_int(m));
-}
-
+// vq_wnorm_elt_lds_kernel: the same, plus max_ij |W_ij| in wmax_bits[1] (the two-piece fp16 sweep scales the codebook by a power of
+// two from it);
 // the same values in the same order (s = fma(w_c, w_c, s), c ascending), rows arriving coalesced through LDS: a thread per code
 // reading its row from global memory was 64 cache lines per wave instruction and 20 us for the training shape's 512 x 64
 // codebook, in front of the quantiser on the step's critical path.  64 codes per workgroup, dynamic LDS 64 (d + 1) floats.
@@ -283,7 +274,7 @@ __device__ __forceinline__ void vq_split3(float x0, float x1, unsigned& h, unsig
 }
 // ---- the sweep as THREE fp16 products (matmul mode 3, `float32x2`: csrc/conv_gemm.hip "matmul mode 3") ------------------
 // x 2^k = hi + lo (fp16, RNE), <w, z> ~= (w_lo z_hi + w_hi z_lo + w_hi z_hi) 2^-(kw + kz): half the MFMAs of the six-product
-// sweep.  The codebook takes ONE power of two (from max_ij |W_ij|: vq_wnorm_elt_kernel), every latent row its OWN (from its
+// sweep.  The codebook takes ONE power of two (from max_ij |W_ij|: vq_wnorm_elt_lds_kernel), every latent row its OWN (from its
 // d entries, which its lane pair holds anyway): 2^(14 - e) puts the largest entry in [2^14, 2^15).  Rounding band:
 //   * representation: |x - (hi + lo) 2^-k| <= 2^-22 |x| + 2^-39 max|x| per entry, the dropped w_lo z_lo <= 2^-22 |w z|: over a
 //     row, <= 3 * 2^-22 |w||z| + 2^-39 sqrt(d) (max|z_n| |w| + max|W| |z|) <= (6 + 2^-13 sqrt(d)) u S  (u = 2^-24, S = |z|^2 +
@@ -1016,8 +1007,7 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     // mode 3: three fp16 products (VQVAE_VQ_X2=0: mode 2's six bf16 products, the A/B alternate)
     static const int x2_on = getenv("VQVAE_VQ_X2") ? atoi(getenv("VQVAE_VQ_X2")) : 1;
     const bool x2 = x2_on && (d == 64 || d == 128) && vqvae_get_matmul_dtype() == 3;
-    if (x2 && d <= 240) hipLaunchKernelGGL(vq_wnorm_elt_lds_kernel, dim3(cdiv(k, 64)), dim3(64), (size_t)64 * (d + 1) * 4, st, W, k, d, wn, wmax_bits);
-    else if (x2) hipLaunchKernelGGL(vq_wnorm_elt_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
+    if (x2) hipLaunchKernelGGL(vq_wnorm_elt_lds_kernel, dim3(cdiv(k, 64)), dim3(64), (size_t)64 * (d + 1) * 4, st, W, k, d, wn, wmax_bits);      // (x2: d is 64 or 128)
     else hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
     if ((d == 64 || d == 128) && vqvae_get_matmul_dtype() >= 2) {      // modes 2 and 3: the sweep on the 16-bit matrix pipe
@@ -1118,7 +1108,9 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     const long total = (long)B * d * T;
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    if ((long)B * T >= 16384 && d <= 512 && B <= 65535)        // (the training shape's 1 920 rows: one launch of the plain kernel is all latency)
+    // (the training shape's 1 920 rows: one launch of the plain kernel is all latency; d <= 254: the tile's 64 (d + 1) floats stay
+    //  inside the 64 KB of dynamic LDS a launch gets without hipFuncSetAttribute -- wider codes take the plain kernel)
+    if ((long)B * T >= 16384 && d <= 254 && B <= 65535)
       hipLaunchKernelGGL(vq_gather_tile_kernel, dim3((T + 63) / 64, B), dim3(256), (size_t)64 * (d + 1) * 4, st, W, idx, B, d, T, e);
     else
       hipLaunchKernelGGL(vq_gather_kernel, dim3(nb), dim3(256), 0, st, W, idx, B, d, T, e);

@@ -161,6 +161,7 @@ PROTOTYPES = {
     'vqvae_resblock_f16x2_storage': (c_int, [C.POINTER(ResblockDesc)]),
     'vqvae_set_presplit': (c_int, [c_int]),
     'vqvae_pullback_reduce': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'vqvae_f32x2_contract_check': (c_int, [c_int, PP, PP, c_int, P, P]),
     'vqvae_upsample_linear_bwd_f16x2': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                 P, c_long, P, P]),
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),
@@ -220,7 +221,7 @@ EW_ADD, EW_SUB, EW_MUL, EW_AXPBY, EW_SCALE, EW_SQUARE, EW_RELU, EW_RELU_BWD, EW_
     EW_MUL_SCALAR_DEV = range(10)
 PROF_RESBLOCK_GATE, PROF_RESBLOCK_OUT, PROF_RESBLOCK_BWD_GZ, PROF_RESBLOCK_BWD_GX, \
     PROF_RESBLOCK_BWD_GC, PROF_RESBLOCK_WGRAD, PROF_CONV_FWD, PROF_CONV_BWD_DATA, \
-    PROF_CONV_WGRAD, PROF_VQ_NEAREST = range(1, 11)
+    PROF_CONV_WGRAD, PROF_VQ_NEAREST, PROF_RESSTACK_SKIP, PROF_WGRAD_DIL, PROF_WGRAD_RES_SKIP = range(1, 14)
 GEN_NONE, GEN_SOFTMAX, GEN_MOL = range(3)
 GEN_MAX_N = 4
 

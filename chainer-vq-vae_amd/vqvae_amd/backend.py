@@ -209,6 +209,57 @@ def set_presplit(mask):
     _lib.call('vqvae_set_presplit', int(mask))
 
 
+# --------------------------------------------------------------------------- #
+# The run-time guard of 'float32x2' ("the dynamic-range contract").  ResidualNet's chain keeps x_l and gh_l
+# PRE-SPLIT under a-priori bounds; a bound 2^m above the tensor's actual maximum costs m bits of the mode's 2^-39 absolute
+# floor.  Every backward sweep ends with one tiny launch (vqvae_f32x2_contract_check) that compares, on the device, each
+# pre-split tensor's bound with the maximum its producer published and counts the tensors beyond 2^CONTRACT_LOG2_LIMIT.
+# Nothing is read back unless somebody asks:
+#   f32x2_contract_violations()         -> {'violations', 'checked', 'worst_log2'} since the last reset (synchronises)
+#   set_contract_debug(True) / VQVAE_CONTRACT_DEBUG=1: the chain reads the report after every sweep and RAISES on a violation
+# A violation means: switch to 'float32x3' (no scales) or withdraw the pre-split storage (set_presplit(4)).
+# --------------------------------------------------------------------------- #
+CONTRACT_LOG2_LIMIT = int(os.environ.get('VQVAE_CONTRACT_LOG2_LIMIT', '8'))
+
+
+def contract_report():
+    """The three device words (violations, float bits of the worst bound / max, tensors checked); allocated OUTSIDE any
+    recording's arena, once, so that eager and replayed steps count into the same words."""
+    r = _state.get('contract')
+    if r is None:
+        arena, _state['arena'] = _state.get('arena'), None
+        try:
+            r = zeros((4,), np.uint32)
+        finally:
+            _state['arena'] = arena
+        _state['contract'] = r
+    return r
+
+
+def contract_debug():
+    return bool(_state.get('contract_debug', os.environ.get('VQVAE_CONTRACT_DEBUG', '0') == '1'))
+
+
+def set_contract_debug(on):
+    _state['contract_debug'] = bool(on)
+
+
+def f32x2_contract_violations(reset=False):
+    """How many pre-split tensors of the 'float32x2' chain were split under a bound more than 2^CONTRACT_LOG2_LIMIT above
+    their actual maximum since the last reset (0 = the mode delivered what DESIGN.md 3a promises on every step so far)."""
+    if _state.get('contract') is None:
+        return {'violations': 0, 'checked': 0, 'worst_log2': None, 'log2_limit': CONTRACT_LOG2_LIMIT}
+    synchronize()
+    w = _state['contract'].get()
+    worst = float(np.array([w[1]], np.uint32).view(np.float32)[0])
+    out = {'violations': int(w[0]), 'checked': int(w[2]),
+           'worst_log2': (float(np.log2(worst)) if worst > 0 else None), 'log2_limit': CONTRACT_LOG2_LIMIT}
+    if reset:
+        _lib.call('vqvae_memset', _state['contract'].ptr, 0, 16, stream())
+        _state['contract_seen'] = 0
+    return out
+
+
 def synchronize():
     _lib.call('vqvae_stream_synchronize', stream())
     if _state['side'] is not None:
@@ -273,10 +324,25 @@ def arena_end():
     _state['arena'] = None
 
 
+_wtick = [0]
+
+
+def _tick():
+    """A process-unique, increasing stamp (see _Block.wver)."""
+    _wtick[0] += 1
+    return _wtick[0]
+
+
 class _Block(object):
-    __slots__ = ('ptr', 'nbytes', 'arena', '__weakref__')
+    # wver: the VALUE version of the memory -- a fresh stamp at allocation and at every in-place write that goes through a
+    # DeviceArray method (set / copy_from / fill_zero: Link.copyparams, p.data.set(...), manual edits); views share it.
+    # Kernels that write parameters (Adam, EMA, arena adoption, load_npz) are covered by the optimizer's step count and
+    # core.param_epoch(...).  What caches of derived data (packed weight slabs: prepack.py, wavenet._pack_key) key on
+    # besides the pointer, so that neither an edit nor a recycled address can serve slabs packed from other values.
+    __slots__ = ('ptr', 'nbytes', 'arena', 'wver', '__weakref__')
 
     def __init__(self, nbytes):
+        self.wver = _tick()
         nbytes = _round(nbytes)
         arena = _state.get('arena')
         self.arena = arena
@@ -346,6 +412,11 @@ class DeviceArray(object):
 
     # ---- metadata ----
     @property
+    def wver(self):
+        """Value version of the underlying memory (see _Block.wver)."""
+        return self._block.wver
+
+    @property
     def size(self):
         n = 1
         for s in self.shape:
@@ -402,6 +473,7 @@ class DeviceArray(object):
             raise ValueError('size mismatch in DeviceArray.set: %s vs %s' % (host.shape, self.shape))
         _lib.call('vqvae_memcpy_h2d', self.ptr, host.ctypes.data, self.nbytes, stream())
         self.amax = None
+        self._block.wver = _tick()
         return self
 
     def get(self):
@@ -420,11 +492,13 @@ class DeviceArray(object):
             raise ValueError('size mismatch in copy_from')
         _lib.call('vqvae_memcpy_d2d', self.ptr, other.ptr, self.nbytes, stream())
         self.amax = getattr(other, 'amax', None)
+        self._block.wver = _tick()
         return self
 
     def fill_zero(self):
         _lib.call('vqvae_memset', self.ptr, 0, self.nbytes, stream())
         self.amax = None
+        self._block.wver = _tick()
         return self
 
     def __float__(self):

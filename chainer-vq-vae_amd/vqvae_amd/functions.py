@@ -244,6 +244,23 @@ def _conv_desc(B, Cin, Tin, Cout, Tout, K, stride, pad, dil, relu):
     return _lib.Conv1dDesc(B, Cin, Tin, Cout, Tout, K, stride, pad, dil, 1 if relu else 0)
 
 
+def _mask_has_a_taker(v):
+    """True when the Variable ``v`` (a conv's input that carries ``relu_out``) was produced by a node whose backward CONSUMES
+    a gradient flagged ``relu_masked`` -- F.relu, a conv with a fused ReLU, ResidualNet's fused ReLU on the skip sum, through
+    any number of reshapes.  Only then may the conv that reads ``v`` apply that ReLU's mask to the gradient it produces: a
+    ReLU output re-wrapped as a LEAF (``Variable(h.data)``, gradient-check inputs) must receive the conv's plain dL/dx."""
+    c = getattr(v, 'creator', None)
+    while isinstance(c, Reshape):
+        c = getattr(c.inputs[0], 'creator', None)
+    if c is None:
+        return False
+    if isinstance(c, ReLU):
+        return True
+    if isinstance(c, Conv1dFunction):
+        return bool(c.relu)
+    return bool(getattr(c, 'relu_out', False))          # wavenet.ResidualStackFunction(relu_out=True)
+
+
 class Conv1dFunction(FunctionNode):
     """y = conv(x, W, b)[..., :out_len] (+ fused ReLU).  x:(B,Cin,T,1), W:(Cout,Cin,K,1).
     Replaces chainer.functions.convolution_2d / dilated_convolution_2d behind
@@ -316,7 +333,7 @@ class Conv1dFunction(FunctionNode):
                 am = _lib.Conv1dAmax(None, backend.absmax(gy).ptr, gx.amax.ptr, pre)
             elif pre is not None:
                 am = _lib.Conv1dAmax(None, None, None, pre)
-            if getattr(x, 'relu_out', False) and FUSE_RELU_BWD:
+            if getattr(x, 'relu_out', False) and FUSE_RELU_BWD and _mask_has_a_taker(self.inputs[0]):
                 # x is the output of a ReLU: that ReLU's backward, gx * (x > 0), in this launch's epilogue
                 _lib.call('vqvae_conv1d_bwd_data_relu', C.byref(self.desc), W.ptr, gy.ptr, x.ptr, gx.ptr,
                           ws.ptr, ws.nbytes, C.byref(am) if am is not None else None, _S())

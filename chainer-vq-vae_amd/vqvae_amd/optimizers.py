@@ -60,6 +60,11 @@ class Adam(object):
             if not isinstance(p.data, DeviceArray):
                 raise ValueError('optimizer.setup: parameter %s is on the host; call '
                                  'model.to_gpu() first (there is no CPU update path)' % n)
+            # (checked BEFORE any p.data is re-pointed at an arena view: backend.copy_many refuses other dtypes, and a refusal
+            #  half-way through the adoption would leave parameters pointing at views nothing was copied into)
+            g = p.grad.data if isinstance(p.grad, core.Variable) else p.grad
+            if p.data.dtype != np.float32 or (isinstance(g, DeviceArray) and g.dtype != np.float32):
+                raise ValueError('optimizer.setup: parameter %s is %s; the arenas are float32' % (n, p.data.dtype))
         train = [(n, p) for n, p in named if not p._shadow]
         shadow = [(n, p) for n, p in named if p._shadow]
         old = {n: (off, size) for n, off, size in self._layout}

@@ -15,6 +15,7 @@ Only ``Parameter`` weights are prefetched (a weight computed inside the step doe
 ``VQVAE_PREPACK_CONVS=0`` turns it off (bitwise the same step: the same pack kernels write the same slabs)."""
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -37,9 +38,15 @@ def _desc_key(d):
 
 
 def _version(wv, desc):
+    """Everything that can change the VALUES behind a parameter's pointer or the slab a launch would pack from them: the
+    optimizer's step count (Adam / EMA kernels), the load / layout / init epochs (serializers, arena adoption, lazily shaped
+    parameters), the memory's value version (in-place writes through DeviceArray methods -- Link.copyparams, p.data.set(...) --
+    and a recycled address: backend._Block.wver), the matmul mode and the float32x2 threshold."""
     step = getattr(wv, '_owner_step', None)
     lib = _lib.load()
-    return (step() if step is not None else 0, core.param_epoch('load'), core.param_epoch('layout'),
+    W = wv.data
+    return (step() if step is not None else 0, core.param_epoch('load'), core.param_epoch('layout'), core.param_epoch('init'),
+            W.wver if isinstance(W, DeviceArray) else -1,
             lib.vqvae_get_matmul_dtype(), lib.vqvae_conv1d_uses_f32x2(C.byref(desc)))
 
 
@@ -53,7 +60,7 @@ def lookup(wv, W, desc, backward):
     if key not in _used:
         d = _lib.Conv1dDesc()
         C.pointer(d)[0] = desc
-        _used[key] = (wv, d, int(backward))
+        _used[key] = (weakref.ref(wv), d, int(backward))      # (weak: a plan must not keep a dead model's parameters -- and their device buffers -- alive)
     e = _ready.get(key)
     if e is None or e[2] != _version(wv, desc):
         stats['misses'] += 1
@@ -76,7 +83,10 @@ def prefetch():
         return
     lib = _lib.load()
     jobs = []
-    for wv, desc, backward in plan:
+    for wr, desc, backward in plan:
+        wv = wr()
+        if wv is None:                       # the model is gone
+            continue
         W = wv.data
         if not isinstance(W, DeviceArray) or W.ndim < 3 or (W.shape[0], W.shape[1], W.shape[2]) != (desc.Cout, desc.Cin, desc.K):
             continue

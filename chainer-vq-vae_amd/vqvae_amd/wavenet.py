@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from . import _lib, backend, functions as F, links as L
+from . import _lib, backend, core, functions as F, links as L
 from .backend import DeviceArray
 from .core import Chain, ChainList, FunctionNode, type_expect
 
@@ -94,9 +94,27 @@ def _groups(nb, size=_lib.MAX_STACK_GROUP):
     return [(lo, min(nb, lo + size)) for lo in range(0, nb, size)]
 
 
+def _value_key(params):
+    """The parameters' buffers AND the values in them: pointers, the memory's value versions (backend._Block.wver: in-place
+    writes through DeviceArray methods -- Link.copyparams, p.data.set(...) -- and recycled addresses), the load / layout /
+    init epochs (serializers, arena adoption, lazily shaped parameters).  Optimizer steps are checked by the caller
+    (ResidualNet._forward: a slab set packed ahead is only offered to the forward of the step it was packed in)."""
+    return (tuple(p.ptr for p in params), tuple(p.wver for p in params),
+            core.param_epoch('load'), core.param_epoch('layout'), core.param_epoch('init'))
+
+
 def _pack_key(params, d0):
-    return (tuple(p.ptr for p in params), d0.B, d0.T, d0.Cr, d0.Cd, d0.Cs, d0.Cc, d0.K,
-            _lib.load().vqvae_get_matmul_dtype())
+    """What slabs packed ahead (ResidualNet.prepack_async) are valid for: _value_key, the block geometry, the matmul mode."""
+    return _value_key(params) + (d0.B, d0.T, d0.Cr, d0.Cd, d0.Cs, d0.Cc, d0.K, _lib.load().vqvae_get_matmul_dtype())
+
+
+def _owner_steps(pvars):
+    """The optimizer step count behind each parameter Variable (optimizers.Adam sets `_owner_step`); None without an owner."""
+    out = []
+    for v in pvars:
+        f = getattr(v, '_owner_step', None)
+        out.append(f() if f is not None else None)
+    return tuple(set(out)) if len(set(out)) <= 1 else tuple(out)
 
 
 def _build_cproj(params, nb, stream):
@@ -147,6 +165,10 @@ def _grad_out(var, shape):
     return DeviceArray(shape, np.float32)
 
 
+KEEP_CONTRACT_WORDS = False        # tests: keep a host copy of the last sweep's maxima / scale words in LAST_CONTRACT_WORDS
+LAST_CONTRACT_WORDS = None
+
+
 class ResidualStackFunction(FunctionNode):
     """All blocks of a ResidualNet in one node (modules.py:89-96).
     inputs: (x, condition, then 8 params per block) -> skip_connections.
@@ -187,7 +209,7 @@ class ResidualStackFunction(FunctionNode):
             # P_amax) and its packed slabs: built on the side stream by ResidualNet.prepack_async when the step started, if
             # the parameters are the ones it saw; else here
             pre = self.prepacked
-            cp = pre[4] if (pre is not None and pre[0][0] == tuple(p.ptr for p in inputs[2:])) else None
+            cp = pre[4] if (pre is not None and pre[0][:5] == _value_key(inputs[2:])) else None
             self._cslab_b = None
             if cp is not None:
                 self.Wc_all, bc_all = cp[0], cp[1]
@@ -295,6 +317,32 @@ class ResidualStackFunction(FunctionNode):
         self._skip = skip if self.relu_out else None
         self.retain_inputs(tuple(range(len(inputs))))
         return skip,
+
+    def _check_contract(self, nb, hpre):
+        """'float32x2': every pre-split tensor of this sweep -- x_l (l >= 1) and, with `hpre`, gh_l -- against the bound it was
+        split under (backend.f32x2_contract_violations; one launch, no host round trip unless backend.contract_debug())."""
+        pairs = [(self._slot(3 * nb + 1 + l), self._slot(l)) for l in range(1, nb)
+                 if self.descs[l].storage & _lib.STORE_X_F16X2]
+        if hpre:
+            pairs += [(self._slot(4 * nb + 1 + l), self._slot(nb + l)) for l in range(nb)]
+        if not pairs:
+            return
+        global LAST_CONTRACT_WORDS
+        if KEEP_CONTRACT_WORDS and backend._state.get('arena') is None:           # (tests: the words themselves, per block)
+            backend.synchronize()
+            LAST_CONTRACT_WORDS = (nb, self.amax.get().reshape(-1, _lib.AMAX_SLOTS).copy())
+        sc = (C.c_void_p * len(pairs))(*[p[0] for p in pairs])
+        am = (C.c_void_p * len(pairs))(*[p[1] for p in pairs])
+        rep = backend.contract_report()
+        _lib.call('vqvae_f32x2_contract_check', len(pairs), sc, am, backend.CONTRACT_LOG2_LIMIT, rep.ptr, _S())
+        if backend.contract_debug() and backend._state.get('arena') is None:      # (never inside a recording: the read synchronises)
+            r = backend.f32x2_contract_violations()
+            before, backend._state['contract_seen'] = backend._state.get('contract_seen', 0), r['violations']
+            if r['violations'] > before:
+                raise FloatingPointError(
+                    "float32x2: a pre-split tensor of ResidualNet's chain was split under a bound 2^%.1f above its maximum "
+                    "(limit 2^%d, %d violation(s) so far): outside the mode's dynamic-range contract (DESIGN.md 3a) -- use "
+                    "set_matmul_dtype('float32x3') or backend.set_presplit(4)" % (r['worst_log2'], r['log2_limit'], r['violations']))
 
     def _slot(self, i):
         """Device address of group i of self.amax (x_l: l, gh_l: nb + l, g_res_l: 2 nb + l, g_skip: 3 nb; scale words of
@@ -590,6 +638,8 @@ class ResidualStackFunction(FunctionNode):
             grads[2 + 8 * i + 5] = gbr[i]
             grads[2 + 8 * i + 6] = gWs[i]
             grads[2 + 8 * i + 7] = gbs[i]
+        if f16 and self.packed is not None and lat is not None:
+            self._check_contract(nb, hpre)
         self.saved = None                      # release activations
         self.packed = None
         self.amax = None
@@ -655,6 +705,8 @@ class ResidualNet(ChainList):
         for b in blocks:
             args += b.param_list()
         pre, self._prepacked = getattr(self, '_prepacked', None), None
+        if pre is not None and pre[6] != _owner_steps(args[2:]):       # an optimizer step between the pack and this forward
+            pre = None
         fn = ResidualStackFunction([b.dilation for b in blocks], relu_out=relu, prepacked=pre)
         out = fn.apply(args)[0]
         self._cproj_shape = getattr(fn, 'cproj_shape', None)     # (B, Cc, Tl) of the latent-rate projection: the next prepack_async packs for it
@@ -701,7 +753,8 @@ class ResidualNet(ChainList):
             _lib.call('vqvae_resstack_skip_prepare', C.byref(d0), len(blocks),
                       _lib.ptr_array([params[8 * i + 6] for i in range(len(blocks))]),
                       _lib.ptr_array([params[8 * i + 7] for i in range(len(blocks))]), skipws.ptr, skipws.nbytes, side)
-        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side), cp, skipws)
+        self._prepacked = (_pack_key(params, d0), packed, per, backend.Event().record(side), cp, skipws,
+                           _owner_steps([p for b in blocks for p in b.param_list()]))
 
 
 class WaveNet(Chain):

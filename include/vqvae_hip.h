@@ -76,7 +76,7 @@ int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
  *      read (synchronises the device). */
 #define VQVAE_PROF_NONE            0
 #define VQVAE_PROF_RESBLOCK_GATE   1   /* dilated conv + cond proj + gate (fwd)       */
-#define VQVAE_PROF_RESBLOCK_OUT    2   /* res/skip 1x1 (fwd)                          */
+#define VQVAE_PROF_RESBLOCK_OUT    2   /* res 1x1 + residual add (fwd)                */
 #define VQVAE_PROF_RESBLOCK_BWD_GZ 3   /* bwd: gz + gate derivative                   */
 #define VQVAE_PROF_RESBLOCK_BWD_GX 4   /* bwd-data of the dilated conv                */
 #define VQVAE_PROF_RESBLOCK_BWD_GC 5   /* bwd-data of the condition projection        */
@@ -85,6 +85,9 @@ int vqvae_event_elapsed_ms(float* ms, void* ev_start, void* ev_stop);
 #define VQVAE_PROF_CONV_BWD_DATA   8
 #define VQVAE_PROF_CONV_WGRAD      9
 #define VQVAE_PROF_VQ_NEAREST     10
+#define VQVAE_PROF_RESSTACK_SKIP   11  /* the skip sum of a whole ResidualNet as ONE GEMM (fwd)       */
+#define VQVAE_PROF_WGRAD_DIL       12  /* bwd-weight of the dilated convs (resstack_dil_wgrad: several blocks per launch, incl. the fixed-order reduce) */
+#define VQVAE_PROF_WGRAD_RES_SKIP  13  /* bwd-weight of the res / skip 1x1 convs (resstack_{res,skip}_wgrad, incl. the reduce) */
 #define VQVAE_PROF_NTAGS          16
 int vqvae_prof_enable(int tag_mask);
 int vqvae_prof_reset(void);
@@ -354,6 +357,15 @@ typedef struct {
  * (ascending n: deterministic); part = nblocks consecutive pb_part buffers of B * (T / 128) * Cd * 4 floats          */
 int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
                           float* gP, vqvae_stream_t s);
+/* The run-time guard of float32x2's pre-split storage (VQVAE_STORE_*_F16X2): pair i = (scale[i], amax[i]) names one
+ * pre-split tensor by its SCALE words (the a-priori bound it was split under, word 0) and the words its producer raised
+ * to its ACTUAL maximum.  A bound 2^m above the maximum costs m bits of the mode's absolute floor; the check counts, on
+ * the device and without a host round trip, every tensor with bound / max > 2^log2_limit (or a bound below the maximum):
+ *   report[0] += violations, report[1] = max(report[1], float bits of the largest bound / max seen), report[2] += tensors
+ * checked (report: 3 device words the caller zeroes when it starts counting).  NULL pairs, groups nobody wrote and
+ * all-zero tensors are skipped.  There is no counterpart in the reference (Chainer computes in fp32, modules.py:40-55). */
+int vqvae_f32x2_contract_check(int n, const uint32_t* const* scale, const uint32_t* const* amax, int log2_limit,
+                               uint32_t* report, vqvae_stream_t s);
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
                         const vqvae_resblock_params* params, const int* has_res, void* packed,

@@ -135,16 +135,37 @@ def device_relu_sites(model, x_enc, x_dec, speaker):
         return {'enc': enc, 'ce': ce, 's': s.data.get()[..., 0], 'z1': z1.data.get()[..., 0]}
 
 
-def align_relu_kinks(cache, dev, noise=2e-5):
+def align_relu_kinks(cache, dev, noise=2e-5, stats=None):
     """Makes the oracle's cached activations take the device's side at ReLU kinks (in place).
     Returns the number of elements changed; fails if the two disagree anywhere that is not zero
-    to within ``noise`` x the tensor's scale (that would be an arithmetic difference)."""
+    to within ``noise`` x the tensor's scale (that would be an arithmetic difference).
+
+    ``stats`` (a dict) receives the NOISE MODEL's prediction of that number, so that callers can hold the
+    count against something derived rather than a round ceiling: per site, sigma = the rms difference of
+    the two evaluations over the elements both call active (the arithmetic noise actually present), rho =
+    the oracle's density of activations just above zero (elements in (0, 64 sigma] / (64 sigma); the density
+    just below is the same to first order), and two evaluations whose difference is ~N(0, sigma^2) disagree
+    about the sign of rho * E|delta| = rho * sigma * sqrt(2 / pi) elements on each side of the kink:
+    expected = 2 * rho * sigma * sqrt(2 / pi), summed over the sites (stats['expected'], ['per_site'])."""
     flips = [0]
+    if stats is not None:
+        stats.setdefault('expected', 0.0)
+        stats.setdefault('per_site', [])
 
     def fix(post, dv, name, pre=None):
         ref = post if pre is None else pre
         mism = (ref > 0) != (dv > 0)
         n = int(mism.sum())
+        if stats is not None:
+            both = (post > 0) & (dv > 0)
+            if both.any():
+                delta = post[both].astype(np.float64) - dv[both]
+                sigma = float(np.sqrt(np.mean(delta * delta)))
+                w = 64.0 * sigma
+                rho = float(((post > 0) & (post <= w)).sum()) / w if w > 0 else 0.0
+                exp = 2.0 * rho * sigma * np.sqrt(2.0 / np.pi)
+                stats['expected'] += exp
+                stats['per_site'].append((name, n, exp, sigma / max(float(np.abs(ref).max()), 1e-30)))
         if n:
             scale = float(np.abs(ref).max())
             worst = max(float(np.abs(ref[mism]).max()), float(np.abs(dv[mism]).max()))
@@ -166,8 +187,16 @@ def align_relu_kinks(cache, dev, noise=2e-5):
     return flips[0]
 
 
+def kink_flip_ceiling(stats):
+    """The most ReLU kink flips the noise model allows (see align_relu_kinks): a Poisson count with the predicted mean, held to
+    mean + 4 sqrt(mean) + 4 with the mean doubled for what the model leaves out (the noise is neither Gaussian nor
+    independent of the value)."""
+    m = 2.0 * stats['expected']
+    return int(np.ceil(m + 4.0 * np.sqrt(m) + 4.0))
+
+
 def oracle_train_step_aligned(P, state, batch, n_loop, n_layer, dev_sites, beta=0.25, alpha=2e-4, ema=None,
-                              ema_decay=0.9999, loss_kind='softmax'):
+                              ema_decay=0.9999, loss_kind='softmax', kink_stats=None):
     """oracle.train_step (updaters.py:6-19 incl. the EMA blend) with the ReLU kink choices of the
     device (see above) applied between its forward and its backward."""
     x_enc, x_dec, speaker, t = batch
@@ -175,7 +204,7 @@ def oracle_train_step_aligned(P, state, batch, n_loop, n_layer, dev_sites, beta=
     if ema is not None:
         for (n1, a), (n2, b) in zip(O.flatten_params(ema), O.flatten_params(P['decoder'])):
             O.ema_update(a, b, ema_decay)
-    flips = align_relu_kinks(cache, dev_sites)
+    flips = align_relu_kinks(cache, dev_sites, stats=kink_stats)
     G = O.vae_backward(P, cache, speaker, t, n_loop, n_layer, beta, loss_kind)
     flatP, flatG = dict(O.flatten_params(P)), dict(O.flatten_params(G))
     state['t'] = state.get('t', 0) + 1

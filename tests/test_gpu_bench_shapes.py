@@ -190,21 +190,25 @@ def test_presplit_storage_changes_only_the_rounding_point(gpu):
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
 
-def test_presplit_chain_keeps_a_quiet_sample(gpu):
+@pytest.mark.parametrize('nblocks,ratio', [(3, 1e-4), (20, 1e-3), (20, 1e-4)])
+def test_presplit_chain_keeps_a_quiet_sample(gpu, nblocks, ratio):
     """The dynamic-range contract of 'float32x2' (test_gpu_kernels.py::test_float32x2_dynamic_range_contract) through
     ResidualNet's chain with its PRE-SPLIT tensors: x_l and gh_l are split under a-priori BOUNDS (max |x_l| + the res
     conv's row norm; the column norms of Wr / Ws times max |g_res| / max |g_skip|), which sit up to 2^6 above the true
     maxima, so the absolute floor under a quiet sample is that much higher than for a tensor split under its own maximum:
-    2 * K * 2^-33 * max|x| * max|W| per contraction.  A B = 4 batch whose last sample is 1e-4 of the others in x and in
+    2 * K * 2^-33 * max|x| * max|W| per contraction.  A B = 4 batch whose last sample is `ratio` of the others in x and in
     the output gradient still gets that sample's forward output and input gradient to 1e-4 of ITS OWN scale against the
-    oracle (three blocks, dilations 1, 2, 4; T = 2048)."""
+    oracle -- through three blocks (dilations 1, 2, 4) and through the configs' full depth of 20 (dilations 1 .. 512,
+    twice: the stored stream is re-split twenty times in a row and the gradient stream crosses twenty backward-data
+    GEMMs); T = 2048.  The guard (backend.f32x2_contract_violations) must stay silent: every bound within 2^8."""
     from vqvae_amd import functions as F
     from vqvae_amd.core import Variable
     from vqvae_amd.wavenet import ResidualStackFunction
     gpu.set_matmul_dtype('float32x2')
     try:
-        Bq, Tq, ratio = 4, 2048, 1e-4
-        dils = [1, 2, 4]
+        Bq, Tq = 4, 2048
+        dils = [1, 2, 4] if nblocks == 3 else [2 ** (i % 10) for i in range(nblocks)]
+        gpu.f32x2_contract_violations(reset=True)
         Tl, Cl, G, nspk = Tq // 64, 64, 128, 7
         rs = np.random.RandomState(23)
         blocks = [_rb_params(rs, 256, 256, 256, Cl + G, 2) for _ in dils]
@@ -241,8 +245,14 @@ def test_presplit_chain_keeps_a_quiet_sample(gpu):
         gx = vx.grad.get()[..., 0]
         assert_close_scaled(gx, g_res, 1e-4, 'gx')
         rel = np.abs(gx[-1] - g_res[-1]).max() / np.abs(g_res[-1]).max()
-        print('quiet sample (%g of the batch): gx %.2e of its own scale' % (ratio, rel))
+        sk = skip.data.get()[..., 0]
+        rel_s = np.abs(sk[-1] - skip_ref[-1]).max() / np.abs(skip_ref[-1]).max()
+        rep = gpu.f32x2_contract_violations()
+        print('quiet sample (%g of the batch) through %d blocks: gx %.2e, skip %.2e of its own scale; loosest bound 2^%.1f over %d pre-split tensors'
+              % (ratio, nblocks, rel, rel_s, rep['worst_log2'], rep['checked']))
         assert rel <= 1e-4, 'gx of the quiet sample: %.2e of its own scale' % rel
+        assert rel_s <= 1e-4, 'skip of the quiet sample: %.2e of its own scale' % rel_s
+        assert rep['violations'] == 0 and rep['checked'] == 2 * nblocks - 1, rep
     finally:
         gpu.set_matmul_dtype(gpu.default_matmul_dtype())
 
@@ -267,11 +277,14 @@ def test_config1_whole_step_matches_oracle(gpu):
     upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
     sites = H.device_relu_sites(model, batch[0], batch[1], batch[2])
     upd.update()
+    ks = {}
     with _limit_blas():
         losses, cache, G, flips = H.oracle_train_step_aligned(P, {}, batch, cfg['n_loop'], cfg['n_layer'], sites,
-                                                              ema=P_ema, ema_decay=0.9999)
-    print('configs[1]: %d ReLU kink elements (of ~90 M) took the other side on the device' % flips)
-    assert flips <= 1024
+                                                              ema=P_ema, ema_decay=0.9999, kink_stats=ks)
+    # the count is held against the noise model's own prediction (helpers.align_relu_kinks), not a round number
+    print('configs[1]: %d ReLU kink elements (of ~90 M) took the other side on the device; the noise model predicts %.1f, allows %d'
+          % (flips, ks['expected'], H.kink_flip_ceiling(ks)))
+    assert flips <= H.kink_flip_ceiling(ks), ks['per_site']
     idx_dev = model.vq._cache[3][0].get()
     np.testing.assert_array_equal(idx_dev.reshape(cache['idx'].shape), cache['idx'])
     assert cache['idx'].size == 16 * 120

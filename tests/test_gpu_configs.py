@@ -55,11 +55,14 @@ def test_config0_whole_step_matches_oracle(gpu, matmul_mode):
     upd = V.VQVAE_StandardUpdater(_Iter([batch]), opt, device=0)
     sites = H.device_relu_sites(model, batch[0], batch[1], batch[2])     # ReLU kink choices (helpers.py)
     upd.update()
+    ks = {}
     with _limit_blas():
         losses, cache, G, flips = H.oracle_train_step_aligned(P, {}, batch, cfg['n_loop'], cfg['n_layer'], sites,
-                                                              ema=P_ema, ema_decay=0.9999)
-    print('configs[0]: %d ReLU kink elements (of ~5.6 M) took the other side on the device' % flips)
-    assert flips <= 64
+                                                              ema=P_ema, ema_decay=0.9999, kink_stats=ks)
+    # the count is held against the noise model's own prediction (helpers.align_relu_kinks), not a round number
+    print('configs[0]: %d ReLU kink elements (of ~5.6 M) took the other side on the device; the noise model predicts %.1f, allows %d'
+          % (flips, ks['expected'], H.kink_flip_ceiling(ks)))
+    assert flips <= H.kink_flip_ceiling(ks), ks['per_site']
     # argmin indices: bit-exact (the model's own search, reused for both quantiser applications)
     idx_dev = model.vq._cache[3][0].get()
     np.testing.assert_array_equal(idx_dev.reshape(cache['idx'].shape), cache['idx'])

@@ -58,7 +58,7 @@ def test_train_steps_match_oracle(gpu, matmul_mode, ema):
         for name, arr in G.items():
             dn = H._dev_name(name, ema)
             assert dn in g_dev, 'missing grad for ' + dn
-            assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 2e-4, 'step %d grad %s' % (step, dn))
+            assert_close_scaled(g_dev[dn].reshape(arr.shape), arr, 1e-4, 'step %d grad %s' % (step, dn))      # north_star's bar
         # the last block's res conv never receives a gradient (modules.py:89-96)
         last = '/decoder%s/resnet/%d/res/W' % ('/target' if ema else '', cfg['n_loop'] * cfg['n_layer'] - 1)
         assert last not in g_dev
@@ -601,3 +601,83 @@ def test_prepacked_conv_slabs_give_the_same_step_bitwise(gpu, min_gflop):
         wn.PREPACK_ASYNC = True
         prepack.reset()
         backend.set_f32x2_min_gflop(8.0)
+
+
+@pytest.mark.gpu
+def test_a_prepacked_slab_is_not_served_after_an_in_place_parameter_write(gpu):
+    """ADVICE r5 (prepack.py): a slab packed ahead is keyed by the parameter's pointer AND the values behind it.  An in-place
+    write through a DeviceArray method -- p.data.set(...), Link.copyparams (updaters.py:77) -- changes neither the pointer nor
+    the optimizer's step count; the memory's value version (backend._Block.wver) does change, so the next lookup misses and
+    the conv packs from the NEW weights."""
+    from vqvae_amd import links as L, prepack
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((2, 32, 96, 1)).astype(np.float32)
+    W1 = (0.1 * rs.standard_normal((48, 32, 3, 1))).astype(np.float32)
+    W2 = (0.1 * rs.standard_normal((48, 32, 3, 1))).astype(np.float32)
+    conv = L.Convolution2D(32, 48, (3, 1), pad=(1, 0), nobias=True)
+    conv.W.data = W1.copy()
+    conv.to_gpu()
+    other = L.Convolution2D(32, 48, (3, 1), pad=(1, 0), nobias=True)
+    other.W.data = W2.copy()
+    other.to_gpu()
+    enabled = prepack.ENABLED
+    prepack.reset()
+    prepack.ENABLED = True
+    try:
+        vx = Variable(gpu.to_device(x))
+        y1 = conv(vx).data.get()                                    # records the use; packs in line
+        assert (prepack.stats['hits'], prepack.stats['misses']) == (0, 1)
+        prepack.prefetch()                                          # packs the slab of W1 ahead
+        ya = conv(vx).data.get()
+        assert (prepack.stats['hits'], prepack.stats['misses']) == (1, 1) and np.array_equal(ya, y1)
+        ptr = conv.W.data.ptr
+        conv.W.data.set(W2)                                         # in place: same pointer, no optimizer, no epoch
+        assert conv.W.data.ptr == ptr
+        y2 = conv(vx).data.get()
+        assert prepack.stats['misses'] == 2, 'the slab packed from the old weights was served'
+        want2 = O.conv1d_fwd(x[..., 0], W2[..., 0], None, pad=1)
+        assert_close(y2[..., 0], want2, 1e-4, 'conv after p.data.set')
+        prepack.prefetch()                                          # a fresh slab of W2 ...
+        conv.W.data.set(W1)
+        conv.copyparams(other)                                      # ... and Link.copyparams writes W2's values back in place
+        y3 = conv(vx).data.get()
+        assert np.array_equal(y3, y2)
+        conv.W.data.set(W1)
+        y4 = conv(vx).data.get()
+        assert np.array_equal(y4, y1)
+    finally:
+        prepack.ENABLED = enabled
+        prepack.reset()
+
+
+@pytest.mark.gpu
+def test_a_relu_output_rewrapped_as_a_leaf_receives_the_plain_conv_gradient(gpu):
+    """ADVICE r5 (functions.py): the conv that reads a ReLU's output applies that ReLU's backward mask to the gradient it
+    produces only when the node that made the input will consume the mask.  ``Variable(h.data)`` -- a leaf that merely
+    carries the array's `relu_out` mark -- must get dL/dx of the conv itself."""
+    from vqvae_amd import functions as F, links as L
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((2, 16, 64, 1)).astype(np.float32)
+    W = (0.2 * rs.standard_normal((24, 16, 3, 1))).astype(np.float32)
+    gy = rs.standard_normal((2, 24, 64, 1)).astype(np.float32)
+    conv = L.Convolution2D(16, 24, (3, 1), pad=(1, 0), nobias=True)
+    conv.W.data = W.copy()
+    conv.to_gpu()
+    h = F.relu(Variable(gpu.to_device(x)))
+    assert h.data.relu_out
+    leaf = Variable(h.data)                      # stop-gradient re-wrap (net.py:83 style)
+    y = conv(leaf)
+    y.grad = gpu.to_device(gy)
+    y.backward()
+    want = O.conv1d_bwd(np.maximum(x[..., 0], 0), W[..., 0], gy[..., 0], pad=1)[0]
+    assert not getattr(leaf.grad, 'relu_masked', False)
+    assert_close_scaled(leaf.grad.get()[..., 0], want, 1e-4, 'gradient at a re-wrapped ReLU output')
+    assert (np.abs(want[x[..., 0] <= 0]) > 0).any()          # the mask would have zeroed entries the plain gradient has
+    # ... while through the graph the mask is still fused and consumed (same gradient as the separate kernels)
+    vx = Variable(gpu.to_device(x))
+    y2 = conv(F.relu(vx))
+    y2.grad = gpu.to_device(gy)
+    y2.backward()
+    assert_close_scaled(vx.grad.get()[..., 0], want * (x[..., 0] > 0), 1e-4, 'gradient through the fused ReLU backward')
