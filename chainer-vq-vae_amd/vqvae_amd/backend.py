@@ -166,12 +166,30 @@ def set_f32x2_min_gflop(gflop):
     _lib.call('vqvae_set_f32x2_min_gflop', float(gflop))
 
 
-def defer_to_side(keep):
+def defer_to_side(keep, writes=None):
     """Work has been enqueued on the side stream that the main stream does not wait for yet; ``keep``: everything that work
     reads or writes through temporaries (the allocator invariant below: a block must not return to the pool before a join
-    has been enqueued behind its last side-stream user).  join_side() closes the window."""
+    has been enqueued behind its last side-stream user).  ``writes``: the arrays that work WRITES (gradient slots): only an
+    accumulation into one of those has to join early (side_writes_pending); None = unknown, every accumulation joins.
+    join_side() closes the window."""
     _state.setdefault('side_keep', []).append(keep)
     _state['side_pending'] = True
+    if writes is None:
+        _state['side_writes'] = None
+    elif _state.get('side_writes', set()) is not None:
+        _state.setdefault('side_writes', set()).update(int(w.ptr) for w in writes if w is not None)
+
+
+def side_writes_pending(*arrays):
+    """True when work deferred to the side stream may still be writing one of ``arrays`` (by device pointer): the main stream
+    must join before it reads or accumulates into it.  A gradient that no deferred launch touches -- every parameter of the
+    encoder / condition embed / quantiser while the decoder's last weight gradients run beside their backward -- does not."""
+    if not _state.get('side_pending'):
+        return False
+    w = _state.get('side_writes', set())
+    if w is None:
+        return True
+    return any(a is not None and int(a.ptr) in w for a in arrays)
 
 
 class deferred_join(object):
@@ -199,6 +217,7 @@ def join_side(force=True):
         wait_event(stream(), Event().record(side_stream()))
         _state['side_pending'] = False
         _state['side_keep'] = []
+        _state['side_writes'] = set()
 
 
 def set_presplit(mask):

@@ -275,8 +275,8 @@ class Variable(object):
             self.grad = gx
         else:
             masked = getattr(self.grad, 'relu_masked', False) and getattr(gx, 'relu_masked', False)
-            if isinstance(self, Parameter):
-                backend.join_side()      # (a parameter's contributions may come from launches deferred to the side stream)
+            if isinstance(self, Parameter) and backend.side_writes_pending(self.grad, gx):
+                backend.join_side()      # (one of the two contributions comes from a launch deferred to the side stream)
             self.grad = F.raw_add(self.grad, gx)
             self.grad.relu_masked = masked       # a sum of masked gradients is the masked sum
 
@@ -322,7 +322,12 @@ class Parameter(Variable):
                 self.grad = self._grad_slot
                 return
             gx = gx.reshape(self._grad_slot.shape)
-            backend.join_side()      # (gx, or an earlier contribution to the slot, may come from a launch deferred to the side stream)
+            # (only when gx, or an earlier contribution to the slot, comes from a launch deferred to the side stream: joining for
+            #  EVERY copied gradient -- the speaker embedding's is the first of the sweep's tail -- made the main stream wait for all
+            #  of the deferred weight gradients, 1.4 ms, in front of the condition-embed / encoder backward they were deferred to
+            #  run beside)
+            if backend.side_writes_pending(self._grad_slot, gx):
+                backend.join_side()
             if self.grad is None:
                 self._grad_slot.copy_from(gx)
             else:

@@ -576,7 +576,8 @@ class ResidualStackFunction(FunctionNode):
             backend.wait_event(sd, backend.Event().record(_S()))       # every gh, g_res of the chain is complete
             flush_dil(sd, ws_defer)
             flush_res(0, sd, ws_defer)
-            backend.defer_to_side([self.saved, ghs, g_ress, gdil, ws_defer, self.packed, self.amax, g_skip])
+            backend.defer_to_side([self.saved, ghs, g_ress, gdil, ws_defer, self.packed, self.amax, g_skip],
+                                  writes=[a for pair in gdil.values() for a in pair] + gWr + gbr)
         else:
             flush_res(0)
         if overlap:
@@ -621,7 +622,7 @@ class ResidualStackFunction(FunctionNode):
                 _lib.call('vqvae_split', gbc_all.ptr + lo * d.Cd * 4, _lib.ptr_array(gbc[lo:hi]),
                           hi - lo, d.Cd, 0, sw)
             if defer:
-                backend.defer_to_side([gWc_all, gbc_all, gP, lat, gWc, gbc, wsw])
+                backend.defer_to_side([gWc_all, gbc_all, gP, lat, gWc, gbc, wsw], writes=[gWc_all, gbc_all] + gWc + gbc)
             for i in range(nb):
                 grads[2 + 8 * i + 2] = gWc[i]
                 grads[2 + 8 * i + 3] = gbc[i]
