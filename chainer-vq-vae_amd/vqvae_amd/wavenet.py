@@ -149,6 +149,7 @@ def _pack_stack(params, d0, nb, stream):
 
 FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
 DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
+DEFER_DIL_BLOCKS = 5      # how many of the blocks nearest the input keep their dilated-conv weight gradients for the side stream (a multiple of DIL_WGRAD_GROUP; 10 and 15 measured 0.05-0.1 ms slower: the tail they would run beside is full)
 BATCH_PULLBACK = os.environ.get('VQVAE_BATCH_PULLBACK', '1') != '0'
 PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
 # 'bfloat16' mode: the chain's tensors the caller may keep in HBM as bf16 (x_l, gh_l, g_res_l: vqvae_resblock_desc.storage) are
@@ -446,6 +447,12 @@ class ResidualStackFunction(FunctionNode):
             ws = ws_side if ws is None else ws
             if not dil_pending:
                 return
+            if len(dil_pending) > dil_group:          # (the deferred blocks: a launch per group, as in line)
+                rest = dil_pending[dil_group:]
+                del dil_pending[dil_group:]
+                flush_dil(stream, ws)
+                dil_pending.extend(rest)
+                return flush_dil(stream, ws)
             blocks = list(dil_pending)
             del dil_pending[:]
             if overlap:
@@ -542,7 +549,7 @@ class ResidualStackFunction(FunctionNode):
                 ghs[i] = gh
                 gdil[i] = (gp[0], gp[1])
                 dil_pending.append(i)
-                if (len(dil_pending) >= dil_group or i == 0) and not (defer and i == 0):
+                if (len(dil_pending) >= dil_group or i == 0) and not (defer and i < DEFER_DIL_BLOCKS):
                     flush_dil()               # waits (on the side stream) for the chain up to here
                 elif overlap:
                     backend.wait_event(side, backend.Event().record(_S()))
