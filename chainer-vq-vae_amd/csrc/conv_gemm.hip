@@ -4838,7 +4838,7 @@ namespace vq {
 // whole rows -- deterministic (one owner per channel, fixed order), every byte of `part` read once
 constexpr int PBR_C = 64;
 __global__ __launch_bounds__(PBR_C) void pullback_reduce_kernel(const float* __restrict__ part, const int32_t* __restrict__ v0,
-                                                               int nblocks, int B, int nt, int Cd, int Tl, float* __restrict__ gP) {
+                                                               int nblocks, int B, int nt, int Cd, int Tl, float* __restrict__ gP, long gP_bstride) {
   extern __shared__ float img[];                 // [PBR_C][Tl + 1]
   const int chunks = Cd / PBR_C;
   const int cchunk = blockIdx.x % chunks;
@@ -4858,18 +4858,23 @@ __global__ __launch_bounds__(PBR_C) void pullback_reduce_kernel(const float* __r
     if (vb + 3 < Tl) row[vb + 3] += p.w;
   }
   __syncthreads();
-  float* dst = gP + ((long)b * nblocks * Cd + (long)l * Cd + cchunk * PBR_C) * Tl;      // PBR_C consecutive rows of Tl: one contiguous run
+  float* dst = gP + (long)b * gP_bstride + ((long)l * Cd + cchunk * PBR_C) * Tl;      // PBR_C consecutive rows of Tl: one contiguous run
   for (int i = threadIdx.x; i < PBR_C * Tl; i += PBR_C) dst[i] = img[(i / Tl) * (Tl + 1) + i % Tl];
 }
 }  // namespace vq
 
-extern "C" int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
-                                     float* gP, vqvae_stream_t s) {
+extern "C" int vqvae_pullback_reduce_into(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
+                                          float* gP, size_t gP_bstride, vqvae_stream_t s) {
   VQ_REQUIRE(part && v0 && gP && nblocks > 0 && B > 0 && Cd > 0 && Tl > 0 && T % vq::BN == 0 && (long)T >= 64L * Tl,
              "pullback_reduce: bad arguments (T %% 128 == 0, T >= 64 Tl)");
   VQ_REQUIRE(Cd % vq::PBR_C == 0 && (size_t)vq::PBR_C * (Tl + 1) * 4 <= 64 * 1024, "pullback_reduce: Cd %% 64 == 0, Tl <= 255");
+  VQ_REQUIRE(gP_bstride >= (size_t)nblocks * Cd * Tl, "pullback_reduce: batch stride of gP smaller than the rows written");
   const size_t lds = (size_t)vq::PBR_C * (Tl + 1) * sizeof(float);
-  hipLaunchKernelGGL(vq::pullback_reduce_kernel, dim3((unsigned)(nblocks * B * (Cd / vq::PBR_C))), dim3(vq::PBR_C), lds, (hipStream_t)s, part, v0, nblocks, B, T / vq::BN, Cd, Tl, gP);
+  hipLaunchKernelGGL(vq::pullback_reduce_kernel, dim3((unsigned)(nblocks * B * (Cd / vq::PBR_C))), dim3(vq::PBR_C), lds, (hipStream_t)s, part, v0, nblocks, B, T / vq::BN, Cd, Tl, gP, (long)gP_bstride);
   VQ_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
+                                     float* gP, vqvae_stream_t s) {
+  return vqvae_pullback_reduce_into(part, v0, nblocks, B, T, Cd, Tl, gP, (size_t)nblocks * Cd * Tl, s);
 }

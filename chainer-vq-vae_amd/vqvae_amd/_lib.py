@@ -161,6 +161,7 @@ PROTOTYPES = {
     'vqvae_resblock_f16x2_storage': (c_int, [C.POINTER(ResblockDesc)]),
     'vqvae_set_presplit': (c_int, [c_int]),
     'vqvae_pullback_reduce': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'vqvae_pullback_reduce_into': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'vqvae_f32x2_contract_check': (c_int, [c_int, PP, PP, c_int, P, P]),
     'vqvae_upsample_linear_bwd_f16x2': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                 P, c_long, P, P]),

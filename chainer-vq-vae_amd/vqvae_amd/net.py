@@ -85,9 +85,11 @@ class VAE(Chain):
         dec = self.decoder
         dec = getattr(dec, 'target' if core.config.train else 'ema', dec)
         rn = getattr(dec, 'resnet', None)
-        if hasattr(rn, 'prepack_async') and isinstance(x_dec, backend.DeviceArray):
-            rn.prepack_async(x_dec.shape[0], x_dec.shape[2] if x_dec.ndim == 4 else x_dec.shape[1])
+        # (issued BEHIND the encoder's launches -- see prepack_async -- but ordered behind the point where the step started)
+        start = backend.Event().record(backend.stream()) if isinstance(x_dec, backend.DeviceArray) else None
         z = self.encoder(x_enc)
+        if hasattr(rn, 'prepack_async') and isinstance(x_dec, backend.DeviceArray):
+            rn.prepack_async(x_dec.shape[0], x_dec.shape[2] if x_dec.ndim == 4 else x_dec.shape[1], after=start)
         z_const = Variable(z.data)            # stop-gradient view of the latents
 
         # Two quantiser applications route the gradients (net.py:82-83): through `e` the

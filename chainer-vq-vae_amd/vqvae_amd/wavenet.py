@@ -149,6 +149,7 @@ def _pack_stack(params, d0, nb, stream):
 
 FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
 DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
+PB_REDUCE_GROUP = 5       # blocks per vqvae_pullback_reduce_into launch
 DEFER_DIL_BLOCKS = 5      # how many of the blocks nearest the input keep their dilated-conv weight gradients for the side stream (a multiple of DIL_WGRAD_GROUP; 10 and 15 measured 0.05-0.1 ms slower: the tail they would run beside is full)
 BATCH_PULLBACK = os.environ.get('VQVAE_BATCH_PULLBACK', '1') != '0'
 PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
@@ -576,6 +577,13 @@ class ResidualStackFunction(FunctionNode):
             g_res = gx
             if pending[0] - i >= grp:          # g_res of blocks i .. pending-1 are all available
                 flush_res(i)
+            # the fused pull-back's partial sums of the blocks the chain has passed, PB_REDUCE_GROUP at a time: ~15 us between two
+            # chip-filling launches instead of one launch over all blocks in the tail (52 us alone, 160 us beside the deferred
+            # weight gradients it then shares the chip with)
+            if pb_part is not None and (i % PB_REDUCE_GROUP == 0):
+                hi_b = min(nb, i + PB_REDUCE_GROUP)
+                _lib.call('vqvae_pullback_reduce_into', pb_part.ptr + i * (pb_part.nbytes // nb), tb['v0'].ptr, hi_b - i,
+                          d0.B, d0.T, d0.Cd, Tl, gP.ptr + i * d0.Cd * Tl * 4, nb * d0.Cd * Tl, _S())
         d = self.descs[0]
         # weight gradients of the res convs of the blocks not yet covered (those nearest the input)
         if defer:
@@ -592,7 +600,7 @@ class ResidualStackFunction(FunctionNode):
             # caller issues after backward returns) is ordered behind the side stream's work
             backend.wait_event(_S(), backend.Event().record(side))
         if pb_part is not None:
-            _lib.call('vqvae_pullback_reduce', pb_part.ptr, tb['v0'].ptr, nb, d.B, d.T, d.Cd, Tl, gP.ptr, _S())
+            pass                               # reduced group by group inside the chain (above)
         elif gh_all is not None:
             bf = 1 if store & _lib.STORE_GH_BF16 else 0
             n = d.B * d.Cd * d.T
@@ -720,11 +728,15 @@ class ResidualNet(ChainList):
         self._cproj_shape = getattr(fn, 'cproj_shape', None)     # (B, Cc, Tl) of the latent-rate projection: the next prepack_async packs for it
         return out
 
-    def prepack_async(self, B, T):
-        """The chain's weight slabs for an upcoming forward over (B, ., T), packed on the SIDE stream now -- VAE.__call__ calls
-        this before the encoder, so the ten-odd packing launches (~0.2 ms on a handful of workgroups) run beside the
-        encoder / quantiser / condition-embed chain instead of in front of the first gate GEMM.  The forward takes the
-        result if nothing changed (parameters, shapes, matmul mode), else packs as before."""
+    def prepack_async(self, B, T, after=None):
+        """The chain's weight slabs for an upcoming forward over (B, ., T), packed on the SIDE stream now: the 25 packing
+        launches (~0.3 ms on a handful of workgroups) run beside the encoder / quantiser / condition-embed chain instead of in
+        front of the first gate GEMM.  The forward takes the result if nothing changed (parameters, shapes, matmul mode), else
+        packs as before.  ``after``: the main-stream event the side stream has to be behind (the optimizer's last write of the
+        parameters); None: the main stream as it is now.  VAE.__call__ records that event when the step starts but calls this
+        AFTER it has enqueued the encoder: launches reach the GPU in the order they are issued -- from Python and from a
+        replayed hipGraph alike (ROCm enqueues a graph's nodes one by one, in capture order) -- so 25 side-stream launches
+        issued in front of the first encoder conv delayed the whole critical path by the time it takes to ISSUE them."""
         if not (PACK_ONCE and PREPACK_ASYNC):
             return
         blocks = list(self.children())
@@ -734,7 +746,7 @@ class ResidualNet(ChainList):
         Wd, Wc, Ws = params[0], params[2], params[6]
         d0 = _lib.ResblockDesc(B, T, Wd.shape[1], Wd.shape[0], Ws.shape[0], Wc.shape[1], Wd.shape[2], blocks[0].dilation)
         side = backend.side_stream()
-        backend.wait_event(side, backend.Event().record(_S()))       # the optimizer's last write of the parameters
+        backend.wait_event(side, after if after is not None else backend.Event().record(_S()))       # the optimizer's last write of the parameters
         packed, per = _pack_stack(params, d0, len(blocks), side)
         # ... and, when the last forward projected the condition at the latent rate, that projection's weight / bias
         # (three concats and an add over the blocks' parameters) and its packed slabs for both directions

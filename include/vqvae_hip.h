@@ -357,6 +357,11 @@ typedef struct {
  * (ascending n: deterministic); part = nblocks consecutive pb_part buffers of B * (T / 128) * Cd * 4 floats          */
 int vqvae_pullback_reduce(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
                           float* gP, vqvae_stream_t s);
+/* the same for a GROUP of blocks inside a larger gP: gP points at the group's first row (l = 0 of `part`), gP_bstride =
+ * elements between batch items of the whole tensor (rows of all blocks * Tl).  ResidualNet's backward finishes the blocks
+ * it has passed five at a time, between the chain's big launches, instead of all twenty in the latency-bound tail. */
+int vqvae_pullback_reduce_into(const float* part, const int32_t* v0, int nblocks, int B, int T, int Cd, int Tl,
+                               float* gP, size_t gP_bstride, vqvae_stream_t s);
 /* The run-time guard of float32x2's pre-split storage (VQVAE_STORE_*_F16X2): pair i = (scale[i], amax[i]) names one
  * pre-split tensor by its SCALE words (the a-priori bound it was split under, word 0) and the words its producer raised
  * to its ACTUAL maximum.  A bound 2^m above the maximum costs m bits of the mode's absolute floor; the check counts, on

@@ -14,7 +14,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', ''), r['Grid_Size_X'], r['Workgroup_Size_X']) for r in rows), key=lambda t: t[0])
 adam = [i for i, k in enumerate(ks) if 'adam_kernel' in k[2]]
 # the last TIMED replay: bench.py runs eager steps after the timed region (roofline pass) -- take the replay with the most regular spacing: the 4th from the end of the first 9+... simply the step before the last gap > 2 ms
-step = ks[adam[-8] + 1:adam[-7] + 1] if len(adam) > 9 else ks[adam[-2] + 1:adam[-1] + 1]
+# bench.py (steps = 6): ... 6 timed replays, 1 eager step, 6 eager steps of the roofline pass -> the 4th timed replay ends at adam[-10]
+step = ks[adam[-11] + 1:adam[-10] + 1]
 t0 = step[0][0]
 print('%d launches, %.3f ms wall (first start to adam end), %.3f ms kernel time' % (len(step), (step[-1][1] - t0) / 1e6, sum(e - s for s, e, *_ in step) / 1e6))
 with open(sys.argv[2], 'w') as f:
