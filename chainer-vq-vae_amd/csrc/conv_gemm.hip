@@ -3344,6 +3344,26 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // two taps of one tensor: interleave them channel group by channel group (TAP2).  The choice depends
   // on the contraction only, never on the tile shape, so that a result does not change with the batch size.
   static const int x3_tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
+  // A 1x1 conv over >= 64 channels into 256-row tiles (proj1 / proj2 and their backward-data, the latent-rate condition
+  // projection): ONE segment, so it used to miss the two-tap loop and run 256 x 256 tiles, one workgroup per CU, 16 K steps
+  // between a prologue and a 256 KB epilogue -- 16 GFLOP in 105 us, 0.18 of the three-product ceiling.  Its contraction is
+  // presented as TWO segments, the lower and the upper half of the channels (same tensor, same shift; the second slab is the
+  // first one's upper K steps), which the TAP2 / LEAN loop interleaves like two taps: two workgroups per CU, one tile's
+  // epilogue beside the other's loop.  Depends on the contraction only (never on B or T); the K order changes, the products do not.
+  // (proj1 / proj2 forward and backward-data 105 -> ~70 us each, the step 14.87 -> 14.73 ms: same box, two interleaved rounds)
+  if constexpr (EPI == EPI_LINEAR) {
+    Seg& s0 = g.seg[0];
+    if (x3_tap2 && big && (mode == 2 || mode == 3) && g.nseg == 1 && g.ksplit == 1 && s0.cin >= 64 && s0.cin % 32 == 0 &&
+        s0.tmul == 1 && s0.tdiv == 1 && !g.x16 && !g.z16 && !g.add16 && !g.y16) {
+      Seg& s1 = g.seg[1];
+      s1 = s0;
+      const int half = s0.cin / 2;
+      s0.cin = s1.cin = half;
+      s1.x = s0.x + (long)half * s0.x_cstride;
+      s1.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(s0.w) + (size_t)(half / BK) * 32u * (mode == 3 ? 2 : 3) * (size_t)s0.ldw);
+      g.nseg = 2;
+    }
+  }
   const bool tap2 = x3_tap2 && mode != 0 && g.nseg == 2 && g.ksplit == 1 &&
                     g.seg[0].cin == g.seg[1].cin && g.seg[0].cin % BK == 0 &&
                     g.seg[0].x_cstride == g.seg[1].x_cstride && g.seg[0].x_bstride == g.seg[1].x_bstride &&
