@@ -3354,6 +3354,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if constexpr (EPI == EPI_LINEAR) {
     Seg& s0 = g.seg[0];
     if (x3_tap2 && big && (mode == 2 || mode == 3) && g.nseg == 1 && g.ksplit == 1 && s0.cin >= 64 && s0.cin % 32 == 0 &&
+        !(g.M == 256 && s0.cin == 128) &&      // (the residual 1x1's shape keeps the K order of lin128_stream_kernel, its bitwise twin)
         s0.tmul == 1 && s0.tdiv == 1 && !g.x16 && !g.z16 && !g.add16 && !g.y16) {
       Seg& s1 = g.seg[1];
       s1 = s0;

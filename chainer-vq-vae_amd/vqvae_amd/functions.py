@@ -363,6 +363,101 @@ class Conv1dFunction(FunctionNode):
         return (gx, gW, gb) if self._has_b else (gx, gW)
 
 
+# --------------------------------------------------------------------------- #
+# a stack of "same"-padded dilated 3-tap convs + ReLU at the latent rate in ONE launch per direction
+# (ConditionEmbed's five local convs, net.py:34-53; csrc/latent.hip)
+# --------------------------------------------------------------------------- #
+FUSE_CONV_STACK = True
+
+
+class ConvStackFunction(FunctionNode):
+    """inputs (x, W_1, b_1, ..., W_L, b_L) -> h_L, h_l = relu(conv(h_{l-1}; W_l, pad = dilate = dil_l) + b_l).  One workgroup per
+    sample keeps the sample's (C, T') state in LDS through all layers; the backward launch walks them back (ReLU masks,
+    bias / weight gradients as per-sample shares summed in a fixed order, backward-data) and a second tiny launch reduces the
+    shares.  Replaces L conv launches forward and 3 L backward, all of them latency (25-60 us each for ~2 us of arithmetic)."""
+
+    def __init__(self, dilations):
+        self.dil = [int(d) for d in dilations]
+
+    @staticmethod
+    def supported(x, Ws, dilations):
+        if not FUSE_CONV_STACK or not isinstance(x, DeviceArray):
+            return False
+        if _lib.load().vqvae_get_matmul_dtype() == 1:      # 'bfloat16': every conv rounds its operands (the mode's contract); the stack computes in fp32
+            return False
+        if len(x.shape) < 3:
+            return False
+        B, Cc, T = x.shape[:3]
+        if any(W is None or not isinstance(W, DeviceArray) or tuple(W.shape[:3]) != (Cc, Cc, 3) for W in Ws):
+            return False
+        arr = (C.c_int * len(dilations))(*[int(d) for d in dilations])
+        return bool(_lib.load().vqvae_convstack_supported(len(dilations), Cc, T, arr))
+
+    def forward(self, inputs):
+        backend.require_device(*inputs)
+        x = inputs[0]
+        L = len(self.dil)
+        assert len(inputs) == 1 + 2 * L
+        B, Cc, T = x.shape[:3]
+        Ws, bs = inputs[1::2], inputs[2::2]
+        hs = [DeviceArray(x.shape, np.float32) for _ in range(L)]
+        dil = (C.c_int * L)(*self.dil)
+        _lib.call('vqvae_convstack_fwd', L, B, Cc, T, dil, x.ptr, _lib.ptr_array(Ws), _lib.ptr_array(bs),
+                  _lib.ptr_array(hs), _S())
+        self._hs = hs
+        self.retain_inputs(tuple(range(len(inputs))))
+        hs[-1].relu_out = False           # (this node applies its own ReLU masks: a reader must not fuse one into its backward)
+        return hs[-1],
+
+    def backward(self, indexes, gys):
+        ins = [v.data for v in self.get_retained_inputs()]
+        x = ins[0]
+        L = len(self.dil)
+        B, Cc, T = x.shape[:3]
+        Ws = ins[1::2]
+        gy = gys[0].data
+        gx = DeviceArray(x.shape, np.float32) if 0 in indexes else None
+        gWs, gbs = [], []
+        for l in range(L):
+            wv, bv = self.inputs[1 + 2 * l], self.inputs[2 + 2 * l]
+            gW = gb = None
+            if (1 + 2 * l) in indexes:
+                buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
+                gW = buf.reshape(Ws[l].shape) if buf is not None else DeviceArray(Ws[l].shape, np.float32)
+            if (2 + 2 * l) in indexes:
+                buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
+                gb = buf if buf is not None else DeviceArray((Cc,), np.float32)
+            gWs.append(gW)
+            gbs.append(gb)
+        dil = (C.c_int * L)(*self.dil)
+        nbytes = _lib.load().vqvae_convstack_workspace_bytes(L, B, Cc)
+        ws = DeviceArray((int(nbytes) // 4 + 1,), np.float32)
+        _lib.call('vqvae_convstack_bwd', L, B, Cc, T, dil, x.ptr, _lib.ptr_array(Ws), _lib.ptr_array(self._hs), gy.ptr,
+                  _p(gx), _lib.ptr_array(gWs), _lib.ptr_array(gbs), 0, ws.ptr, ws.nbytes, _S())
+        self._hs = None
+        out = [gx]
+        for l in range(L):
+            out += [gWs[l], gbs[l]]
+        return tuple(out)
+
+
+def conv_stack(x, convs):
+    """relu(conv_L(... relu(conv_1(x)))) for a list of DilatedConvolution2D links (3 taps, pad == dilate, stride 1, C -> C): one
+    fused node where the library serves the shape, else the links one by one (relu fused in each conv's epilogue)."""
+    x = as_variable(x)
+    ok = all(getattr(c, 'W', None) is not None and c.W.data is not None and c.b is not None and c.b.data is not None
+             and c.stride[0] == 1 and c.pad[0] == c.dilate[0] for c in convs)
+    if ok and ConvStackFunction.supported(x.data, [c.W.data for c in convs], [c.dilate[0] for c in convs]):
+        args = [x]
+        for c in convs:
+            args += [c.W, c.b]
+        return ConvStackFunction([c.dilate[0] for c in convs]).apply(args)[0]
+    h = x
+    for c in convs:
+        h = c(h, relu=True)
+    return h
+
+
 def convolution_1d(x, W, b=None, stride=1, pad=0, dilate=1, out_len=None, relu=False):
     args = (x, W) if b is None else (x, W, b)
     return Conv1dFunction(stride, pad, dilate, out_len, relu).apply(args)[0]

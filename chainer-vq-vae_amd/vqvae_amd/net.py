@@ -53,9 +53,16 @@ class ConditionEmbed(Chain):
         self.upscale_factor = upscale_factor
 
     def __call__(self, local_condition, global_condition):
+        convs = [getattr(self, 'local_embed%d' % i) for i in range(1, len(_COND_DILATIONS) + 1)]
         h = local_condition
-        for i in range(1, len(_COND_DILATIONS) + 1):
-            h = getattr(self, 'local_embed%d' % i)(h, relu=True)
+        width = h.shape[1]
+        for c in convs:                        # lazily shaped (net.py:34-43): the first call creates the parameters, as the links would
+            if c.W.data is None:
+                c._initialize_params(width)
+                if isinstance(h.data, backend.DeviceArray):
+                    c.W.to_gpu()
+            width = c.W.shape[0]
+        h = F.conv_stack(h, convs)             # one launch per direction where the library serves the shape (csrc/latent.hip)
         # resize_images(local) ++ resize_images(EmbedID(speaker)) ++ concat in one node that
         # keeps the result at the latent rate until a consumer needs the full-rate tensor
         return F.condition_assemble(h, self.global_embed.W, global_condition, self.upscale_factor)

@@ -371,6 +371,22 @@ int vqvae_pullback_reduce_into(const float* part, const int32_t* v0, int nblocks
  * all-zero tensors are skipped.  There is no counterpart in the reference (Chainer computes in fp32, modules.py:40-55). */
 int vqvae_f32x2_contract_check(int n, const uint32_t* const* scale, const uint32_t* const* amax, int log2_limit,
                                uint32_t* report, vqvae_stream_t s);
+
+/* ---- a stack of latent-rate convolutions in one launch per direction (csrc/latent.hip) -------------------------------
+ * L "same"-padded dilated 3-tap convs + ReLU over (B, C, T) tensors, layer l: h_l = relu(conv(h_{l-1}; W_l (C, C, 3), pad =
+ * dil_l, dilate = dil_l) + b_l), h_0 = x -- ConditionEmbed's five local convs (net.py:34-53).  One workgroup per sample
+ * keeps the sample's state in LDS; every h_l is written once for the backward.  Served: L <= 8, C in {32, 64}, T <= 128,
+ * dilations <= 16 (vqvae_convstack_supported); fp32 MFMA arithmetic in every matmul mode.
+ *   fwd:  h[l] (B, C, T) receives h_{l+1}, l = 0 .. L-1
+ *   bwd:  gy = gradient of h_L; gx (nullable) = gradient of x; gW[l] / gb[l] (nullable) receive (accumulate != 0: are added)
+ *         the parameter gradients, summed over the samples in ascending order (deterministic); ws: convstack_workspace_bytes */
+int vqvae_convstack_supported(int L, int C, int T, const int* dil);
+size_t vqvae_convstack_workspace_bytes(int L, int B, int C);
+int vqvae_convstack_fwd(int L, int B, int C, int T, const int* dil, const float* x, const float* const* W,
+                        const float* const* b, float* const* h, vqvae_stream_t s);
+int vqvae_convstack_bwd(int L, int B, int C, int T, const int* dil, const float* x, const float* const* W,
+                        const float* const* h, const float* gy, float* gx, float* const* gW, float* const* gb,
+                        int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
                         const vqvae_resblock_params* params, const int* has_res, void* packed,

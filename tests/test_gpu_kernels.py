@@ -1238,3 +1238,56 @@ def test_mean_squared_difference_keeps_the_bits_of_the_arithmetic_chain(gpu):
             out.append((l.data.get().copy(), va.grad.get().copy(), vb.grad.get().copy()))
         for x, y in zip(*out):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize('B,Cc,T,dils', [(3, 64, 120, (1, 2, 4, 8, 16)), (2, 32, 8, (1, 2, 4, 8, 16)), (1, 64, 128, (16, 1)),
+                                         (4, 32, 37, (3,))])
+def test_conv_stack_fused_vs_oracle(gpu, matmul_mode, B, Cc, T, dils):
+    """csrc/latent.hip: ConditionEmbed's stack of "same"-padded dilated 3-tap convs + ReLU (net.py:34-53) as one launch per
+    direction -- h_L, the input gradient and every weight / bias gradient against the oracle's layer-by-layer restatement
+    (1e-4), and against the library's own conv-by-conv path."""
+    from vqvae_amd import functions as F, links as L
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(100 + Cc + T)
+    x = rs.standard_normal((B, Cc, T)).astype(np.float32)
+    Ws = [(rs.standard_normal((Cc, Cc, 3)) / np.sqrt(3 * Cc)).astype(np.float32) for _ in dils]
+    bs = [(0.1 * rs.standard_normal(Cc)).astype(np.float32) for _ in dils]
+    gy = rs.standard_normal((B, Cc, T)).astype(np.float32)
+    # oracle
+    hs = [x]
+    for W, b, d in zip(Ws, bs, dils):
+        hs.append(np.maximum(O.conv1d_fwd(hs[-1], W, b, pad=d, dil=d), 0))
+    g = gy
+    want_gW, want_gb = [None] * len(dils), [None] * len(dils)
+    for l in range(len(dils) - 1, -1, -1):
+        g = g * (hs[l + 1] > 0)
+        g, want_gW[l], want_gb[l] = O.conv1d_bwd(hs[l], Ws[l], g, pad=dils[l], dil=dils[l])
+
+    def run(fused):
+        convs = []
+        for W, b, d in zip(Ws, bs, dils):
+            c = L.DilatedConvolution2D(Cc, Cc, (3, 1), pad=(d, 0), dilate=(d, 1))
+            c.W.data = to4(W).copy()
+            c.b.data = b.copy()
+            c.to_gpu()
+            convs.append(c)
+        vx = Variable(_dev(gpu, to4(x)))
+        old = F.FUSE_CONV_STACK
+        F.FUSE_CONV_STACK = fused
+        try:
+            y = F.conv_stack(vx, convs)
+        finally:
+            F.FUSE_CONV_STACK = old
+        assert isinstance(y.creator, F.ConvStackFunction) == fused
+        y.grad = _dev(gpu, to4(gy))
+        y.backward()
+        return (y.data.get()[..., 0], vx.grad.get()[..., 0], [c.W.grad.get()[..., 0] for c in convs], [c.b.grad.get() for c in convs])
+    got = run(True)
+    assert_close(got[0], hs[-1], 1e-4, 'conv stack h_L')
+    assert_close_scaled(got[1], g, 1e-4, 'conv stack gx')
+    for l in range(len(dils)):
+        assert_close_scaled(got[2][l], want_gW[l], 1e-4, 'conv stack gW %d' % l)
+        assert_close_scaled(got[3][l], want_gb[l], 1e-4, 'conv stack gb %d' % l)
+    ref = run(False)
+    assert_close(got[0], ref[0], 2e-5, 'fused vs conv-by-conv h_L')
+    assert_close_scaled(got[1], ref[1], 2e-5, 'fused vs conv-by-conv gx')
