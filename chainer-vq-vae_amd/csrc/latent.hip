@@ -41,63 +41,64 @@ template <int C> struct CStackGeom {
                                                             // walk down the rows (weight-gradient operands) touches 32 banks too
   static constexpr int WP = 3 * C + 1;                      // LDS row pitch of the weights (odd)
   static constexpr int NW = (C / 32) * 4;                   // waves: one 32 x 32 tile each of the C x 128 output
-  static constexpr size_t lds_fwd = (size_t)(2 * C * TP + C * WP) * sizeof(float);
+  static constexpr size_t lds_fwd = (size_t)(2 * C * TP) * sizeof(float);      // (the weights are read from L2 as the MFMA's A operand: a weight
+                                                                               //  image would put the workgroup at 132 KB of LDS, and it has to fit BESIDE a
+                                                                               //  49 KB weight-gradient workgroup of the decoder or it waits ~0.5 ms for a free CU)
 };
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_fwd_kernel(const CStackArgs a) {
+__global__ __launch_bounds__(CStackGeom<C>::NW * 64, 4) void cstack_fwd_kernel(const CStackArgs a) {
   using G = CStackGeom<C>;
-  constexpr int TP = G::TP, WP = G::WP, NT = G::NW * 64;
-  constexpr int WPT = (C * 3 * C + NT - 1) / NT;           // weight elements per thread and layer
+  constexpr int TP = G::TP, NT = G::NW * 64;
   extern __shared__ float lds[];
   float* act0 = lds;                     // [C][TP]
   float* act1 = lds + C * TP;
-  float* wl = lds + 2 * C * TP;          // [C][WP]: wl[co][j * C + ci] = W[co][ci][j]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int b = blockIdx.x, T = a.T;
+  const int mt = wave & (C / 32 - 1), nt = wave / (C / 32);       // this wave's tile: rows 32 mt .., columns 32 nt ..
+  const int n = nt * 32 + li;
+  // A operand of step (j, c): W[co = 32 mt + li][ci = c + kh][j] -- straight from L2, in sixths of a layer (half a tap: C / 4 MFMA
+  // steps) through a ring of three register buffers, two sixths ahead of the MFMAs (<= 128 VGPRs: two workgroups' worth per CU)
+  constexpr int H = C / 4;
+  auto fetch_a = [&](int l, int sx, float (&av)[H]) {              // sx = 2 j + half
+    const float* wr = a.W[l] + (long)(32 * mt + li) * (3 * C) + 3 * kh + (sx >> 1) + 6 * H * (sx & 1);
+#pragma unroll
+    for (int q = 0; q < H; ++q) av[q] = wr[6 * q];
+  };
+  float r0[H], r1[H], r2[H];
+  fetch_a(0, 0, r0); fetch_a(0, 1, r1);
   // zero both activation images (halos and the columns beyond T stay zero for the whole launch)
   for (int i = tid; i < 2 * C * TP; i += NT) lds[i] = 0.f;
-  float wreg[WPT];
-  auto fetch_w = [&](int l) {
-    const float* W = a.W[l];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) { const int e = tid + NT * i; wreg[i] = e < C * 3 * C ? W[e] : 0.f; }
-  };
-  auto store_w = [&]() {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + NT * i;
-      if (e < C * 3 * C) { const int co = e / (3 * C), r = e - co * 3 * C, ci = r / 3, j = r - 3 * ci; wl[co * WP + j * C + ci] = wreg[i]; }
-    }
-  };
-  fetch_w(0);
   __syncthreads();
   {
     const float* xb = a.x + (long)b * C * T;
     for (int i = tid; i < C * T; i += NT) { const int c = i / T, t = i - c * T; act0[c * TP + CS_HALO + t] = xb[i]; }
   }
-  store_w();
   __syncthreads();
-  const int mt = wave & (C / 32 - 1), nt = wave / (C / 32);       // this wave's tile: rows 32 mt .., columns 32 nt ..
-  const int n = nt * 32 + li;
   for (int l = 0; l < a.L; ++l) {
     const float* in = (l & 1) ? act1 : act0;
     float* out = (l & 1) ? act0 : act1;
-    if (l + 1 < a.L) fetch_w(l + 1);                               // travels under this layer's MFMAs
     const int dil = a.dil[l];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* ar = wl + (32 * mt + li) * WP + kh;
+    const float* br = in + kh * TP + CS_HALO + n;
+    const bool more = l + 1 < a.L;
+    auto mma6 = [&](const float (&av)[H], int sx) {                // channels c = 2 (q + H * half) + kh, column shift (j - 1) dil
+      const float* bq = br + (2 * H * (sx & 1)) * TP + ((sx >> 1) - 1) * dil;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float* br = in + kh * TP + CS_HALO + n + (j - 1) * dil;
-#pragma unroll 8
-      for (int c = 0; c < C; c += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[j * C + c], br[c * TP], acc, 0, 0, 0);
-    }
+      for (int q = 0; q < H; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[2 * q * TP], acc, 0, 0, 0);
+    };
+    fetch_a(l, 2, r2); mma6(r0, 0);
+    fetch_a(l, 3, r0); mma6(r1, 1);
+    fetch_a(l, 4, r1); mma6(r2, 2);
+    fetch_a(l, 5, r2); mma6(r0, 3);
+    if (more) fetch_a(l + 1, 0, r0);
+    mma6(r1, 4);
+    if (more) fetch_a(l + 1, 1, r1);
+    mma6(r2, 5);
     float* hb = a.h[l] + (long)b * C * T;
     const float* bias = a.b[l];
 #pragma unroll
@@ -107,39 +108,22 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_fwd_kernel(cons
       v = fmaxf(v, 0.f);
       if (n < T) { out[m * TP + CS_HALO + n] = v; hb[(long)m * T + n] = v; }
     }
-    __syncthreads();                    // every wave is done with `in` and with wl
-    if (l + 1 < a.L) { store_w(); __syncthreads(); }
+    __syncthreads();                    // `out` is complete, every wave is done with `in`
   }
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_bwd_kernel(const CStackArgs a) {
+__global__ __launch_bounds__(CStackGeom<C>::NW * 64, 4) void cstack_bwd_kernel(const CStackArgs a) {
   using G = CStackGeom<C>;
-  constexpr int TP = G::TP, WP = G::WP, NT = G::NW * 64, NW = G::NW;
-  constexpr int WPT = (C * 3 * C + NT - 1) / NT;
+  constexpr int TP = G::TP, NT = G::NW * 64, NW = G::NW;
   extern __shared__ float lds[];
   float* bufA = lds;                     // [C][TP]
   float* bufB = lds + C * TP;
-  float* wt = lds + 2 * C * TP;          // [C][WP]: wt[ci][j * C + co] = W[co][ci][j]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int b = blockIdx.x, T = a.T, L = a.L;
   for (int i = tid; i < 2 * C * TP; i += NT) lds[i] = 0.f;
-  float wreg[WPT];
-  auto fetch_w = [&](int l) {
-    const float* W = a.W[l];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) { const int e = tid + NT * i; wreg[i] = e < C * 3 * C ? W[e] : 0.f; }
-  };
-  auto store_w = [&]() {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + NT * i;
-      if (e < C * 3 * C) { const int co = e / (3 * C), r = e - co * 3 * C, ci = r / 3, j = r - 3 * ci; wt[ci * WP + j * C + co] = wreg[i]; }
-    }
-  };
-  fetch_w(L - 1);
   __syncthreads();
   // g_L = gy * (h_L > 0) -> bufA;  h_{L-1} -> bufB
   float* g = bufA;
@@ -154,12 +138,10 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_bwd_kernel(cons
       hp[c * TP + CS_HALO + t] = hq[i];
     }
   }
-  store_w();
   __syncthreads();
   for (int l = L - 1; l >= 0; --l) {
     const int dil = a.dil[l];
     float* part = a.part + ((long)b * L + l) * (C * 3 * C + C);
-    if (l > 0) fetch_w(l - 1);
     // ---- bias gradient: row sums of g
     if (tid < C) {
       const float* gr = g + tid * TP + CS_HALO;
@@ -194,14 +176,29 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_bwd_kernel(cons
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* ar = wt + (32 * mt + li) * WP + kh;
+      // A operand of step (j, c): W[co = c + kh][ci = 32 mt + li][j] -- from L2, in sixths of the contraction through a ring of three
+      // register buffers (see cstack_fwd_kernel)
+      constexpr int H = C / 4;
+      const float* wr = a.W[l] + (long)kh * (3 * C) + 3 * (32 * mt + li);
+      const float* br = g + kh * TP + CS_HALO + n;
+      auto fetch_a = [&](int sx, float (&av)[H]) {
+        const float* w2 = wr + (long)(2 * H * (sx & 1)) * (3 * C) + (sx >> 1);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float* br = g + kh * TP + CS_HALO + n - (j - 1) * dil;
-#pragma unroll 8
-        for (int c = 0; c < C; c += 2)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[j * C + c], br[c * TP], acc, 0, 0, 0);
-      }
+        for (int q = 0; q < H; ++q) av[q] = w2[(long)(2 * q) * (3 * C)];
+      };
+      auto mma6 = [&](const float (&av)[H], int sx) {
+        const float* bq = br + (2 * H * (sx & 1)) * TP - ((sx >> 1) - 1) * dil;
+#pragma unroll
+        for (int q = 0; q < H; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[2 * q * TP], acc, 0, 0, 0);
+      };
+      float r0[H], r1[H], r2[H];
+      fetch_a(0, r0); fetch_a(1, r1);
+      fetch_a(2, r2); mma6(r0, 0);
+      fetch_a(3, r0); mma6(r1, 1);
+      fetch_a(4, r1); mma6(r2, 2);
+      fetch_a(5, r2); mma6(r0, 3);
+      mma6(r1, 4);
+      mma6(r2, 5);
       float* gxb = (l == 0) ? a.gx + (long)b * C * T : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -220,7 +217,6 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64) void cstack_bwd_kernel(cons
       float* tmp = g; g = hp; hp = tmp;
       const float* hq = (l >= 2 ? a.h[l - 2] : a.x) + (long)b * C * T;
       for (int i = tid; i < C * T; i += NT) { const int c = i / T, t = i - c * T; hp[c * TP + CS_HALO + t] = hq[i]; }
-      store_w();
       __syncthreads();
     }
   }
@@ -306,5 +302,164 @@ extern "C" int vqvae_convstack_bwd(int L, int B, int C, int T, const int* dil, c
   const int total = L * (C * 3 * C + C);
   hipLaunchKernelGGL(cstack_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)ws, gr, B, L, C, accumulate);
   VQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// =====================================================================================================================
+// Backward of ONE encoder stage (net.py:12-17: Convolution2D(C, C, (4, 1), stride 2, pad 1)) in ONE launch + a reduce:
+//     y[co][t] = b[co] + sum_{ci, j} W[co][ci][j] x[ci][2 t + j - 1]          x: (B, C, Tin), y: (B, C, Tout), Tout = Tin / 2
+//   gx[ci][u] = sum_{co, j} W[co][ci][j] gy[co][(u + 1 - j) / 2]  (where that is an integer), optionally * (x > 0)
+//   gW[co][ci][j] = sum_{b, t} gy[co][t] x[ci][2 t + j - 1],  gb[co] = sum_{b, t} gy[co][t]
+// It used to be four launches per stage (backward-data GEMM, phase split of x, weight-gradient GEMM, its reduce), each 15-150 us
+// of latency in the sweep's tail.  A workgroup owns 128 input columns [p0, p0 + 128) of one sample:
+//   * backward-data by PARITY: an even column u = 2 v takes taps 1 and 3 (t = v, v - 1), an odd one taps 0 and 2 (t = v + 1,
+//     v) -- two dense (C x 64) x K = 2 C products instead of one (C x 128) x K = 4 C with every other operand zero; with
+//     C = 64 that is exactly one 32 x 32 MFMA tile per wave (parity x row half x column half);
+//   * the weight gradient over the 64 output columns t = p0 / 2 .. + 63 the workgroup owns: (C x 4 C) x K = 64, two tiles
+//     per wave, written as this workgroup's share; cstage_reduce_kernel sums the shares in ascending order.
+// fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32); gy slice (17 KB) and x slice (34 KB) staged once in LDS, W read from L2.
+// =====================================================================================================================
+namespace vq {
+
+struct CStageArgs {
+  const float* x; const float* gy; const float* W;      // (B, C, Tin), (B, C, Tout), (C, C, 4)
+  float* gx;                                            // (B, C, Tin) or null
+  float* part;                                          // [B * nslice][C * 4 C + C]
+  int B, Tin, Tout, nslice, mask;                       // mask: gx *= (x > 0)
+};
+
+template <int C>
+__global__ __launch_bounds__(512, 4) void cstage_bwd_kernel(const CStageArgs a) {
+  static_assert(C == 64, "one MFMA tile per wave for backward-data needs C == 64");
+  constexpr int GP = 67, HP = 131, NT = 512;
+  extern __shared__ float lds[];
+  float* gl = lds;                        // [C][GP]: gy[co][t0 - 1 + i], i = 0 .. 65
+  float* hl = gl + C * GP;                // [C][HP]: x[ci][p0 - 1 + i], i = 0 .. 129
+  // (50 KB: the workgroup has to fit beside a 49 KB weight-gradient workgroup of the decoder, see cstack; backward-data's
+  //  weights are read from L2 as the MFMA's A operand)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.x / a.nslice, sl = blockIdx.x - b * a.nslice;
+  const int p0 = sl * 128, t0 = p0 / 2;
+  const int Tin = a.Tin, Tout = a.Tout;
+  // ---- stage everything (all loads are independent: they travel together)
+  {
+    const float* gyb = a.gy + (long)b * C * Tout;
+    for (int i = tid; i < C * 66; i += NT) {
+      const int c = i / 66, q = i - c * 66, t = t0 - 1 + q;
+      gl[c * GP + q] = (t >= 0 && t < Tout) ? gyb[(long)c * Tout + t] : 0.f;
+    }
+    const float* xb = a.x + (long)b * C * Tin;
+    for (int i = tid; i < C * 130; i += NT) {
+      const int c = i / 130, q = i - c * 130, u = p0 - 1 + q;
+      hl[c * HP + q] = (u >= 0 && u < Tin) ? xb[(long)c * Tin + u] : 0.f;
+    }
+  }
+  __syncthreads();
+  float* part = a.part + (long)blockIdx.x * (C * 4 * C + C);
+  // ---- bias share: the owned columns t0 .. t0 + 63 are gl columns 1 .. 64
+  if (tid < C) {
+    float s = 0.f;
+    for (int q = 1; q <= 64; ++q) s += gl[tid * GP + q];
+    part[C * 4 * C + tid] = s;
+  }
+  // ---- weight-gradient share: (co) x (j, ci), K = the 64 owned t; tiles: 2 row x 8 column, two per wave
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int tile = wave + 8 * rep, mt = tile & 1, nt = tile >> 1;
+    const int ncol = nt * 32 + li, j = ncol / C, ci = ncol - j * C;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ar = gl + (32 * mt + li) * GP + 1 + kh;                 // gy[co][t0 + t + kh]
+    const float* br = hl + ci * HP + 2 * kh + j;                          // x[ci][2 (t0 + t + kh) + j - 1] = hl[ci][2 t + 2 kh + j]
+#pragma unroll 8
+    for (int t = 0; t < 64; t += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[t], br[2 * t], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      part[(long)m * (4 * C) + ncol] = acc[r];
+    }
+  }
+  // ---- backward-data by parity
+  if (a.gx != nullptr) {
+    const int par = wave & 1, mt = (wave >> 1) & 1, nt = wave >> 2;
+    const int v = nt * 32 + li;                                            // local column pair index: u = p0 + 2 v + par
+    // even u: taps (1, t = v), (3, t = v - 1); odd u: taps (0, t = v + 1), (2, t = v);  gl column of t0 + t' is t' + 1
+    const int ja = par ? 0 : 1, jb = par ? 2 : 3;
+    const int qa = par ? v + 2 : v + 1, qb = par ? v + 1 : v;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A operand of step (j, c): W[co = c + kh][ci = 32 mt + li][j]: both taps' 32 + 32 values requested before the first MFMA
+    const float* wr = a.W + (long)kh * (4 * C) + 4 * (32 * mt + li);
+    float wa[C / 2], wb[C / 2];
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) { wa[q] = wr[(long)(2 * q) * (4 * C) + ja]; wb[q] = wr[(long)(2 * q) * (4 * C) + jb]; }
+    const float* ba = gl + kh * GP + qa;
+    const float* bb = gl + kh * GP + qb;
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q], ba[2 * q * GP], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[q], bb[2 * q * GP], acc, 0, 0, 0);
+    const int u = p0 + 2 * v + par;
+    float* gxb = a.gx + (long)b * C * Tin;
+    if (u < Tin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float val = acc[r];
+        if (a.mask) val = hl[m * HP + (u - p0 + 1)] > 0.f ? val : 0.f;
+        gxb[(long)m * Tin + u] = val;
+      }
+    }
+  }
+}
+
+// gW[co][ci][j] (+)= sum_w part[w][co][j * C + ci];  gb[co] (+)= sum_w part[w][C * 4C + co]   (ascending w: deterministic)
+__global__ __launch_bounds__(256) void cstage_reduce_kernel(const float* __restrict__ part, int nwg, int C, float* __restrict__ gW,
+                                                            float* __restrict__ gb, int accumulate) {
+  const int per = C * 4 * C + C;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                 // four independent chains keep the loads in flight; the ORDER of the final
+  int w = 0;                                                    // additions is fixed, so the result is reproducible
+  for (; w + 3 < nwg; w += 4) {
+    s0 += part[(long)w * per + e]; s1 += part[(long)(w + 1) * per + e];
+    s2 += part[(long)(w + 2) * per + e]; s3 += part[(long)(w + 3) * per + e];
+  }
+  for (; w < nwg; ++w) s0 += part[(long)w * per + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (e < C * 4 * C) {
+    if (gW) { const int co = e / (4 * C), r = e - co * 4 * C, j = r / C, ci = r - j * C; float* q = gW + ((long)co * C + ci) * 4 + j; *q = accumulate ? *q + s : s; }
+  } else if (gb) { float* q = gb + (e - C * 4 * C); *q = accumulate ? *q + s : s; }
+}
+
+}  // namespace vq
+
+extern "C" int vqvae_conv_s2_bwd_supported(int Cin, int Cout, int K, int stride, int pad, int dil, int Tin, int Tout) {
+  return (Cin == 64 && Cout == 64 && K == 4 && stride == 2 && pad == 1 && dil == 1 && Tin >= 2 && Tout == Tin / 2) ? 1 : 0;
+}
+extern "C" size_t vqvae_conv_s2_bwd_workspace_bytes(int B, int C, int Tin) {
+  return (size_t)B * ((Tin + 127) / 128) * ((size_t)C * 4 * C + C) * sizeof(float);
+}
+extern "C" int vqvae_conv_s2_bwd(int B, int C, int Tin, int Tout, const float* x, const float* W, const float* gy, int mask_by_x,
+                                 float* gx, float* gW, float* gb, int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s) {
+  VQ_REQUIRE(x && W && gy && ws && B > 0 && vqvae_conv_s2_bwd_supported(C, C, 4, 2, 1, 1, Tin, Tout), "conv_s2_bwd: unsupported stage (C = 64, 4 taps, stride 2, pad 1, Tout = Tin / 2)");
+  if (ws_bytes < vqvae_conv_s2_bwd_workspace_bytes(B, C, Tin)) { set_error("conv_s2_bwd: workspace too small"); return VQVAE_E_WORKSPACE; }
+  CStageArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.gy = gy; a.W = W; a.gx = gx; a.part = (float*)ws; a.B = B; a.Tin = Tin; a.Tout = Tout;
+  a.nslice = (Tin + 127) / 128; a.mask = mask_by_x;
+  const size_t lds = (size_t)(64 * 67 + 64 * 131) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cstage_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  hipLaunchKernelGGL(cstage_bwd_kernel<64>, dim3(B * a.nslice), dim3(512), lds, (hipStream_t)s, a);
+  VQ_LAUNCH_CHECK();
+  if (gW || gb) {
+    const int per = C * 4 * C + C;
+    hipLaunchKernelGGL(cstage_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)ws, B * a.nslice, C, gW, gb, accumulate);
+    VQ_LAUNCH_CHECK();
+  }
   return 0;
 }

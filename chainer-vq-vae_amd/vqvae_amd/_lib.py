@@ -167,6 +167,9 @@ PROTOTYPES = {
     'vqvae_convstack_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'vqvae_convstack_fwd': (c_int, [c_int, c_int, c_int, c_int, C.POINTER(c_int), P, PP, PP, PP, P]),
     'vqvae_convstack_bwd': (c_int, [c_int, c_int, c_int, c_int, C.POINTER(c_int), P, PP, PP, P, P, PP, PP, c_int, P, c_size_t, P]),
+    'vqvae_conv_s2_bwd_supported': (c_int, [c_int] * 8),
+    'vqvae_conv_s2_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'vqvae_conv_s2_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, P, c_int, P, c_size_t, P]),
     'vqvae_upsample_linear_bwd_f16x2': (c_int, [P, c_long, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                                 P, c_long, P, P]),
     'vqvae_mulaw_bins': (c_int, [P, c_size_t, P, c_int, P, P]),

@@ -323,6 +323,26 @@ class Conv1dFunction(FunctionNode):
         wsb = _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.desc))
         ws = backend.workspace(wsb)
         f32x2 = self._f32x2 and bool(_lib.load().vqvae_conv1d_uses_f32x2(C.byref(self.desc)))
+        d = self.desc
+        if (FUSE_S2_BWD and 1 in indexes and not f32x2 and _lib.load().vqvae_get_matmul_dtype() != 1
+                and _lib.load().vqvae_conv_s2_bwd_supported(d.Cin, d.Cout, d.K, d.stride, d.pad, d.dil, d.Tin, d.Tout)):
+            # an encoder stage (net.py:12-17): backward-data, weight and bias gradient in ONE launch + a reduce (csrc/latent.hip)
+            gx = DeviceArray(self._x_shape, np.float32) if 0 in indexes else None
+            wv = self.inputs[1]
+            buf = wv.grad_buffer() if hasattr(wv, 'grad_buffer') else None
+            gW = buf.reshape(W.shape) if buf is not None else DeviceArray(W.shape, np.float32)
+            gb = None
+            if self._has_b:
+                bv = self.inputs[2]
+                buf = bv.grad_buffer() if hasattr(bv, 'grad_buffer') else None
+                gb = buf if buf is not None else DeviceArray((d.Cout,), np.float32)
+            mask = bool(gx is not None and getattr(x, 'relu_out', False) and FUSE_RELU_BWD and _mask_has_a_taker(self.inputs[0]))
+            w2 = backend.workspace(_lib.load().vqvae_conv_s2_bwd_workspace_bytes(d.B, d.Cin, d.Tin))
+            _lib.call('vqvae_conv_s2_bwd', d.B, d.Cin, d.Tin, d.Tout, x.ptr, W.ptr, gy.ptr, 1 if mask else 0,
+                      _p(gx), gW.ptr, _p(gb), 0, w2.ptr, w2.nbytes, _S())
+            if gx is not None:
+                gx.relu_masked = mask
+            return (gx, gW, gb) if self._has_b else (gx, gW)
         gx = None
         if 0 in indexes:
             gx = DeviceArray(self._x_shape, np.float32)
@@ -368,6 +388,7 @@ class Conv1dFunction(FunctionNode):
 # (ConditionEmbed's five local convs, net.py:34-53; csrc/latent.hip)
 # --------------------------------------------------------------------------- #
 FUSE_CONV_STACK = True
+FUSE_S2_BWD = True        # an encoder stage's whole backward in one launch (Conv1dFunction.backward)
 
 
 class ConvStackFunction(FunctionNode):

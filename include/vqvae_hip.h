@@ -387,6 +387,15 @@ int vqvae_convstack_fwd(int L, int B, int C, int T, const int* dil, const float*
 int vqvae_convstack_bwd(int L, int B, int C, int T, const int* dil, const float* x, const float* const* W,
                         const float* const* h, const float* gy, float* gx, float* const* gW, float* const* gb,
                         int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
+/* The whole backward of ONE encoder stage -- Convolution2D(C, C, (4, 1), stride 2, pad 1), net.py:12-17, C = 64 -- in one
+ * launch + a reduce instead of four (backward-data GEMM, phase split, weight-gradient GEMM, reduce): gx (nullable; with
+ * mask_by_x != 0 multiplied by x > 0, the backward of the ReLU that produced x), gW (C, C, 4) and gb (C,) (nullable;
+ * accumulate != 0: added to).  Workgroups own 128 input columns each; their weight-gradient shares are summed in ascending
+ * order (deterministic).  fp32 MFMA arithmetic in every matmul mode.  ws: vqvae_conv_s2_bwd_workspace_bytes. */
+int vqvae_conv_s2_bwd_supported(int Cin, int Cout, int K, int stride, int pad, int dil, int Tin, int Tout);
+size_t vqvae_conv_s2_bwd_workspace_bytes(int B, int C, int Tin);
+int vqvae_conv_s2_bwd(int B, int C, int Tin, int Tout, const float* x, const float* W, const float* gy, int mask_by_x,
+                      float* gx, float* gW, float* gb, int accumulate, void* ws, size_t ws_bytes, vqvae_stream_t s);
 size_t vqvae_resstack_packed_bytes(const vqvae_resblock_desc* d);
 int vqvae_resstack_pack(const vqvae_resblock_desc* d, int nblocks,
                         const vqvae_resblock_params* params, const int* has_res, void* packed,

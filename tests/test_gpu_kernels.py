@@ -1291,3 +1291,47 @@ def test_conv_stack_fused_vs_oracle(gpu, matmul_mode, B, Cc, T, dils):
     ref = run(False)
     assert_close(got[0], ref[0], 2e-5, 'fused vs conv-by-conv h_L')
     assert_close_scaled(got[1], ref[1], 2e-5, 'fused vs conv-by-conv gx')
+
+
+@pytest.mark.parametrize('B,Tin,relu_in', [(2, 240, True), (3, 128, False), (1, 960, True), (2, 130, True)])
+def test_encoder_stage_backward_fused_vs_oracle(gpu, matmul_mode, B, Tin, relu_in):
+    """csrc/latent.hip cstage_bwd_kernel: the whole backward of an encoder stage (64 -> 64 channels, 4 taps, stride 2, pad 1;
+    net.py:12-17) in one launch + a reduce -- gx (with the input ReLU's mask where the input is a ReLU output whose producer
+    takes the mask), gW, gb against the oracle, and against the library's four-launch path."""
+    from vqvae_amd import functions as F, links as L
+    from vqvae_amd.core import Variable
+    rs = np.random.RandomState(Tin)
+    Cc, Tout = 64, Tin // 2
+    x0 = rs.standard_normal((B, Cc, Tin)).astype(np.float32)
+    W = (rs.standard_normal((Cc, Cc, 4)) / 16).astype(np.float32)
+    b = (0.1 * rs.standard_normal(Cc)).astype(np.float32)
+    gy = rs.standard_normal((B, Cc, Tout)).astype(np.float32)
+    x = np.maximum(x0, 0) if relu_in else x0
+    want_gx, want_gW, want_gb = O.conv1d_bwd(x, W, gy, stride=2, pad=1)
+    if relu_in:
+        want_gx = want_gx * (x0 > 0)
+
+    def run(fused):
+        conv = L.Convolution2D(Cc, Cc, (4, 1), stride=(2, 1), pad=(1, 0))
+        conv.W.data = to4(W).copy()
+        conv.b.data = b.copy()
+        conv.to_gpu()
+        vx = Variable(_dev(gpu, to4(x0)))
+        h = F.relu(vx) if relu_in else vx
+        old = F.FUSE_S2_BWD
+        F.FUSE_S2_BWD = fused
+        try:
+            y = conv(h)
+            y.grad = _dev(gpu, to4(gy))
+            y.backward()
+        finally:
+            F.FUSE_S2_BWD = old
+        return vx.grad.get()[..., 0], conv.W.grad.get()[..., 0], conv.b.grad.get(), y.data.get()[..., 0]
+    got = run(True)
+    assert_close(got[3], O.conv1d_fwd(x, W, b, stride=2, pad=1)[:, :, :Tout], 1e-4, 'stage y')
+    assert_close_scaled(got[0], want_gx, 1e-4, 'stage gx')
+    assert_close_scaled(got[1], want_gW, 1e-4, 'stage gW')
+    assert_close_scaled(got[2], want_gb, 1e-4, 'stage gb')
+    ref = run(False)
+    for a_, b_, n in zip(got[:3], ref[:3], ('gx', 'gW', 'gb')):
+        assert_close_scaled(a_, b_, 2e-5, 'fused vs four launches: ' + n)
