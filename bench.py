@@ -364,11 +364,14 @@ def spawn_ranks(n, argv):
     raise SystemExit(rc)
 
 
+NO_AFFINITY = [False]      # --no-affinity
+
+
 def pin_rank_to_cores(local_rank, n_local):
     """One contiguous slice of the visible cores per rank (the host side of a step is ~500 Python-driven
     kernel launches: eight unpinned ranks migrating across sockets show up as rank skew).  Returns the
     (first, last, count) it pinned to, or None when the platform has no sched_setaffinity / one rank."""
-    if n_local <= 1 or not hasattr(os, 'sched_setaffinity') or os.environ.get('VQVAE_NO_AFFINITY'):
+    if n_local <= 1 or not hasattr(os, 'sched_setaffinity') or NO_AFFINITY[0]:
         return None
     try:
         cores = sorted(os.sched_getaffinity(0))
@@ -443,8 +446,8 @@ def run_c4(args, rank, n, local):
     if rank == 0:
         mode = backend.default_matmul_dtype() if not getattr(args, 'matmul', None) else args.matmul
         x3 = mode in ('float32x3', 'float32x2')
-        # 'float32x2': three fp16 products of the scaled two-piece split since round 5 (VQVAE_VQ_X2=0: mode 2's six bf16 products)
-        X3_PRODUCTS = 3 if (mode == 'float32x2' and os.environ.get('VQVAE_VQ_X2', '1') != '0') else 6
+        # 'float32x2': three fp16 products of the scaled two-piece split since round 5 ('float32x3': six bf16 products)
+        X3_PRODUCTS = 3 if mode == 'float32x2' else 6
         peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS
         flop = 2.0 * N * k * d                              # expansion form, re-check not counted
         byts = 4.0 * (N * d + k * d + N + N * d)            # z read, codebook once, idx write, e write
@@ -533,6 +536,7 @@ def main():
                          'codebook and commitment losses still back-propagate (VQVAE_ParallelUpdater(overlap_comm=True)); '
                          'the default with more than one rank')
     ap.add_argument('--no-overlap-comm', action='store_true', help='N > 1: the whole arena in one all-reduce on the main stream')
+    ap.add_argument('--no-affinity', action='store_true', help='N > 1: leave CPU affinity and NUMA policy alone')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the RCCL communicator even with one rank (bootstrap self-test)')
     args = ap.parse_args()
@@ -553,6 +557,7 @@ def main():
         cpus_at_start = set(os.sched_getaffinity(0))
     except AttributeError:
         cpus_at_start = None
+    NO_AFFINITY[0] = args.no_affinity
     affinity = pin_rank_to_cores(local, n)       # (replaced below by the GPU's NUMA node when sysfs names one)
     if args.scaling == 'strong':
         if 128 % n:
@@ -567,7 +572,7 @@ def main():
     backend.init(local)
     # N > 1: this rank's host memory and threads next to its GPU (the page-locked input buffers, the Python heap)
     numa = None
-    if n > 1 and not os.environ.get('VQVAE_NO_AFFINITY'):
+    if n > 1 and not args.no_affinity:
         import ctypes as C
         from vqvae_amd.comm import bind_to_numa_node, gpu_numa_node
         bus = C.create_string_buffer(32)

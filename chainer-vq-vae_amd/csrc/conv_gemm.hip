@@ -3250,11 +3250,6 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   if (EPI == EPI_LINEAR && g.out[1].y == nullptr) g.out[0].rows = g.M;
   const long nblk = (long)g.ntile_m * g.ntile_n * g.B;
   if (nblk <= 0) return 0;
-  static const bool trace = getenv("VQVAE_TRACE_GEMM") != nullptr;
-  if (trace && nblk <= 64) {
-    int ktot = 0; for (int i = 0; i < g.nseg; ++i) ktot += g.seg[i].cin;
-    fprintf(stderr, "[gemm] epi %d M %d Tout %d B %d nseg %d K %d blocks %ld tag %d tmul %d tdiv %d\n", EPI, g.M, g.Tout, g.B, g.nseg, ktot, nblk, tag, g.seg[0].tmul, g.seg[0].tdiv);
-  }
   VQ_REQUIRE(nblk < (1L << 31), "conv_gemm: grid too large");
   if (mode != 0)          // modes 1 - 3 address a batch item's activations with 32-bit buffer offsets
     for (int i = 0; i < g.nseg; ++i)
@@ -3339,11 +3334,9 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
                "conv_gemm: a bf16 residual / gradient stream needs matmul mode 1, whole 256-row tiles and a plain (acc + add) epilogue");
   // 256-column tiles when they still give every CU a workgroup (measured at configs[1]: dilated conv
   // forward and backward-data -6.5 %, the short 1x1 contractions unchanged)
-  static const int x3_nb = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
   const long nblk2 = (long)g.ntile_m * cdiv(g.Tout, 2 * BN) * g.B;
   // two taps of one tensor: interleave them channel group by channel group (TAP2).  The choice depends
   // on the contraction only, never on the tile shape, so that a result does not change with the batch size.
-  static const int x3_tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
   // A 1x1 conv over >= 64 channels into 256-row tiles (proj1 / proj2 and their backward-data, the latent-rate condition
   // projection): ONE segment, so it used to miss the two-tap loop and run 256 x 256 tiles, one workgroup per CU, 16 K steps
   // between a prologue and a 256 KB epilogue -- 16 GFLOP in 105 us, 0.18 of the three-product ceiling.  Its contraction is
@@ -3353,7 +3346,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // (proj1 / proj2 forward and backward-data 105 -> ~70 us each, the step 14.87 -> 14.73 ms: same box, two interleaved rounds)
   if constexpr (EPI == EPI_LINEAR) {
     Seg& s0 = g.seg[0];
-    if (x3_tap2 && big && (mode == 2 || mode == 3) && g.nseg == 1 && g.ksplit == 1 && s0.cin >= 64 && s0.cin % 32 == 0 &&
+    if (big && (mode == 2 || mode == 3) && g.nseg == 1 && g.ksplit == 1 && s0.cin >= 64 && s0.cin % 32 == 0 &&
         !(g.M == 256 && s0.cin == 128) &&      // (the residual 1x1's shape keeps the K order of lin128_stream_kernel, its bitwise twin)
         s0.tmul == 1 && s0.tdiv == 1 && !g.x16 && !g.z16 && !g.add16 && !g.y16) {
       Seg& s1 = g.seg[1];
@@ -3365,7 +3358,7 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
       g.nseg = 2;
     }
   }
-  const bool tap2 = x3_tap2 && mode != 0 && g.nseg == 2 && g.ksplit == 1 &&
+  const bool tap2 = mode != 0 && g.nseg == 2 && g.ksplit == 1 &&
                     g.seg[0].cin == g.seg[1].cin && g.seg[0].cin % BK == 0 &&
                     g.seg[0].x_cstride == g.seg[1].x_cstride && g.seg[0].x_bstride == g.seg[1].x_bstride &&
                     g.seg[0].Tin == g.seg[1].Tin && g.seg[0].tmul == g.seg[1].tmul && g.seg[0].tdiv == g.seg[1].tdiv &&
@@ -3376,11 +3369,10 @@ static int launch_gemm(GemmArgs& g, int tag, hipStream_t st) {
   // 217 -> 198 us at configs[1] against the 256 x 256 tiles, which stay for every other contraction.  Same K
   // order and products as the 256 x 256-tile two-tap kernel (VQVAE_X3_LEAN=0, the A/B alternate): the choice never changes a result.
   static const int x3_lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
-  const bool lean = x3_lean && X3_LEAN && tap2 && big && mode != 0 && EPI != EPI_GATE_BWD && x3_nb != 3;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
-  const bool wide = mode != 0 && big && !lean && ((x3_nb == 2 && nblk2 >= 256) || x3_nb == 3);   // 3: always (tools/occ_scaling.py)
+  const bool lean = x3_lean && X3_LEAN && tap2 && big && mode != 0 && EPI != EPI_GATE_BWD;   // mode 1: the 256 x 128 kernel needs 122 VGPRs as it is
+  const bool wide = mode != 0 && big && !lean && nblk2 >= 256;
   if constexpr (EPI == EPI_GATE) {       // the latent-rate condition as one more K step: the 256 x 128-tile two-tap loop, modes 2 / 3 (see the kernel)
-    static const int kstep = getenv("VQVAE_COND_KSTEP") ? atoi(getenv("VQVAE_COND_KSTEP")) : 1;
-    g.lerp.fold = (g.lerp.fold && kstep && g.lerp.P && lean && (mode == 2 || (mode == 3 && g.lerp.amax)) && g.Tout % BN == 0 &&
+    g.lerp.fold = (g.lerp.fold && g.lerp.P && lean && (mode == 2 || (mode == 3 && g.lerp.amax)) && g.Tout % BN == 0 &&
                    (long)g.Tout >= 26L * g.lerp.Tl) ? 1 : 0;
   }
   if (wide) g.ntile_n = cdiv(g.Tout, 2 * BN);
@@ -3542,9 +3534,8 @@ static WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   // 128-row tile units per residency round: 512 = one 256-row workgroup (two units) per CU.  The 256-row
   // six-product kernel would admit two per CU since round 3 (128 VGPRs), i.e. 1024 units: twice the splits
   // (and slab traffic) for half the K range each measured 22.02 against 21.97 ms per step, 768 units 22.24:
-  // the plan stays (VQVAE_W3_SLOTS overrides it for such A/B runs).
-  static const long slots_env = getenv("VQVAE_W3_SLOTS") ? atol(getenv("VQVAE_W3_SLOTS")) : 0;
-  const long slots = slots_env > 0 ? slots_env : ((M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512);
+  // the plan stays.
+  const long slots = (M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512;
   long want = 1;
   double best = -1.0;
   for (long w = 1; w <= maxs; ++w) {
@@ -3607,22 +3598,16 @@ static int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hi
                  "wgrad: float32x2 segment %d without its maxima", i);
   const int mode = g_matmul_dtype == 3 ? ((w.f16x2 && fast) ? 3 : 2) : g_matmul_dtype;
   ProfScope ps(tag, st);
-  static const int w3_nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
-  const long blocks2 = (long)(p.ntile_m / 2) * w.ntile_p * p.nsplit;
   if (g_matmul_dtype == 3 && (w.x16 || w.g16)) {        // pre-split operands (see presplit_pair): their `amax` words are scale words
     VQ_REQUIRE(fast && mode == 3 && w.M % 256 == 0, "wgrad: pre-split operands need a float32x2 launch on 256-row tiles");
     const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
     if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, true>), grid, dim3(512), 0, st, w);
     else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, false, true>), grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, false>), grid, dim3(512), 0, st, w);
-  } else if (fast && mode == 3 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
-    hipLaunchKernelGGL((wgrad3_kernel<4, 2, 2>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
   } else if (fast && mode == 3 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && mode == 3) {
     hipLaunchKernelGGL((wgrad3_kernel<2, 1, 2>), dim3(p.ntile_m * p.ntile_n * p.nsplit), dim3(256), 0, st, w);
-  } else if (fast && mode == 2 && w.M % 256 == 0 && w3_nc == 2 && blocks2 >= 224) {
-    hipLaunchKernelGGL((wgrad3_kernel<4, 2, 3>), dim3((unsigned)blocks2), dim3(512), 0, st, w);
   } else if (fast && mode == 2 && w.M % 256 == 0) {
     hipLaunchKernelGGL((wgrad3_kernel<4, 1, 3>), dim3((p.ntile_m / 2) * p.ntile_n * p.nsplit), dim3(512), 0, st, w);
   } else if (fast && mode == 2) {
@@ -3703,8 +3688,7 @@ static size_t conv_pack_floats(const vqvae_conv1d_desc* d) {
 // for even e, xo[t + (e - 1) / 2] for odd e.  (Until round 3 these layers ran the generic fp32-MFMA kernel.)
 static int phase_pitch(const vqvae_conv1d_desc* d) { return ((d->Tin + 1) / 2 + 3) & ~3; }
 static bool phase_split_ok(const vqvae_conv1d_desc* d) {
-  static const int on = getenv("VQVAE_WGRAD_PHASES") ? atoi(getenv("VQVAE_WGRAD_PHASES")) : 1;
-  return on && d->stride == 2 && d->dil == 1 && d->K <= MAXSEG && d->Tout % 4 == 0 && d->Tin >= 8;
+  return d->stride == 2 && d->dil == 1 && d->K <= MAXSEG && d->Tout % 4 == 0 && d->Tin >= 8;
 }
 static size_t phase_split_floats(const vqvae_conv1d_desc* d) {
   return phase_split_ok(d) ? (size_t)2 * d->B * d->Cin * phase_pitch(d) + 64 : 0;
@@ -3724,14 +3708,14 @@ __global__ void phase_split_kernel(const float* __restrict__ x, long rows, int T
 
 // matmul mode 3, generic conv entry points: the float32x2 kernels need the operands' absolute maxima before they run.
 // Nobody hands them to these entry points, so a launch large enough to pay for it (>= 8 GFLOP: proj1 / proj2 at the
-// configs; vqvae_set_f32x2_min_gflop / VQVAE_F16X2_MIN_GFLOP override, 0 = every launch, which is how the parity and
+// configs; vqvae_set_f32x2_min_gflop overrides, 0 = every launch, which is how the parity and
 // accuracy tests reach these kernels at their small shapes) runs
 // absmax_kernel over its activation operand first (one read of the tensor: ~25 us per 126 MB against ~60 us saved);
 // everything smaller keeps mode 2's kernels.  The maxima live in the last 64 bytes of the workspace.
-static double g_f32x2_min_gflop = -1.0;        // < 0: not set (VQVAE_F16X2_MIN_GFLOP, else 8)
+static double g_f32x2_min_gflop = -1.0;        // < 0: not set (vqvae_set_f32x2_min_gflop), 8 then
 static bool conv_f16x2(const vqvae_conv1d_desc* d) {
   if (g_matmul_dtype != 3) return false;
-  if (g_f32x2_min_gflop < 0.0) g_f32x2_min_gflop = getenv("VQVAE_F16X2_MIN_GFLOP") ? atof(getenv("VQVAE_F16X2_MIN_GFLOP")) : 8.0;
+  if (g_f32x2_min_gflop < 0.0) g_f32x2_min_gflop = 8.0;
   return 2.0 * d->B * d->Tout * (double)d->Cout * d->Cin * d->K >= g_f32x2_min_gflop * 1e9;
 }
 extern "C" int vqvae_set_f32x2_min_gflop(double gflop) {
@@ -4077,49 +4061,38 @@ static RbLayout rb_layout(const vqvae_resblock_desc* d) {
 // z (B, Cd/2, T) is read only through GEMM staging (res 1x1, skip sum, res / skip weight gradients).  In matmul
 // mode 1 that staging rounds it to bf16, so for the configs-sized blocks every producer and consumer agrees -- through
 // this one predicate -- to keep it in HBM as bf16 (same element strides, the caller's buffer is simply half used):
-// identical results, 31.5 MB less per launch that touches it at configs[4].  VQVAE_Z16=0 keeps it fp32.
+// identical results, 31.5 MB less per launch that touches it at configs[4].
 static bool z_bf16(const vqvae_resblock_desc* d) {
-  static const int on = getenv("VQVAE_Z16") ? atoi(getenv("VQVAE_Z16")) : 1;
-  return on && g_matmul_dtype == 1 && d->Cd / 2 == 128 && d->Cr == 256 && d->Cs % 256 == 0 && d->T % 64 == 0 &&
+  return g_matmul_dtype == 1 && d->Cd / 2 == 128 && d->Cr == 256 && d->Cs % 256 == 0 && d->T % 64 == 0 &&
          (long)d->B * (d->Cr > d->Cs ? d->Cr : d->Cs) * d->T * 4 < (1L << 31);     // the bf16-reading kernels address with 32-bit offsets
 }
 
 static bool gates_bf16(const vqvae_resblock_desc* d) {
-  static const int on = getenv("VQVAE_G16") ? atoi(getenv("VQVAE_G16")) : 1;
-  return on && z_bf16(d);
+  return z_bf16(d);
 }
 
 // gh = [ga; gb] (B, Cd, T) stored as bf16 (vqvae_resblock_desc::storage & VQVAE_STORE_GH_BF16): the same blocks, on
-// the caller's request.  VQVAE_H16=0 makes the library report it as unsupported.
+// the caller's request.
 static int bf16_storage_supported(const vqvae_resblock_desc* d) {
-  static const int h16 = getenv("VQVAE_H16") ? atoi(getenv("VQVAE_H16")) : 1;
   int m = 0;
-  if (h16 && gates_bf16(d) && d->K == 2 && d->Cd == 256) m |= VQVAE_STORE_GH_BF16;
-  static const int x16 = getenv("VQVAE_X16") ? atoi(getenv("VQVAE_X16")) : 1;
+  if (gates_bf16(d) && d->K == 2 && d->Cd == 256) m |= VQVAE_STORE_GH_BF16;
   static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
   // (the gate GEMM reads a bf16 x in its 256 x 128-tile two-tap form only: not offered when an A/B switch turns that form off)
   static const int lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
-  static const int tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
-  static const int nb3 = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
-  if (x16 && lin128 && lean && tap2 && nb3 != 3 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
-  static const int r16 = getenv("VQVAE_R16") ? atoi(getenv("VQVAE_R16")) : 1;
-  if (r16 && tap2 && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->Cs == d->Cr && d->T % 128 == 0) m |= VQVAE_STORE_GX_BF16 | VQVAE_STORE_GRES_BF16;
+  if (lin128 && lean && gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->T % 128 == 0) m |= VQVAE_STORE_X_BF16 | VQVAE_STORE_RES_BF16;
+  if (gates_bf16(d) && d->K == 2 && d->Cd == 256 && d->Cs == d->Cr && d->T % 128 == 0) m |= VQVAE_STORE_GX_BF16 | VQVAE_STORE_GRES_BF16;
   return m;
 }
 
 // matmul mode 3 (float32x2): the tensors of the packed chain that can be kept PRE-SPLIT (see presplit_pair) -- the
 // configs-sized blocks whose two-tap GEMMs run the 256 x 128-tile loop and whose residual 1x1 runs the streaming kernel.
-// VQVAE_PRESPLIT=0 makes the library report none.
-static int g_presplit = -1;          // < 0: not set (VQVAE_PRESPLIT, else 7); bit 0: gh, bit 1: the residual stream, bit 2: sigmoid + z instead of tanh + sigmoid + z
+// vqvae_set_presplit(0) makes the library report none.
+static int g_presplit = 7;           // (vqvae_set_presplit) bit 0: gh, bit 1: the residual stream, bit 2: sigmoid + z instead of tanh + sigmoid + z
 static int f16x2_storage_supported(const vqvae_resblock_desc* d) {
-  if (g_presplit < 0) g_presplit = getenv("VQVAE_PRESPLIT") ? atoi(getenv("VQVAE_PRESPLIT")) : 7;
   const int on = g_presplit;
   static const int lin128 = getenv("VQVAE_LIN128") ? atoi(getenv("VQVAE_LIN128")) : 32;
   static const int lean = getenv("VQVAE_X3_LEAN") ? atoi(getenv("VQVAE_X3_LEAN")) : X3_LEAN;
-  static const int tap2 = getenv("VQVAE_X3_TAP2") ? atoi(getenv("VQVAE_X3_TAP2")) : 1;
-  static const int nb3 = getenv("VQVAE_X3_NB") ? atoi(getenv("VQVAE_X3_NB")) : 2;
-  static const int w3nc = getenv("VQVAE_W3_NC") ? atoi(getenv("VQVAE_W3_NC")) : 1;
-  if (!on || g_matmul_dtype != 3 || g_wgrad_impl == 1 || !lean || !tap2 || nb3 == 3 || w3nc != 1) return 0;
+  if (!on || g_matmul_dtype != 3 || g_wgrad_impl == 1 || !lean) return 0;
   if (!(d->K == 2 && d->Cd == 256 && d->Cr == 256 && d->T % 128 == 0 && d->dil < d->T &&
         (long)d->B * d->Cd * d->T * 4 < (1L << 31))) return 0;
   int m = 0;

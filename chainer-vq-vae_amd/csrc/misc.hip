@@ -1095,8 +1095,7 @@ int vqvae_upsample_linear_bwd(const float* gy, long gy_bstride, int B, int C, in
                               long gx_bstride, vqvae_stream_t s) {
   VQ_REQUIRE(gy && w0 && w1 && lo0 && hi0 && lo1 && hi1 && gx, "upsample_bwd: null pointer");
   const size_t n = (size_t)B * C * Tin;
-  static const int seg_on = getenv("VQVAE_UPS_SEG") ? atoi(getenv("VQVAE_UPS_SEG")) : 1;
-  if (seg_on && Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 &&
+  if (Tin >= 3 && Tout >= 8 * Tin && Tout % 4 == 0 && Tout / 4 <= 2 * UPS_NT && gy_bstride % 4 == 0 &&
       ((uintptr_t)gy) % 16 == 0 && ((uintptr_t)w0) % 16 == 0 && ((uintptr_t)w1) % 16 == 0) {
     int nb = B * C;
     if (nb > 512) nb = 512;                      // persistent: 2 workgroups per CU
@@ -1370,12 +1369,11 @@ int vqvae_embed_onehot_wgrad(const float* x, const int32_t* idx, const int32_t* 
   int nb = (int)((rows + 3) / 4);
   if (nb > 2048) nb = 2048;
   const size_t lds2 = (size_t)BC_WAVES * BC_NCOPY * 2 * q * sizeof(float);
-  static const int use_sort = getenv("VQVAE_EMBED_SORT") ? atoi(getenv("VQVAE_EMBED_SORT")) : 1;
   int lpc = 1;
   while (lpc * 2 * q <= ES_NT && lpc < 64) lpc *= 2;       // lanes per class: 4 at q = 256
   const size_t lds_sort = (size_t)(ES_NW * q + ES_NT) * sizeof(int) + (size_t)T * 2;
   const size_t lds_gath = (size_t)2 * (T + 4) * sizeof(float) + (((size_t)T * 2 + 15) & ~(size_t)15) + (size_t)(q + 1) * sizeof(int);
-  if (use_sort && K == 2 && T % 4 == 0 && T <= 65535 && q <= ES_NT && (((uintptr_t)gy) % 16 == 0) &&
+  if (K == 2 && T % 4 == 0 && T <= 65535 && q <= ES_NT && (((uintptr_t)gy) % 16 == 0) &&
       lds_sort <= 64 * 1024 && lds_gath <= 150 * 1024) {
     unsigned short* perm = reinterpret_cast<unsigned short*>((char*)ws + embed_ws_sort_off(B, Cout, q, K));
     int32_t* off = reinterpret_cast<int32_t*>((char*)perm + align_up((size_t)B * T * sizeof(unsigned short), 256));

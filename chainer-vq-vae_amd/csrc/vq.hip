@@ -1004,9 +1004,8 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
     const int nw = vq_cols_per_block(dpad);
     VQ_REQUIRE(nw > 0, "vq_nearest_fwd: d=%d too large for the LDS-staged MFMA path (max ~1000)", d);
     VQ_CHECK_HIP(hipMemsetAsync(wmax_bits, 0, 256, st));
-    // mode 3: three fp16 products (VQVAE_VQ_X2=0: mode 2's six bf16 products, the A/B alternate)
-    static const int x2_on = getenv("VQVAE_VQ_X2") ? atoi(getenv("VQVAE_VQ_X2")) : 1;
-    const bool x2 = x2_on && (d == 64 || d == 128) && vqvae_get_matmul_dtype() == 3;
+    // mode 3: three fp16 products (mode 2: six bf16 products)
+    const bool x2 = (d == 64 || d == 128) && vqvae_get_matmul_dtype() == 3;
     if (x2) hipLaunchKernelGGL(vq_wnorm_elt_lds_kernel, dim3(cdiv(k, 64)), dim3(64), (size_t)64 * (d + 1) * 4, st, W, k, d, wn, wmax_bits);      // (x2: d is 64 or 128)
     else hipLaunchKernelGGL(vq_wnorm_kernel, dim3(cdiv(k, 256)), dim3(256), 0, st, W, k, d, wn, wmax_bits);
     VQ_LAUNCH_CHECK();
@@ -1019,9 +1018,7 @@ extern "C" int vqvae_vq_nearest_fwd(const float* z, const float* W, int B, int d
       const size_t lds = 2 * (x2 ? 2 : 3) * 64 * (size_t)(d / 8 + 1) * 16;
       const unsigned grid = (unsigned)((N + 255) / 256);
       // the candidate pass pays when re-checking a row against all k codes costs more than sweeping it again
-      static const int cand_on = getenv("VQVAE_VQ_CAND") ? atoi(getenv("VQVAE_VQ_CAND")) : 1;
-      static const long cand_minN = getenv("VQVAE_VQ_CAND_MINN") ? atol(getenv("VQVAE_VQ_CAND_MINN")) : 1024;      // (round 5: N = 1920 at k = 8192 1.49 -> 1.32 ms with it; 4096 until then)
-      cand_path = cand_on && k >= 1024 && N >= cand_minN;
+      cand_path = k >= 1024 && N >= 1024;      // (round 5: N = 1920 at k = 8192 1.49 -> 1.32 ms with it; from N = 4096 until then)
       // the candidate sweep covers at most N/8 flagged rows per launch geometry; rows beyond are re-checked in full
       const unsigned cgrid = (unsigned)((N / 8 + 255) / 256);
       if (cand_path) VQ_CHECK_HIP(hipMemsetAsync(ccount, 0, (size_t)N * 4, st));

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 _state = {'stream': None, 'side': None, 'device': None, 'pool': {}, 'live_bytes': 0,
-          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': os.environ.get('VQVAE_OVERLAP', '0') == '1'}
+          'pool_bytes': 0, 'ws': {}, 'events': [], 'overlap': False}
 
 
 def init(device=0):
@@ -83,7 +83,7 @@ def overlap_enabled():
     float32x3 kernels (one 8-wave workgroup per CU, the chip at its power limit) a second stream
     only interleaves work that cannot co-reside -- measured +0.58 ms per step at configs[1]; it
     was worth -1.6 ms with round 1's fp32 MFMA kernels and is neutral in that mode now.
-    set_overlap(True) or VQVAE_OVERLAP=1 turns it on."""
+    set_overlap(True) turns it on."""
     return _state['overlap']
 
 
@@ -224,7 +224,7 @@ def set_presplit(mask):
     """'float32x2' only: which tensors of ResidualNet's chain are kept PRE-SPLIT in HBM (fp16 hi | lo dwords written once
     by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; bit 2: the
     gate kernel saves sigmoid and z only (the backward takes tanh = z / sigmoid: VQVAE_STORE_GATES_SIG); default 7
-    ($VQVAE_PRESPLIT), 0 = every tensor fp32 and every reader splits for itself (round 4's form, the A/B alternate)."""
+    0 = every tensor fp32 and every reader splits for itself (round 4's form, the A/B alternate)."""
     _lib.call('vqvae_set_presplit', int(mask))
 
 
@@ -235,10 +235,10 @@ def set_presplit(mask):
 # pre-split tensor's bound with the maximum its producer published and counts the tensors beyond 2^CONTRACT_LOG2_LIMIT.
 # Nothing is read back unless somebody asks:
 #   f32x2_contract_violations()         -> {'violations', 'checked', 'worst_log2'} since the last reset (synchronises)
-#   set_contract_debug(True) / VQVAE_CONTRACT_DEBUG=1: the chain reads the report after every sweep and RAISES on a violation
+#   set_contract_debug(True): the chain reads the report after every sweep and RAISES on a violation
 # A violation means: switch to 'float32x3' (no scales) or withdraw the pre-split storage (set_presplit(4)).
 # --------------------------------------------------------------------------- #
-CONTRACT_LOG2_LIMIT = int(os.environ.get('VQVAE_CONTRACT_LOG2_LIMIT', '8'))
+CONTRACT_LOG2_LIMIT = 8
 
 
 def contract_report():
@@ -256,7 +256,7 @@ def contract_report():
 
 
 def contract_debug():
-    return bool(_state.get('contract_debug', os.environ.get('VQVAE_CONTRACT_DEBUG', '0') == '1'))
+    return bool(_state.get('contract_debug', False))
 
 
 def set_contract_debug(on):

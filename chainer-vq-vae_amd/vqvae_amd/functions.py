@@ -228,9 +228,9 @@ def reshape(a, shape):
     return Reshape(shape).apply((a,))[0]
 
 
-# A ReLU's backward gx = gy * (y > 0) runs in the epilogue of the conv that reads y and produces gy (VQVAE_FUSE_RELU_BWD=0:
+# A ReLU's backward gx = gy * (y > 0) runs in the epilogue of the conv that reads y and produces gy (FUSE_RELU_BWD=0:
 # in a pass of its own, as until round 4)
-FUSE_RELU_BWD = os.environ.get('VQVAE_FUSE_RELU_BWD', '1') != '0'
+FUSE_RELU_BWD = True
 
 
 def relu(a):

@@ -12,7 +12,7 @@ NEXT step's ``prefetch()`` (called by ``VAE.__call__`` before anything else) pac
 slab is handed out only while it provably matches what the launch would pack itself: same parameter buffer, same parameter
 version (optimizer step, load_npz), same matmul mode and float32x2 threshold -- anything else packs in line as before.
 Only ``Parameter`` weights are prefetched (a weight computed inside the step does not exist yet when the step starts).
-``VQVAE_PREPACK_CONVS=0`` turns it off (bitwise the same step: the same pack kernels write the same slabs)."""
+``prepack.ENABLED = False`` turns it off (bitwise the same step: the same pack kernels write the same slabs)."""
 import ctypes as C
 import os
 import weakref
@@ -22,7 +22,7 @@ import numpy as np
 from . import _lib, backend, core
 from .backend import DeviceArray
 
-ENABLED = os.environ.get('VQVAE_PREPACK_CONVS', '1') != '0'
+ENABLED = True
 _MAX_JOBS = 24            # MAXSEG of csrc/conv_gemm.hip: jobs of one pack launch
 _FIRST_JOBS = 6            # jobs of a prefetch's first launch
 

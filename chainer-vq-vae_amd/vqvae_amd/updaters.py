@@ -177,8 +177,8 @@ class StandardUpdater(object):
 # loss1 + loss3 hands the encoder g1 + g3 and walks it ONCE -- the same gradients (summation order aside: the two
 # contributions are added at z instead of in every encoder parameter), minus one encoder backward per step (6 backward-data
 # GEMMs, 6 weight gradients and their ~50 small launches: ~0.5 ms of 17 at configs[1]).  The codebook still receives the
-# codebook loss only.  VQVAE_SEQUENTIAL_BACKWARD=1 (or merged=False) runs the reference's three sweeps.
-MERGED_BACKWARD = os.environ.get('VQVAE_SEQUENTIAL_BACKWARD', '0') in ('0', '')
+# codebook loss only.  merged=False (or updaters.MERGED_BACKWARD = False) runs the reference's three sweeps.
+MERGED_BACKWARD = True
 
 
 def _merged_sweep(losses, merged=None):

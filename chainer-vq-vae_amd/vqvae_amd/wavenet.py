@@ -19,7 +19,7 @@ from .core import Chain, ChainList, FunctionNode, type_expect
 
 _S = backend.stream
 DIL_WGRAD_GROUP = 5      # blocks per batched dilated-conv weight-gradient launch
-PACK_ONCE = os.environ.get('VQVAE_PACK_ONCE', '1') != '0'     # weight slabs of the whole chain re-laid once per step
+PACK_ONCE = True         # weight slabs of the whole chain re-laid once per step (False: per call; test_pack_once_equals_pack_per_call)
 
 
 def _p(a):
@@ -147,15 +147,15 @@ def _pack_stack(params, d0, nb, stream):
     return packed, per
 
 
-FUSE_PULLBACK = os.environ.get('VQVAE_FUSE_PULLBACK', '1') != '0'
-DEFER_WGRAD = os.environ.get('VQVAE_DEFER_WGRAD', '1') != '0'
+FUSE_PULLBACK = True     # (tests A/B it through this attribute)
+DEFER_WGRAD = True
 PB_REDUCE_GROUP = 5       # blocks per vqvae_pullback_reduce_into launch
 DEFER_DIL_BLOCKS = 5      # how many of the blocks nearest the input keep their dilated-conv weight gradients for the side stream (a multiple of DIL_WGRAD_GROUP; 10 and 15 measured 0.05-0.1 ms slower: the tail they would run beside is full)
-BATCH_PULLBACK = os.environ.get('VQVAE_BATCH_PULLBACK', '1') != '0'
-PREPACK_ASYNC = os.environ.get('VQVAE_PREPACK_ASYNC', '1') != '0'
+BATCH_PULLBACK = True
+PREPACK_ASYNC = True
 # 'bfloat16' mode: the chain's tensors the caller may keep in HBM as bf16 (x_l, gh_l, g_res_l: vqvae_resblock_desc.storage) are
-# taken whenever the library offers them; VQVAE_BF16_STORAGE=0 leaves every one fp32 (operand rounding only: ADVICE r4)
-BF16_STORAGE = os.environ.get('VQVAE_BF16_STORAGE', '1') != '0'
+# taken whenever the library offers them; wavenet.BF16_STORAGE = False leaves every one fp32 (operand rounding only: ADVICE r4)
+BF16_STORAGE = True
 
 
 def _grad_out(var, shape):
@@ -404,7 +404,7 @@ class ResidualStackFunction(FunctionNode):
             tb = F.resize_tables(Tl, d0.T)
             gP = DeviceArray((Bl, nb * d0.Cd, Tl), np.float32)
         # 'float32x2': the pull-back of every gh_l to the latent rate runs inside the launch that produces gh_l
-        # (vqvae_resblock_amax.pb_part) and one reduce launch finishes all blocks; VQVAE_FUSE_PULLBACK=0: a launch per block
+        # (vqvae_resblock_amax.pb_part) and one reduce launch finishes all blocks; FUSE_PULLBACK = False: a launch per block
         pb_part = None
         # (measured in the bf16 mode too: the gate-derivative kernel of that mode loses more than the launch costs -- configs[4]
         # 18.8 -> 20.4 ms -- so it keeps its pull-back launches)
@@ -413,7 +413,7 @@ class ResidualStackFunction(FunctionNode):
             pb_part = DeviceArray((nb, d0.B, d0.T // 128, d0.Cd, 4), np.float32)
         # where the pull-back stays a kernel of its own (bf16 mode, float32x3, fp32 MFMA): ONE launch over all blocks' gh when
         # the chain is done (vqvae_upsample_linear_bwd_blocks) instead of a launch per block -- the gh_l then are the
-        # slices of one array.  VQVAE_BATCH_PULLBACK=0: a launch per block, as before (same sums in the same order)
+        # slices of one array.  BATCH_PULLBACK = False: a launch per block, as before (same sums in the same order)
         gh_all = None
         if (BATCH_PULLBACK and pb_part is None and lat is not None and self.packed is not None and not overlap
                 and not (store & _lib.STORE_GH_F16X2) and Tl >= 3 and d0.T >= 8 * Tl and d0.T % 4 == 0 and d0.T // 4 <= 2048
@@ -435,7 +435,7 @@ class ResidualStackFunction(FunctionNode):
         # gradients and every res conv's -- need nothing that comes later, and what comes later is the latent-rate tail of the
         # backward pass (pull-back reduce, condition embed, encoder, VQ: ~70 launches of 5-30 us on a handful of workgroups
         # each, 0.7 ms during which the chip is all but idle).  They go to the side stream and run BESIDE that tail;
-        # Variable.backward() joins the streams when the sweep is done (backend.join_side).  VQVAE_DEFER_WGRAD=0: in line.
+        # Variable.backward() joins the streams when the sweep is done (backend.join_side).  DEFER_WGRAD = False: in line.
         defer = DEFER_WGRAD and not overlap and lat is not None and self.packed is not None
         if defer:          # (sized for everything this sweep sends to the side stream before the first of it is enqueued)
             need = max(need, _lib.load().vqvae_conv1d_workspace_bytes(C.byref(self.pdesc)))

@@ -261,7 +261,7 @@ int vqvae_resblock_bf16_storage(const vqvae_resblock_desc* d);
 /* the pre-split bits the library supports for this block shape in the current matmul mode (0 outside mode 3)      */
 int vqvae_resblock_f16x2_storage(const vqvae_resblock_desc* d);
 /* which tensors vqvae_resblock_f16x2_storage may offer: bit 0 = gh, bit 1 = the residual stream, bit 2 = GATES_SIG
- * (default 7, or $VQVAE_PRESPLIT; 0 = every tensor of the chain stays fp32 -- the A/B switch of the pre-split tests) */
+ * (default 7; 0 = every tensor of the chain stays fp32 -- the A/B switch of the pre-split tests) */
 int vqvae_set_presplit(int mask);
 
 typedef struct {            /* parameters, Chainer layouts (modules.py:13-22)     */

@@ -681,3 +681,56 @@ def test_a_relu_output_rewrapped_as_a_leaf_receives_the_plain_conv_gradient(gpu)
     y2.grad = gpu.to_device(gy)
     y2.backward()
     assert_close_scaled(vx.grad.get()[..., 0], want * (x[..., 0] > 0), 1e-4, 'gradient through the fused ReLU backward')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['float32x2', 'float32x3', 'bfloat16'])
+def test_scheduling_switches_do_not_change_the_step(gpu, mode):
+    """The module-level A/B alternates that only change WHERE or IN HOW MANY launches something runs -- wavenet.DEFER_WGRAD
+    (decoder weight gradients beside the sweep's tail), functions.FUSE_RELU_BWD (a ReLU's backward in the producing conv's
+    epilogue), wavenet.BATCH_PULLBACK (one pull-back launch over all blocks; modes without the fused pull-back),
+    wavenet.DEFER_DIL_BLOCKS / PB_REDUCE_GROUP / DIL_WGRAD_GROUP (grouping of launches) -- give bit-identical losses,
+    parameters and Adam moments over two steps; wavenet.BF16_STORAGE (bf16 mode: chain tensors kept as bf16) changes the
+    rounding points only (losses to 2e-3)."""
+    import vqvae_amd as V
+    import vqvae_amd.functions as Fm
+    import vqvae_amd.wavenet as wn
+    from vqvae_amd.optimizers import Adam
+    cfg = dict(H.SMALL, residual=256, dilated=256, skip=256, n_layer=2)        # (256 channels: the packed chain, pre-split / bf16 storage)
+    batches = [O.synth_batch(2, length=1024, n_speaker=cfg['n_speaker'], seed=40 + s) for s in range(2)]
+    gpu.set_matmul_dtype(mode)
+    saved = {k: getattr(wn, k) for k in ('DEFER_WGRAD', 'BATCH_PULLBACK', 'DEFER_DIL_BLOCKS', 'PB_REDUCE_GROUP', 'DIL_WGRAD_GROUP', 'BF16_STORAGE')}
+    saved_relu = Fm.FUSE_RELU_BWD
+
+    def run(**kw):
+        for k, v in saved.items():
+            setattr(wn, k, kw.get(k, v))
+        Fm.FUSE_RELU_BWD = kw.get('FUSE_RELU_BWD', saved_relu)
+        _, model = H.build_model(cfg, seed=12)
+        model.to_gpu()
+        opt = Adam(2e-4)
+        opt.setup(model)
+        upd = V.VQVAE_StandardUpdater(_Iter(batches), opt, device=0)
+        losses = []
+        for _ in range(2):
+            upd.update()
+            losses.append([float(l.data.get()) for l in upd.last_losses])
+        return losses, opt.params.get(), opt.m.get(), opt.v.get()
+    try:
+        ref = run()
+        for kw in (dict(DEFER_WGRAD=False), dict(FUSE_RELU_BWD=False), dict(BATCH_PULLBACK=False), dict(DEFER_DIL_BLOCKS=0),
+                   dict(PB_REDUCE_GROUP=1), dict(DIL_WGRAD_GROUP=1)):
+            got = run(**kw)
+            assert got[0] == ref[0], (kw, got[0], ref[0])
+            for a, b in zip(ref[1:], got[1:]):
+                assert np.array_equal(a, b), kw
+        if mode == 'bfloat16':
+            got = run(BF16_STORAGE=False)
+            for la, lb in zip(ref[0], got[0]):
+                for a, b in zip(la, lb):
+                    assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (ref[0], got[0])
+    finally:
+        for k, v in saved.items():
+            setattr(wn, k, v)
+        Fm.FUSE_RELU_BWD = saved_relu
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
