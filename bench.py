@@ -282,7 +282,7 @@ def kernel_source_hash():
     """sha256 over the HIP sources whose kernels the roofline/traffic figures describe."""
     import hashlib
     h = hashlib.sha256()
-    for name in ('conv_gemm.hip', 'vq.hip', 'common.h'):
+    for name in ('gemm_common.h', 'conv_gemm_x3.hip', 'vq.hip', 'common.h'):
         with open(os.path.join(ROOT, 'chainer-vq-vae_amd', 'csrc', name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]

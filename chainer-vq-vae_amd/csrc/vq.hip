@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void vq_mfma_reg_kernel(
 
 // ---- the same sweep on the bf16 matrix pipe (matmul mode 2, d = 64 or 128) ------------------------
 // <w_j, z_n> as six v_mfma_f32_32x32x16_bf16 products of an exact three-way bf16 split of both
-// operands (csrc/conv_gemm.hip, "matmul mode 2"): 6 x 32 cycles per 16 c instead of 8 x 64.  The
+// operands (csrc/gemm_common.h, "matmul mode 2"): 6 x 32 cycles per 16 c instead of 8 x 64.  The
 // codebook is split once per call (vq_wsplit_kernel: [piece][code][d] bf16), the latent fragment of
 // a wavefront's 32 columns is split once and stays in registers for the whole sweep.
 // Rounding band: each kept product is exact, the three dropped ones are < 2^-25 |ab|; an MFMA adds 16
@@ -272,7 +272,7 @@ __device__ __forceinline__ void vq_split3(float x0, float x1, unsigned& h, unsig
   r0 -= __builtin_bit_cast(float, m << 16); r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
   l = vq_pk(r0, r1);
 }
-// ---- the sweep as THREE fp16 products (matmul mode 3, `float32x2`: csrc/conv_gemm.hip "matmul mode 3") ------------------
+// ---- the sweep as THREE fp16 products (matmul mode 3, `float32x2`: csrc/gemm_common.h "matmul mode 3") ------------------
 // x 2^k = hi + lo (fp16, RNE), <w, z> ~= (w_lo z_hi + w_hi z_lo + w_hi z_hi) 2^-(kw + kz): half the MFMAs of the six-product
 // sweep.  The codebook takes ONE power of two (from max_ij |W_ij|: vq_wnorm_elt_lds_kernel), every latent row its OWN (from its
 // d entries, which its lane pair holds anyway): 2^(14 - e) puts the largest entry in [2^14, 2^15).  Rounding band:

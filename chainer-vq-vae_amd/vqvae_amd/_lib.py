@@ -218,7 +218,7 @@ PROTOTYPES = {
 }
 
 # elementwise op codes / profiler tags (mirror the header)
-MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in conv_gemm.hip)
+MAX_STACK_GROUP = 24              # blocks per resstack call (MAXSEG in csrc/gemm_common.h)
 STORE_X_BF16, STORE_RES_BF16 = 2, 4
 STORE_GX_BF16, STORE_GRES_BF16 = 8, 16
 STORE_GH_BF16 = 1                 # vqvae_resblock_desc.storage bits (VQVAE_STORE_*)

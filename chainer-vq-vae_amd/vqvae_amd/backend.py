@@ -139,7 +139,7 @@ def _set_matmul_code(code):
 def set_matmul_dtype(name):
     """'float32' (fp32 MFMA), 'bfloat16' (operands rounded to bf16, fp32 accumulate),
     'float32x3' (fp32 products as six bf16 MFMA products of an exact three-way operand split:
-    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/conv_gemm.hip, "matmul mode 2") or
+    fp32 accuracy at 0.375 of the fp32 MFMA time -- csrc/gemm_common.h, "matmul mode 2") or
     'float32x2' (the default: three fp16 MFMA products of a two-piece split of operands scaled by a power of
     two per tensor -- "matmul mode 3": fp32 accuracy at 0.19 of the fp32 MFMA time; the tensors' absolute maxima
     travel with them through ResidualNet's chain, other large convs scan their operand once).
@@ -222,7 +222,7 @@ def join_side(force=True):
 
 def set_presplit(mask):
     """'float32x2' only: which tensors of ResidualNet's chain are kept PRE-SPLIT in HBM (fp16 hi | lo dwords written once
-    by their producer, csrc/conv_gemm.hip "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; bit 2: the
+    by their producer, csrc/gemm_common.h "PRE-SPLIT storage"): bit 0 = gh_l, bit 1 = the residual stream x_l; bit 2: the
     gate kernel saves sigmoid and z only (the backward takes tanh = z / sigmoid: VQVAE_STORE_GATES_SIG); default 7
     0 = every tensor fp32 and every reader splits for itself (round 4's form, the A/B alternate)."""
     _lib.call('vqvae_set_presplit', int(mask))

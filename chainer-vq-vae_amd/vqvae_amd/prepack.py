@@ -23,7 +23,7 @@ from . import _lib, backend, core
 from .backend import DeviceArray
 
 ENABLED = True
-_MAX_JOBS = 24            # MAXSEG of csrc/conv_gemm.hip: jobs of one pack launch
+_MAX_JOBS = 24            # MAXSEG of csrc/gemm_common.h: jobs of one pack launch
 _FIRST_JOBS = 6            # jobs of a prefetch's first launch
 
 _used = {}                # key -> (weight Variable, desc, backward): this step's convs in order of first use (the next plan)

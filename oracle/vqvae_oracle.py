@@ -350,13 +350,13 @@ def causal_conv_bwd(x, W, gh, dil, need_gx=True):
 
 def gates_saved_as_bf16(Ch, Cr, Cs, T):
     """The bf16 mode of the configs-sized blocks (BASELINE configs[4]) keeps the saved gate values tanh / sigmoid as
-    bf16 (csrc/conv_gemm.hip z_bf16 / GemmArgs::g16): same predicate, restated."""
+    bf16 (csrc/conv_api.hip z_bf16 / GemmArgs::g16): same predicate, restated."""
     return _BF16[0] and Ch == 128 and Cr == 256 and Cs % 256 == 0 and T % 64 == 0
 
 
 def gh_saved_as_bf16(Ch, Cr, Cs, T, K):
     """... and, on the default (latent-rate condition) path, the gate pre-activation gradient gh = [ga; gb] of every
-    block (vqvae_resblock_desc.storage & VQVAE_STORE_GH_BF16; csrc/conv_gemm.hip bf16_storage_supported): the
+    block (vqvae_resblock_desc.storage & VQVAE_STORE_GH_BF16; csrc/conv_api.hip bf16_storage_supported): the
     contractions that read it round it anyway, its bias sums and the condition gradient see the rounded values."""
     return gates_saved_as_bf16(Ch, Cr, Cs, T) and K == 2
 

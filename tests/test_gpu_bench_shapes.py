@@ -117,7 +117,7 @@ def test_resstack_b16_vs_oracle(gpu, matmul_mode):
 
 
 def test_presplit_storage_changes_only_the_rounding_point(gpu):
-    """'float32x2', PRE-SPLIT storage (csrc/conv_gemm.hip; vqvae_resblock_desc.storage & VQVAE_STORE_*_F16X2): gh_l and
+    """'float32x2', PRE-SPLIT storage (csrc/gemm_common.h; vqvae_resblock_desc.storage & VQVAE_STORE_*_F16X2): gh_l and
     the residual stream x_l are written by their producers as fp16 hi | lo dwords under an a-priori bound, and their
     readers stage them with two permutes per element pair instead of splitting them again.  Against the same chain with
     every tensor fp32 (backend.set_presplit(0), round 4's form) the only difference is WHERE the split is rounded: every

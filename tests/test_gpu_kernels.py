@@ -514,7 +514,7 @@ ACC_CASES = [(2, 32, 256, 32, 4, 2, 1, 1), (2, 96, 300, 80, 2, 1, 8, 8), (2, 40,
 @pytest.mark.parametrize('case', ACC_CASES)
 def test_float32x3_is_as_accurate_as_fp32_mfma(gpu, case):
     """'float32x3' computes every fp32 product as six bf16 MFMA products of an exact three-way split
-    of both operands (csrc/conv_gemm.hip, matmul mode 2), 'float32x2' as three fp16 MFMA products of a
+    of both operands (csrc/gemm_common.h, matmul mode 2), 'float32x2' as three fp16 MFMA products of a
     two-piece split of operands scaled by a power of two per tensor (mode 3).  Both are fp32 modes, not
     reduced-precision ones: against a float64 evaluation, forward, backward-data and backward-weight are
     (1) within 2e-6 of the result's scale and (2) no further away than the fp32 MFMA path ('float32') is,

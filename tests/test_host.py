@@ -417,11 +417,16 @@ def test_hot_kernels_keep_their_staging_in_registers(tmp_path):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
-    src = os.path.join(ROOT, 'chainer-vq-vae_amd', 'csrc', 'conv_gemm.hip')
-    out = str(tmp_path / 'conv_gemm.s')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-                           '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
-    text = open(out).read()
+    text = ''
+    procs = []
+    for fam in ('conv_gemm_x3', 'conv_gemm_fp32', 'wgrad'):          # the kernel families (csrc/gemm_common.h), compiled side by side
+        src = os.path.join(ROOT, 'chainer-vq-vae_amd', 'csrc', fam + '.hip')
+        out = str(tmp_path / (fam + '.s'))
+        procs.append((out, subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+                                             '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)))
+    for out, pr in procs:
+        assert pr.wait() == 0, out
+        text += open(out).read()
     meta = {}
     for m in re.finditer(r'\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+)'
                          r'.*?\.vgpr_count:\s*(\d+).*?\.vgpr_spill_count:\s*(\d+)', text, re.S):

@@ -1,6 +1,6 @@
 // Microbenchmark of the fp32 MFMA conv-GEMM main loop (the ResidualBlock's dilated conv at BASELINE
 // configs[1]: M = 256 output rows, K = 2 taps x 256 channels, N = B*T = 16 x 7680 columns), used to
-// choose the LDS image / fragment-read scheme of csrc/conv_gemm.hip.  Every variant computes the
+// choose the LDS image / fragment-read scheme of csrc/conv_gemm_x3.hip.  Every variant computes the
 // same Y[b][m][t] = sum_{tap,ci} W[m][ci][tap] * X[b][ci][t - (1-tap)*dil] with a trivial epilogue
 // and is checked on sampled outputs.
 //   V0  the round-1 loop: As[k][m], Bs[k][n], one ds_read_b32 per operand value (ds_read2_b32)

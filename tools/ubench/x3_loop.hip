@@ -7,7 +7,7 @@
 // The three dropped products (m*l, l*m, l*l) are below 2^-25 of |a*b| -- under the rounding of one
 // fp32 multiply -- and each kept product of two bf16 is exact in fp32.  v_mfma_f32_32x32x16_bf16 runs
 // at 16x the rate of v_mfma_f32_32x32x2_f32, so six of them per 16 k cost 6/16 of the fp32 MFMA time.
-//   X1  256 x 128 tile, 8 waves as 4 x 2 (64 x 64 each: the accumulator layout of csrc/conv_gemm.hip),
+//   X1  256 x 128 tile, 8 waves as 4 x 2 (64 x 64 each: the accumulator layout of csrc/conv_gemm_x3.hip),
 //       weights pre-split and packed in fragment order, activations split while they are staged
 //   X2  X1 with the fetches two K steps ahead (two register sets): the product kernel's loop
 //       (modes: ablations -- no A / B loads, no split, no barrier, no fragment reads; 128: the
