@@ -433,9 +433,34 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  // |w_j|^2 of a tile's codes, as this lane's accumulator rows want them: (half h, row group q) = the four consecutive codes
+  // 64 jt + 32 h + 8 q + 4 lk .. + 3.  Requested at the TOP of a tile, in front of its MFMAs: round 5 read wn[j] where it was used,
+  // behind a branch per distance (`j < k`) -- 32 branches and 32 dependent L1 round trips per tile and wave beside 48 MFMAs, the
+  // matrix pipe 29 % busy at configs[3].  Codes beyond k (the last tile of a k that is no multiple of 64) get +inf: their
+  // accumulator rows are zero (load_tile), their distance +inf, and they never win.  wn4: k % 4 == 0 and wn 16-byte aligned.
+  const bool wn4 = (k & 3) == 0 && (reinterpret_cast<uintptr_t>(wn) & 15) == 0;
   for (int jt = 0; jt < ntile; ++jt) {
     const int cur = jt & 1;
     if (jt + 1 < ntile) load_tile(jt + 1);
+    float wv[2][16];
+    if (wn4 && jt * TILE + TILE <= k) {                       // (wave-uniform)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wn + jt * TILE + h * 32 + 8 * q + 4 * lk);
+          wv[h][4 * q] = w4.x; wv[h][4 * q + 1] = w4.y; wv[h][4 * q + 2] = w4.z; wv[h][4 * q + 3] = w4.w;
+        }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const float w = wn[min(j, k - 1)];                  // unconditional (a load behind a branch would wait for it where it stands)
+          wv[h][r] = j < k ? w : INFINITY;
+        }
+    }
     const uint4* base = wt + (size_t)cur * NP * TILE * ROW;
     f32x16 a0, a1;
 #pragma unroll
@@ -486,8 +511,8 @@ __global__ __launch_bounds__(512, 2) void vq_mfma_x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = jt * TILE + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (j < k) {
-          const float v = fmaf(cn, h ? a1[r] : a0[r], wn[j]);
+        {
+          const float v = fmaf(cn, h ? a1[r] : a0[r], wv[h][r]);
           if constexpr (CAND) {
             if (v <= thr) {                                    // (never for lanes without a row: thr = -inf)
               const int c = atomicAdd(&ccount[slot], 1);
