@@ -1381,7 +1381,8 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
     }
   }
   if (g_matmul_dtype == 3 && x_amax && gh_amax) wa.f16x2 = 1;
-  WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, n);
+  const bool both_presplit = wa.f16x2 && (d->storage & VQVAE_STORE_GH_F16X2) && (d->storage & VQVAE_STORE_X_F16X2);
+  WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, n, both_presplit && wgrad_dma_shape(d->Cd, T, cins, n));
   if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_dil_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;
   wa.nseg = n;
@@ -1399,8 +1400,11 @@ extern "C" size_t vqvae_resstack_dil_wgrad_workspace_bytes(const vqvae_resblock_
   for (int i = 0; i < nblocks * d->K; ++i) cins[i] = d->Cr;
   size_t need = 0;             // any group of 1..nblocks blocks may be flushed; fewer tiles can mean more splits
   for (int n = 1; n <= nblocks; ++n) {
-    WgradPlan p = plan_wgrad(d->Cd, d->B, d->T, cins, n * d->K);
-    if (p.slab_floats + p.bslab_floats > need) need = p.slab_floats + p.bslab_floats;
+    for (int wide = 0; wide < 2; ++wide) {     // the launch takes the wide plan when both operands are stored pre-split (wgrad3_dma_kernel)
+      if (wide && !wgrad_dma_shape(d->Cd, d->T, cins, n * d->K)) continue;
+      WgradPlan p = plan_wgrad(d->Cd, d->B, d->T, cins, n * d->K, wide != 0);
+      if (p.slab_floats + p.bslab_floats > need) need = p.slab_floats + p.bslab_floats;
+    }
   }
   return need * sizeof(float) + 256;
 }

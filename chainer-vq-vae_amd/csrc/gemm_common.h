@@ -1058,7 +1058,8 @@ static bool seg_vec_ok(const Seg& s) {
          (((uintptr_t)s.x) % 16 == 0);
 }
 
-struct WgradPlan { int ntile_m, ntile_n, steps_per_b, steps_per_split, nsplit, nseg; size_t slab_floats, bslab_floats; };
+struct WgradPlan { int ntile_m, ntile_n, steps_per_b, steps_per_split, nsplit, nseg; size_t slab_floats, bslab_floats; int wide; };
+// wide: the splits are chosen for wgrad3_dma_kernel (one 256 x 256-tile workgroup per CU) -- see wgrad_dma_shape
 
 // ---- what the translation units call in one another -------------------------------------------------------------------
 // conv_gemm_x3.hip
@@ -1069,7 +1070,8 @@ size_t ksplit_partial_floats(int M, int Tout, int B, int nk);
 // the dispatch's own events
 template <int EPI> int launch_gemm_fp32(const GemmArgs& g, int wm, unsigned grid, int tag, hipStream_t st);
 // wgrad.hip
-WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg);
+WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg, bool wide = false);
+bool wgrad_dma_shape(int M, int Tout, const int* cins, int nseg);     // float32x2 with both operands pre-split: does this shape run on wgrad3_dma_kernel?
 int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream_t st);
 
 }  // namespace vq

@@ -5,6 +5,18 @@
 
 namespace vq {
 
+// Dev aid (-DVQ_PHASE_TIMING, tools/experiments/wphases.py; never in the product build): where a step of the pre-split
+// weight-gradient loops goes -- thread 0 of every workgroup adds its s_memtime differences to g_wphase[kernel][phase].
+#ifdef VQ_PHASE_TIMING
+__device__ unsigned long long g_wphase[2][8];
+__device__ unsigned long long g_wwave[16][4];
+#define W3_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define W3_ACC(S, A, B) S += (B) - (A)
+#else
+#define W3_T(v)
+#define W3_ACC(S, A, B)
+#endif
+
 template <bool BF16>
 __global__ __launch_bounds__(NT, WGRAD_WAVES_PER_EU) void wgrad_kernel(const WgradArgs a) {
   __shared__ float As[BM][WP];
@@ -754,18 +766,33 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       W3L_FETCH();
       W3L_STAGE(0, true);
       __syncthreads();
+#ifdef VQ_PHASE_TIMING
+      unsigned long long sf = 0, sm = 0, ss = 0, sb = 0;
+#endif
       for (int i = 0; i + 1 < nsteps; i += 2) {
+        W3_T(q0);
         adv();
         W3L_FETCH();                                        // step i + 1
+        W3_T(q1);
         mma(I0{});
+        W3_T(q2);
         W3L_STAGE(1, true);
+        W3_T(q3);
         __syncthreads();
+        W3_T(q4);
+        W3_ACC(sf, q0, q1); W3_ACC(sm, q1, q2); W3_ACC(ss, q2, q3); W3_ACC(sb, q3, q4);
         if (i + 2 < nsteps) adv();
         W3L_FETCH();                                        // step i + 2 (past the end: re-reads the last step, unused)
         mma(I1{});
         W3L_STAGE(0, i + 2 < nsteps);
         __syncthreads();
       }
+#ifdef VQ_PHASE_TIMING
+      if constexpr (XPRE && GPRE) if (tid == 0) {
+        atomicAdd(&g_wphase[0][0], sf); atomicAdd(&g_wphase[0][1], sm); atomicAdd(&g_wphase[0][2], ss); atomicAdd(&g_wphase[0][3], sb);
+        atomicAdd(&g_wphase[0][4], (unsigned long long)(nsteps / 2));
+      }
+#endif
       if (nsteps & 1) mma(I0{});
 #undef W3L_FETCH
 #undef W3L_STAGE
@@ -826,6 +853,235 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
       if constexpr (GPRE) v = __builtin_ldexpf(v, -ka);       // the sums ran over hi + lo = gy * 2^ka
       const int row = m0 + s_row + RSTEP * i;              // global row
       if (s_chunk == 0 && row < a.ntile_m * BM)
+        a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
+    }
+  }
+}
+
+// wgrad3_dma_kernel -- wgrad3_kernel<4, 1, 2, true, true> (float32x2, BOTH operands pre-split: the dilated convs of ResidualNet,
+// gh_l against x_l at two tap shifts) with the operands travelling global -> LDS by LDS-DMA.  Both operands are contiguous
+// along the contraction axis (time) in HBM and a lane's MFMA fragment is 8 consecutive t of its row, so -- unlike the conv
+// kernels' activations -- the stored dwords need no transposition: a stage is the RAW image [row][32 t] of hi | lo dwords,
+// filled by `buffer_load_dwordx4 ... lds` (8 rows x one whole 128-byte line each per wave instruction; LDS[m0 + 16 lane]:
+// the image is lane-linear, so the bank swizzle -- 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7): the 16 lanes one
+// ds_read_b128 cycle serves land on 16 distinct slots of the 256-byte bank row -- is applied to the SOURCE offsets), and the
+// pieces are separated AFTER the fragment read (two ds_read_b128 + eight v_perm_b32 per 32-row fragment pair).  No staging
+// registers, no ds_write pass, no wait for the loads inside the step.
+//   * ONE 16-wave workgroup per CU on a 256 x 256 tile (wave tile 64 x 64, 4 x 4 waves): a 32-t step brings 512 rows x 128 B
+//     = 64 KB for 24 MFMAs per wave where two 256 x 128 workgroups brought 96 KB, in whole cache lines instead of halves;
+//   * two stages (128 KB of LDS): [own DMAs of step i retired: vmcnt(0)] -> raw s_barrier -> first 16-t sub-step (12 MFMAs) ->
+//     issue step i + 1 into the stage step i - 1 was read from -> second sub-step: one barrier per 24 MFMAs.  The DMAs go out
+//     BEHIND the first sub-step's MFMAs: the CU's 64 DMA instructions of a step pass through the address path one after the
+//     other (~50 cycles each: s_memtime stamps per wave showed the last waves of a workgroup issuing theirs 1 700 ticks after
+//     the barrier, their MFMAs starting only then, and the first waves waiting that long at the next barrier);
+//   * a step whose shifted window lies wholly in front of the row (tap 1, the first dil / 32 steps of a row) zero-fills its
+//     B rows with a ds_write_b128; one that crosses the row's first or last sample (dil < 32 only) takes four predicated
+//     dword loads per lane into the same slot (the compiler's own wait for them covers the step's DMAs as well);
+//   * bias sums from the A fragments of the waves at wn == 0 (every row of the tile exactly once per sub-step).
+// Same splits, slabs, scales (2^ka, 2^kb per tile; 2^ku back) and product order as wgrad3_kernel; the host requires
+// Tout % 32 == 0, M % 256 == 0 and whole 256-column segments.
+#ifndef W3_DMA
+#define W3_DMA 1
+#endif
+constexpr int W3D_STAGE = 512 * 8;                         // uint4 per stage: [512 rows][8 chunks of 4 t]
+__global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) {
+  __shared__ uint4 ring[2 * W3D_STAGE];
+  if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
+  constexpr int BM2 = 256, W3DK = 32;
+  const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;
+  int logical;                                             // XCD-aware order, as in wgrad3_kernel
+  {
+    const int nblk = gridDim.x, id = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int ntiles = ntm * a.ntile_p;
+  const int tile = logical % ntiles;
+  const int split = logical / ntiles;
+  const int ct = tile % a.ntile_p;
+  const int mt = tile / a.ntile_p;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i)
+    if (i < a.nseg && ct >= a.seg[i].ptile0) s = i;
+  const WSeg& sg = a.seg[s];
+  const int eg = amax_expo(amax_load(sg.gy ? sg.amax_gy : a.amax_gy));
+  const int ex = amax_expo(sg.amax_x ? amax_load(sg.amax_x) : __builtin_bit_cast(unsigned, sg.amax_x_static));
+  const int ka = 14 - eg, ku = eg + ex - 28;
+  const int ntg = sg.tile0 + 2 * (ct - sg.ptile0);         // first 128-column slab tile of this workgroup
+  const int n0 = (ntg - sg.tile0) * BN;
+  const int m0 = mt * BM2;
+  const int spb = a.steps_per_b;                           // WBK = 32 positions per plan step = one step here
+  const int g0 = split * a.steps_per_split;
+  const int g1 = min(a.B * spb, g0 + a.steps_per_split);
+  const int nsteps = g1 - g0;
+  int b = g0 / spb;
+  int tb = (g0 - b * spb) * W3DK;
+  const int Tout = a.Tout;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+
+  // DMA roles: lane j fills slot j of a 1 KB run = row (j >> 3) of an 8-row group, physical chunk j & 7.  Wave w brings groups
+  // w and w + 16 of A and of B (rows [8 w, 8 w + 8) and 128 further): two groups of one parity swizzle alike -- (row >> 1) & 7
+  // = 4 (w & 1) + ((j >> 4) & 3) in both -- so one per-lane offset serves both runs, the second 128 rows up in the scalar offset.
+  // (the host guarantees whole tiles: M % 256 == 0, cin % 256 == 0 -- every row of the tile exists)
+  constexpr unsigned OOB = 0x80000000u;
+  const i32x4_t ra4 = make_rsrc4(sg.gy ? sg.gy : a.gy), rb4 = make_rsrc4(sg.x);
+  const rsrc_t rbx = make_rsrc(sg.x);
+  const int chunk0 = (lane & 7) ^ (4 * (wave & 1) + ((lane >> 4) & 3));
+  const unsigned voa0 = 4u * (unsigned)((m0 + 8 * wave + (lane >> 3)) * Tout + 4 * chunk0);
+  const unsigned vob0 = 4u * (unsigned)((n0 + 8 * wave + (lane >> 3)) * sg.x_cstride + 4 * chunk0);
+  const unsigned run_a = 512u * (unsigned)Tout, run_b = 512u * (unsigned)sg.x_cstride;     // 128 rows further
+  const unsigned lds0 = lds_addr32(&ring[0]);
+  // LDS image: [8-row group][stage][8 rows][8 chunks] -- a run of a stage is 1 KB, the other stage's run follows it, so a
+  // fragment address reaches both stages, both row blocks and both chunks of a pair through the ds_read's immediate offset
+  const unsigned dst_a = lds0 + 2048u * (unsigned)wave, dst_b = lds0 + 65536u + 2048u * (unsigned)wave;
+  const int wslot_b = 4096 + 128 * wave + lane;            // run 0's slot of this lane as a uint4 index, stage 0 (edge steps; run 1: + 2048, stage 1: + 64)
+  unsigned base_a = 4u * (unsigned)((long)b * a.gy_bstride), base_b = 4u * (unsigned)((long)b * sg.x_bstride);
+  const unsigned adv_a = 4u * (unsigned)a.gy_bstride, adv_b = 4u * (unsigned)sg.x_bstride;
+  const int s_toff = sg.toff, s_tin = sg.Tin;
+  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0)) && wn == 0;
+
+  auto issue = [&](const int st) {                         // the step at the cursor -> stage st; the cursor moves on
+    const unsigned sbytes = (unsigned)st * 1024u;
+    const unsigned soa = base_a + 4u * (unsigned)tb;
+    lds_dma16(dst_a + sbytes, voa0, ra4, soa);
+    lds_dma16(dst_a + sbytes + 32768u, voa0, ra4, soa + run_a);
+    const int w0 = tb + s_toff;                            // the shifted window [w0, w0 + 32)
+    if (w0 >= 0 && w0 + W3DK <= s_tin) {                   // wave-uniform
+      const unsigned sob = base_b + 4u * (unsigned)w0;
+      lds_dma16(dst_b + sbytes, vob0, rb4, sob);
+      lds_dma16(dst_b + sbytes + 32768u, vob0, rb4, sob + run_b);
+    } else if (w0 + W3DK <= 0 || w0 >= s_tin) {            // wholly outside the row: zeros
+      ring[st * 64 + wslot_b] = make_uint4(0u, 0u, 0u, 0u);
+      ring[st * 64 + wslot_b + 2048] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int tin = w0 + 4 * chunk0;
+        const unsigned vrow = 4u * (unsigned)((n0 + 128 * q + 8 * wave + (lane >> 3)) * sg.x_cstride);
+        unsigned v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int t = tin + e;
+          v[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rbx, (t >= 0 && t < s_tin) ? vrow + 4u * (unsigned)t : OOB, base_b, 0);
+        }
+        ring[st * 64 + wslot_b + 2048 * q] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    tb += W3DK;
+    if (tb >= spb * W3DK) { tb = 0; ++b; base_a += adv_a; base_b += adv_b; }
+  };
+  // fragment slots (uint4 index): row R = 32-row base + li sits in group R >> 3 at row R & 7; sub-step h wants logical chunks
+  // 4 h + 2 lk | + 1, found at physical c ^ ((R >> 1) & 7): four addresses per operand (the XORs of the low three bits),
+  // everything else -- stage + 64, row block + 512 -- an immediate
+  const int fsw = (2 * lk) ^ ((li >> 1) & 7);
+  const int fa = (wm * 8 + (li >> 3)) * 128 + (li & 7) * 8 + fsw, fb = 4096 + (wn * 8 + (li >> 3)) * 128 + (li & 7) * 8 + fsw;
+  const unsigned ba0 = 16u * (unsigned)fa, ba1 = 16u * (unsigned)(fa ^ 1), bb0 = 16u * (unsigned)fb, bb1 = 16u * (unsigned)(fb ^ 1);   // as byte offsets
+  auto frag = [&](const uint4 u0, const uint4 u1, uint4 (&p)[2]) {     // eight stored elements -> the hi and the lo fragment word
+    presplit_stage(__builtin_bit_cast(float, u0.x), __builtin_bit_cast(float, u0.y), p[0].x, p[1].x);
+    presplit_stage(__builtin_bit_cast(float, u0.z), __builtin_bit_cast(float, u0.w), p[0].y, p[1].y);
+    presplit_stage(__builtin_bit_cast(float, u1.x), __builtin_bit_cast(float, u1.y), p[0].z, p[1].z);
+    presplit_stage(__builtin_bit_cast(float, u1.z), __builtin_bit_cast(float, u1.w), p[0].w, p[1].w);
+  };
+  auto esum = [&](const uint4 u) {
+    return (presplit_scaled(__builtin_bit_cast(float, u.x)) + presplit_scaled(__builtin_bit_cast(float, u.y))) +
+           (presplit_scaled(__builtin_bit_cast(float, u.z)) + presplit_scaled(__builtin_bit_cast(float, u.w)));
+  };
+  auto ld16 = [&](const unsigned off) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ring) + off); };
+  auto mma = [&](const int st, const int h) {
+    const unsigned so = 1024u * (unsigned)st;
+    {
+      unsigned xa0 = ba0, xa1 = ba1, xb0 = bb0, xb1 = bb1;
+      if (h) {                                             // the second sub-step's four addresses are made here, not kept (registers)
+        asm volatile("v_xor_b32 %0, 64, %0\n\tv_xor_b32 %1, 64, %1\n\tv_xor_b32 %2, 64, %2\n\tv_xor_b32 %3, 64, %3" : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1));
+      }
+      uint4 bq[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) frag(ld16(xb0 + so + j * 8192u), ld16(xb1 + so + j * 8192u), bq[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 u0 = ld16(xa0 + so + i * 8192u), u1 = ld16(xa1 + so + i * 8192u);
+        uint4 ap[2];
+        frag(u0, u1, ap);
+        if (do_bias) bsum[i] += esum(u0) + esum(u1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<2>(ap, bq[j], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // the next sub-step's eight reads stay behind this one's MFMAs (registers)
+    }
+  };
+#ifdef VQ_PHASE_TIMING
+  unsigned long long sw = 0, sb = 0, si = 0, sm = 0;
+#endif
+#define W3D_STEP(ST, I)                                                                        \
+  {                                                                                            \
+    W3_T(q0);                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                               \
+    W3_T(q1);                                                                                  \
+    asm volatile("s_barrier" ::: "memory");                                                    \
+    W3_T(q2);                                                                                  \
+    mma(ST, 0);                                                                                \
+    W3_T(q3);                                                                                  \
+    if ((I) + 1 < nsteps) issue((ST) ^ 1);                                                     \
+    W3_T(q3b);                                                                                 \
+    mma(ST, 1);                                                                                \
+    W3_T(q4);                                                                                  \
+    W3_ACC(sm, q3b, q4);                                                                       \
+    W3_ACC(sw, q0, q1); W3_ACC(sb, q1, q2); W3_ACC(sm, q2, q3); W3_ACC(si, q3, q3b);           \
+  }
+  if (nsteps > 0) {
+    issue(0);
+    int i = 0;
+    for (; i + 2 <= nsteps; i += 2) {
+      W3D_STEP(0, i);
+      W3D_STEP(1, i + 1);
+    }
+    if (i < nsteps) W3D_STEP(0, i);
+  }
+#undef W3D_STEP
+#ifdef VQ_PHASE_TIMING
+  if (tid == 0) {
+    atomicAdd(&g_wphase[1][0], sw); atomicAdd(&g_wphase[1][1], sb); atomicAdd(&g_wphase[1][2], si); atomicAdd(&g_wphase[1][3], sm);
+    atomicAdd(&g_wphase[1][4], (unsigned long long)nsteps);
+  }
+  if (lane == 0) { atomicAdd(&g_wwave[wave][0], sw); atomicAdd(&g_wwave[wave][1], sb); atomicAdd(&g_wwave[wave][2], si); atomicAdd(&g_wwave[wave][3], sm); }
+#endif
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int rowb = wm * 64 + mi * 32;                    // wave-uniform
+    const int mt_slab = (m0 + rowb) / BM;
+    if (mt_slab >= a.ntile_m) continue;
+    float* slab = a.slabs + (((long)split * a.ntile_m + mt_slab) * a.ntile_n + ntg + (wn >> 1)) * (BM * BN);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = (wn & 1) * 64 + ni * 32 + li;
+        slab[row * BN + col] = __builtin_ldexpf(acc[mi][ni][r], ku);
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 32);
+      v = __builtin_ldexpf(v, -ka);                        // the sums ran over hi + lo = gy * 2^ka
+      const int row = m0 + wm * 64 + i * 32 + li;
+      if (lk == 0 && row < a.ntile_m * BM)
         a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
     }
   }
@@ -907,9 +1163,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
 #ifndef W3_SLOTS_256
 #define W3_SLOTS_256 512
 #endif
-WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
+bool wgrad_dma_shape(int M, int Tout, const int* cins, int nseg) {
+  bool ok = W3_DMA != 0 && g_matmul_dtype == 3 && M % 256 == 0 && Tout % WBK == 0;
+  for (int i = 0; i < nseg; ++i) ok = ok && cins[i] % (2 * BN) == 0;
+  return ok;
+}
+WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg, bool wide) {
   WgradPlan p;
   p.nseg = nseg;
+  p.wide = wide ? 1 : 0;
   p.ntile_m = cdiv(M, BM);
   p.ntile_n = 0;
   for (int i = 0; i < nseg; ++i) p.ntile_n += cdiv(cins[i], BN);
@@ -923,7 +1185,9 @@ WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
   // six-product kernel would admit two per CU since round 3 (128 VGPRs), i.e. 1024 units: twice the splits
   // (and slab traffic) for half the K range each measured 22.02 against 21.97 ms per step, 768 units 22.24:
   // the plan stays.
-  const long slots = (M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512;
+  // wide (wgrad3_dma_kernel): a workgroup covers four units and owns its CU: 1024 units per round, and the first split count
+  // that fills 92 % of ONE round is taken (a second round would pay the 256 KB slab store of every workgroup again)
+  const long slots = wide ? 1024 : (M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512;
   long want = 1;
   double best = -1.0;
   for (long w = 1; w <= maxs; ++w) {
@@ -933,7 +1197,7 @@ WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg) {
     const long rounds = (blocks + slots - 1) / slots;
     const double eff = (double)blocks / (double)(rounds * slots);
     if (eff > best + 1e-9) { best = eff; want = w; }
-    if (eff >= 0.92 && blocks >= slots) { want = w; break; }
+    if (eff >= 0.92 && (blocks >= slots || wide)) { want = w; break; }
   }
   p.steps_per_split = (int)((total_steps + want - 1) / want);
   p.nsplit = (int)((total_steps + p.steps_per_split - 1) / p.steps_per_split);
@@ -989,7 +1253,11 @@ int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream
   if (g_matmul_dtype == 3 && (w.x16 || w.g16)) {        // pre-split operands (see presplit_pair): their `amax` words are scale words
     VQ_REQUIRE(fast && mode == 3 && w.M % 256 == 0, "wgrad: pre-split operands need a float32x2 launch on 256-row tiles");
     const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
-    if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, true>), grid, dim3(512), 0, st, w);
+    int cins_[MAXSEG];
+    for (int i = 0; i < w.nseg; ++i) cins_[i] = w.seg[i].cin;
+    const bool dma = w.x16 && w.g16 && wgrad_dma_shape(w.M, w.Tout, cins_, w.nseg);     // (with any plan; the caller asks for a wide one when it knows)
+    if (dma) hipLaunchKernelGGL(wgrad3_dma_kernel, dim3((p.ntile_m / 2) * w.ntile_p * p.nsplit), dim3(1024), 0, st, w);
+    else if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, true>), grid, dim3(512), 0, st, w);
     else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, false, true>), grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, false>), grid, dim3(512), 0, st, w);
   } else if (fast && mode == 3 && w.M % 256 == 0) {
@@ -1028,3 +1296,12 @@ int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream
 }
 
 }  // namespace vq
+
+#ifdef VQ_PHASE_TIMING
+extern "C" int vqvae_debug_wphases(unsigned long long* out, int reset) {       // dev aid, see g_wphase
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vq::g_wphase), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(vq::g_wwave), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vq::g_wphase), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
