@@ -930,7 +930,7 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum = 0.f;
 
   // DMA roles: lane j fills slot j of a 1 KB run = row (j >> 3) of an 8-row group, physical chunk j & 7.  Wave w brings groups
   // w and w + 16 of A and of B (rows [8 w, 8 w + 8) and 128 further): two groups of one parity swizzle alike -- (row >> 1) & 7
@@ -951,7 +951,10 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
   unsigned base_a = 4u * (unsigned)((long)b * a.gy_bstride), base_b = 4u * (unsigned)((long)b * sg.x_bstride);
   const unsigned adv_a = 4u * (unsigned)a.gy_bstride, adv_b = 4u * (unsigned)sg.x_bstride;
   const int s_toff = sg.toff, s_tin = sg.Tin;
-  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0)) && wn == 0;
+  // bias sums (workgroup-uniform): the four waves that share a 64-row block take one (row block i, sub-step h) each -- wave
+  // wn: i = wn >> 1, h = wn & 1 -- from the A fragments they read anyway, and the pairs meet through LDS behind the loop
+  const bool do_bias = (ntg == sg.tile0) && (a.bslabs != nullptr) && (sg.gb || sg.gb2 || (s == 0 && a.ngbl > 0));
+  const int b_i = wn >> 1, b_h = wn & 1;
 
   auto issue = [&](const int st) {                         // the step at the cursor -> stage st; the cursor moves on
     const unsigned sbytes = (unsigned)st * 1024u;
@@ -1015,7 +1018,7 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
         const uint4 u0 = ld16(xa0 + so + i * 8192u), u1 = ld16(xa1 + so + i * 8192u);
         uint4 ap[2];
         frag(u0, u1, ap);
-        if (do_bias) bsum[i] += esum(u0) + esum(u1);
+        if (do_bias && i == b_i && h == b_h) bsum += esum(u0) + esum(u1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<2>(ap, bq[j], acc[i][j]);
       }
@@ -1074,15 +1077,17 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
         slab[row * BN + col] = __builtin_ldexpf(acc[mi][ni][r], ku);
       }
   }
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 32);
-      v = __builtin_ldexpf(v, -ka);                        // the sums ran over hi + lo = gy * 2^ka
-      const int row = m0 + wm * 64 + i * 32 + li;
-      if (lk == 0 && row < a.ntile_m * BM)
-        a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = v;
+  if (do_bias) {                                           // workgroup-uniform
+    float* red = reinterpret_cast<float*>(ring);           // [wave][32 rows]: the ring is free behind a barrier
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float v = bsum + __shfl_xor(bsum, 32);           // the two k halves of the fragment
+    if (lk == 0) red[wave * 32 + li] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (b_h == 0 && lk == 0) {
+      const float t = __builtin_ldexpf(red[wave * 32 + li] + red[(wave + 1) * 32 + li], -ka);    // the sums ran over hi + lo = gy * 2^ka
+      const int row = m0 + wm * 64 + b_i * 32 + li;
+      if (row < a.ntile_m * BM)
+        a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = t;
     }
   }
 }
