@@ -1381,7 +1381,8 @@ extern "C" int vqvae_resstack_dil_wgrad(const vqvae_resblock_desc* d, int nblock
     }
   }
   if (g_matmul_dtype == 3 && x_amax && gh_amax) wa.f16x2 = 1;
-  const bool both_presplit = wa.f16x2 && (d->storage & VQVAE_STORE_GH_F16X2) && (d->storage & VQVAE_STORE_X_F16X2);
+  const bool both_presplit = (wa.f16x2 && (d->storage & VQVAE_STORE_GH_F16X2) && (d->storage & VQVAE_STORE_X_F16X2)) ||
+                             (g_matmul_dtype == 1 && (d->storage & VQVAE_STORE_GH_BF16) && (d->storage & VQVAE_STORE_X_BF16) && T % 64 == 0);   // (mode 1: both stored as bf16)
   WgradPlan p = plan_wgrad(d->Cd, d->B, T, cins, n, both_presplit && wgrad_dma_shape(d->Cd, T, cins, n));
   if ((p.slab_floats + p.bslab_floats) * sizeof(float) > ws_bytes) { set_error("resstack_dil_wgrad: workspace too small"); return VQVAE_E_WORKSPACE; }
   wa.gy = wa.seg[0].gy; wa.gy_bstride = (long)d->Cd * T; wa.M = d->Cd; wa.Tout = T; wa.B = d->B;

@@ -883,11 +883,17 @@ __global__ __launch_bounds__(128 * WM, (W3_LEAN && WM == 4 && NC == 1 && NP >= 2
 #ifndef W3_DMA
 #define W3_DMA 1
 #endif
-constexpr int W3D_STAGE = 512 * 8;                         // uint4 per stage: [512 rows][8 chunks of 4 t]
+// BF (matmul mode 1, both operands STORED as bf16: configs[4]'s chain): the same image with 2-byte elements -- a 128-byte line is
+// 64 t, a step 64 t = four 16-t sub-steps of 4 MFMAs -- and a 16-byte chunk IS a lane's fragment (8 k of bf16): no permutes, no
+// VALU in the loop at all; products and sums as wgrad3_kernel<4, 1, 1, true, true> (the stored values, fp32 accumulation).
+constexpr int W3D_STAGE = 512 * 8;                         // uint4 per stage: [512 rows][8 chunks of 16 bytes]
+template <bool BF>
 __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) {
   __shared__ uint4 ring[2 * W3D_STAGE];
   if (a.skip_flag != nullptr && *a.skip_flag != 0) return;
-  constexpr int BM2 = 256, W3DK = 32;
+  constexpr unsigned ESZ = BF ? 2u : 4u;                   // bytes per stored element
+  constexpr int TPC = 16 / (int)ESZ;                       // t per 16-byte chunk
+  constexpr int BM2 = 256, W3DK = 8 * TPC, NSUB = W3DK / W2K, PPS = W3DK / WBK;   // positions per step; 16-t sub-steps; plan steps per step
   const int ntm = (a.ntile_m * BM + BM2 - 1) / BM2;
   int logical;                                             // XCD-aware order, as in wgrad3_kernel
   {
@@ -905,15 +911,18 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
   for (int i = 1; i < MAXSEG; ++i)
     if (i < a.nseg && ct >= a.seg[i].ptile0) s = i;
   const WSeg& sg = a.seg[s];
-  const int eg = amax_expo(amax_load(sg.gy ? sg.amax_gy : a.amax_gy));
-  const int ex = amax_expo(sg.amax_x ? amax_load(sg.amax_x) : __builtin_bit_cast(unsigned, sg.amax_x_static));
-  const int ka = 14 - eg, ku = eg + ex - 28;
+  [[maybe_unused]] int ka = 0, ku = 0;
+  if constexpr (!BF) {
+    const int eg = amax_expo(amax_load(sg.gy ? sg.amax_gy : a.amax_gy));
+    const int ex = amax_expo(sg.amax_x ? amax_load(sg.amax_x) : __builtin_bit_cast(unsigned, sg.amax_x_static));
+    ka = 14 - eg; ku = eg + ex - 28;
+  }
   const int ntg = sg.tile0 + 2 * (ct - sg.ptile0);         // first 128-column slab tile of this workgroup
   const int n0 = (ntg - sg.tile0) * BN;
   const int m0 = mt * BM2;
-  const int spb = a.steps_per_b;                           // WBK = 32 positions per plan step = one step here
-  const int g0 = split * a.steps_per_split;
-  const int g1 = min(a.B * spb, g0 + a.steps_per_split);
+  const int spb = a.steps_per_b / PPS;                     // (the host guarantees whole steps: the plan's counts are multiples of PPS)
+  const int g0 = split * (a.steps_per_split / PPS);
+  const int g1 = min(a.B * spb, g0 + a.steps_per_split / PPS);
   const int nsteps = g1 - g0;
   int b = g0 / spb;
   int tb = (g0 - b * spb) * W3DK;
@@ -940,16 +949,16 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
   const i32x4_t ra4 = make_rsrc4(sg.gy ? sg.gy : a.gy), rb4 = make_rsrc4(sg.x);
   const rsrc_t rbx = make_rsrc(sg.x);
   const int chunk0 = (lane & 7) ^ (4 * (wave & 1) + ((lane >> 4) & 3));
-  const unsigned voa0 = 4u * (unsigned)((m0 + 8 * wave + (lane >> 3)) * Tout + 4 * chunk0);
-  const unsigned vob0 = 4u * (unsigned)((n0 + 8 * wave + (lane >> 3)) * sg.x_cstride + 4 * chunk0);
-  const unsigned run_a = 512u * (unsigned)Tout, run_b = 512u * (unsigned)sg.x_cstride;     // 128 rows further
+  const unsigned voa0 = ESZ * (unsigned)((m0 + 8 * wave + (lane >> 3)) * Tout + TPC * chunk0);
+  const unsigned vob0 = ESZ * (unsigned)((n0 + 8 * wave + (lane >> 3)) * sg.x_cstride + TPC * chunk0);
+  const unsigned run_a = 128u * ESZ * (unsigned)Tout, run_b = 128u * ESZ * (unsigned)sg.x_cstride;     // 128 rows further
   const unsigned lds0 = lds_addr32(&ring[0]);
   // LDS image: [8-row group][stage][8 rows][8 chunks] -- a run of a stage is 1 KB, the other stage's run follows it, so a
   // fragment address reaches both stages, both row blocks and both chunks of a pair through the ds_read's immediate offset
   const unsigned dst_a = lds0 + 2048u * (unsigned)wave, dst_b = lds0 + 65536u + 2048u * (unsigned)wave;
   const int wslot_b = 4096 + 128 * wave + lane;            // run 0's slot of this lane as a uint4 index, stage 0 (edge steps; run 1: + 2048, stage 1: + 64)
-  unsigned base_a = 4u * (unsigned)((long)b * a.gy_bstride), base_b = 4u * (unsigned)((long)b * sg.x_bstride);
-  const unsigned adv_a = 4u * (unsigned)a.gy_bstride, adv_b = 4u * (unsigned)sg.x_bstride;
+  unsigned base_a = ESZ * (unsigned)((long)b * a.gy_bstride), base_b = ESZ * (unsigned)((long)b * sg.x_bstride);
+  const unsigned adv_a = ESZ * (unsigned)a.gy_bstride, adv_b = ESZ * (unsigned)sg.x_bstride;
   const int s_toff = sg.toff, s_tin = sg.Tin;
   // bias sums (workgroup-uniform): the four waves that share a 64-row block take one (row block i, sub-step h) each -- wave
   // wn: i = wn >> 1, h = wn & 1 -- from the A fragments they read anyway, and the pairs meet through LDS behind the loop
@@ -958,12 +967,12 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
 
   auto issue = [&](const int st) {                         // the step at the cursor -> stage st; the cursor moves on
     const unsigned sbytes = (unsigned)st * 1024u;
-    const unsigned soa = base_a + 4u * (unsigned)tb;
+    const unsigned soa = base_a + ESZ * (unsigned)tb;
     lds_dma16(dst_a + sbytes, voa0, ra4, soa);
     lds_dma16(dst_a + sbytes + 32768u, voa0, ra4, soa + run_a);
     const int w0 = tb + s_toff;                            // the shifted window [w0, w0 + 32)
     if (w0 >= 0 && w0 + W3DK <= s_tin) {                   // wave-uniform
-      const unsigned sob = base_b + 4u * (unsigned)w0;
+      const unsigned sob = base_b + ESZ * (unsigned)w0;
       lds_dma16(dst_b + sbytes, vob0, rb4, sob);
       lds_dma16(dst_b + sbytes + 32768u, vob0, rb4, sob + run_b);
     } else if (w0 + W3DK <= 0 || w0 >= s_tin) {            // wholly outside the row: zeros
@@ -972,13 +981,23 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     } else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int tin = w0 + 4 * chunk0;
-        const unsigned vrow = 4u * (unsigned)((n0 + 128 * q + 8 * wave + (lane >> 3)) * sg.x_cstride);
+        const int tin = w0 + TPC * chunk0;
+        const unsigned vrow = ESZ * (unsigned)((n0 + 128 * q + 8 * wave + (lane >> 3)) * sg.x_cstride);
         unsigned v[4];
+        if constexpr (BF) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int t = tin + e;
-          v[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rbx, (t >= 0 && t < s_tin) ? vrow + 4u * (unsigned)t : OOB, base_b, 0);
+          for (int e = 0; e < 4; ++e) {
+            const int t = tin + 2 * e;
+            const unsigned lo = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rbx, (t >= 0 && t < s_tin) ? vrow + 2u * (unsigned)t : OOB, base_b, 0);
+            const unsigned hi = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rbx, (t + 1 >= 0 && t + 1 < s_tin) ? vrow + 2u * (unsigned)(t + 1) : OOB, base_b, 0);
+            v[e] = lo | (hi << 16);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int t = tin + e;
+            v[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rbx, (t >= 0 && t < s_tin) ? vrow + 4u * (unsigned)t : OOB, base_b, 0);
+          }
         }
         ring[st * 64 + wslot_b + 2048 * q] = make_uint4(v[0], v[1], v[2], v[3]);
       }
@@ -986,10 +1005,11 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     tb += W3DK;
     if (tb >= spb * W3DK) { tb = 0; ++b; base_a += adv_a; base_b += adv_b; }
   };
-  // fragment slots (uint4 index): row R = 32-row base + li sits in group R >> 3 at row R & 7; sub-step h wants logical chunks
-  // 4 h + 2 lk | + 1, found at physical c ^ ((R >> 1) & 7): four addresses per operand (the XORs of the low three bits),
-  // everything else -- stage + 64, row block + 512 -- an immediate
-  const int fsw = (2 * lk) ^ ((li >> 1) & 7);
+  // fragment slots (uint4 index): row R = 32-row base + li sits in group R >> 3 at row R & 7, logical chunk c at physical
+  // c ^ ((R >> 1) & 7).  fp16 pairs: sub-step h wants chunks 4 h + 2 lk | + 1 (four addresses per operand: the XORs of the
+  // low three bits); bf16: sub-step h wants chunk 2 h + lk, the whole fragment.  Everything else -- stage + 64, row block
+  // + 512 -- is an immediate; the sub-steps' XORs (64 / 32 bytes per h) are applied where they are used (registers).
+  const int fsw = (BF ? lk : 2 * lk) ^ ((li >> 1) & 7);
   const int fa = (wm * 8 + (li >> 3)) * 128 + (li & 7) * 8 + fsw, fb = 4096 + (wn * 8 + (li >> 3)) * 128 + (li & 7) * 8 + fsw;
   const unsigned ba0 = 16u * (unsigned)fa, ba1 = 16u * (unsigned)(fa ^ 1), bb0 = 16u * (unsigned)fb, bb1 = 16u * (unsigned)(fb ^ 1);   // as byte offsets
   auto frag = [&](const uint4 u0, const uint4 u1, uint4 (&p)[2]) {     // eight stored elements -> the hi and the lo fragment word
@@ -999,13 +1019,32 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     presplit_stage(__builtin_bit_cast(float, u1.z), __builtin_bit_cast(float, u1.w), p[0].w, p[1].w);
   };
   auto esum = [&](const uint4 u) {
+    if constexpr (BF) {                                    // eight stored bf16
+      auto two = [](const unsigned w) { return __builtin_bit_cast(float, w << 16) + __builtin_bit_cast(float, w & 0xffff0000u); };
+      return (two(u.x) + two(u.y)) + (two(u.z) + two(u.w));
+    } else
     return (presplit_scaled(__builtin_bit_cast(float, u.x)) + presplit_scaled(__builtin_bit_cast(float, u.y))) +
            (presplit_scaled(__builtin_bit_cast(float, u.z)) + presplit_scaled(__builtin_bit_cast(float, u.w)));
   };
   auto ld16 = [&](const unsigned off) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(ring) + off); };
   auto mma = [&](const int st, const int h) {
     const unsigned so = 1024u * (unsigned)st;
-    {
+    if constexpr (BF) {
+      unsigned xa = ba0, xb = bb0;
+      if (h == 1) asm volatile("v_xor_b32 %0, 32, %0\n\tv_xor_b32 %1, 32, %1" : "+v"(xa), "+v"(xb));
+      if (h == 2) asm volatile("v_xor_b32 %0, 64, %0\n\tv_xor_b32 %1, 64, %1" : "+v"(xa), "+v"(xb));
+      if (h == 3) asm volatile("v_xor_b32 %0, 0x60, %0\n\tv_xor_b32 %1, 0x60, %1" : "+v"(xa), "+v"(xb));
+      uint4 bq[2], aq[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = ld16(xb + so + j * 8192u);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) aq[i] = ld16(xa + so + i * 8192u);
+      if (do_bias && (h & 1) == b_h) bsum += b_i ? esum(aq[1]) : esum(aq[0]);      // (no dynamic index: hipcc would move aq to scratch)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<1>(aq[i], bq[j], acc[i][j]);
+    } else {
       unsigned xa0 = ba0, xa1 = ba1, xb0 = bb0, xb1 = bb1;
       if (h) {                                             // the second sub-step's four addresses are made here, not kept (registers)
         asm volatile("v_xor_b32 %0, 64, %0\n\tv_xor_b32 %1, 64, %1\n\tv_xor_b32 %2, 64, %2\n\tv_xor_b32 %3, 64, %3" : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1));
@@ -1040,6 +1079,7 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     if ((I) + 1 < nsteps) issue((ST) ^ 1);                                                     \
     W3_T(q3b);                                                                                 \
     mma(ST, 1);                                                                                \
+    if constexpr (NSUB == 4) { mma(ST, 2); mma(ST, 3); }                                       \
     W3_T(q4);                                                                                  \
     W3_ACC(sm, q3b, q4);                                                                       \
     W3_ACC(sw, q0, q1); W3_ACC(sb, q1, q2); W3_ACC(sm, q2, q3); W3_ACC(si, q3, q3b);           \
@@ -1074,7 +1114,7 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
       for (int r = 0; r < 16; ++r) {
         const int row = (rowb % BM) + (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int col = (wn & 1) * 64 + ni * 32 + li;
-        slab[row * BN + col] = __builtin_ldexpf(acc[mi][ni][r], ku);
+        slab[row * BN + col] = BF ? acc[mi][ni][r] : __builtin_ldexpf(acc[mi][ni][r], ku);
       }
   }
   if (do_bias) {                                           // workgroup-uniform
@@ -1084,7 +1124,7 @@ __global__ __launch_bounds__(1024, 4) void wgrad3_dma_kernel(const WgradArgs a) 
     if (lk == 0) red[wave * 32 + li] = v;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (b_h == 0 && lk == 0) {
-      const float t = __builtin_ldexpf(red[wave * 32 + li] + red[(wave + 1) * 32 + li], -ka);    // the sums ran over hi + lo = gy * 2^ka
+      const float t = __builtin_ldexpf(red[wave * 32 + li] + red[(wave + 1) * 32 + li], -ka);    // the sums ran over hi + lo = gy * 2^ka (bf16: ka = 0)
       const int row = m0 + wm * 64 + b_i * 32 + li;
       if (row < a.ntile_m * BM)
         a.bslabs[(((long)split * a.nseg + s) * a.ntile_m + row / BM) * BM + row % BM] = t;
@@ -1169,7 +1209,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
 #define W3_SLOTS_256 512
 #endif
 bool wgrad_dma_shape(int M, int Tout, const int* cins, int nseg) {
-  bool ok = W3_DMA != 0 && g_matmul_dtype == 3 && M % 256 == 0 && Tout % WBK == 0;
+  bool ok = W3_DMA != 0 && (g_matmul_dtype == 3 || g_matmul_dtype == 1) && M % 256 == 0 && Tout % WBK == 0;
   for (int i = 0; i < nseg; ++i) ok = ok && cins[i] % (2 * BN) == 0;
   return ok;
 }
@@ -1261,7 +1301,7 @@ int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream
     int cins_[MAXSEG];
     for (int i = 0; i < w.nseg; ++i) cins_[i] = w.seg[i].cin;
     const bool dma = w.x16 && w.g16 && wgrad_dma_shape(w.M, w.Tout, cins_, w.nseg);     // (with any plan; the caller asks for a wide one when it knows)
-    if (dma) hipLaunchKernelGGL(wgrad3_dma_kernel, dim3((p.ntile_m / 2) * w.ntile_p * p.nsplit), dim3(1024), 0, st, w);
+    if (dma) hipLaunchKernelGGL(wgrad3_dma_kernel<false>, dim3((p.ntile_m / 2) * w.ntile_p * p.nsplit), dim3(1024), 0, st, w);
     else if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, true>), grid, dim3(512), 0, st, w);
     else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, false, true>), grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 2, true, false>), grid, dim3(512), 0, st, w);
@@ -1278,7 +1318,11 @@ int launch_wgrad(WgradArgs& w, const WgradPlan& p, float* ws, int tag, hipStream
     if (w.x16) for (int i = 0; i < w.nseg; ++i) ok16 = ok16 && w.seg[i].Tin == w.Tout;
     VQ_REQUIRE(ok16, "wgrad: bf16-stored operands need matmul mode 1, stride-1 segments, 256-row tiles and T %% 16 == 0");
     const dim3 grid((p.ntile_m / 2) * p.ntile_n * p.nsplit);
-    if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true, true>), grid, dim3(512), 0, st, w);
+    int cins_[MAXSEG];
+    for (int i = 0; i < w.nseg; ++i) cins_[i] = w.seg[i].cin;
+    if (w.x16 && w.g16 && wgrad_dma_shape(w.M, w.Tout, cins_, w.nseg) && w.Tout % 64 == 0 && p.steps_per_b % 2 == 0 && p.steps_per_split % 2 == 0)
+      hipLaunchKernelGGL(wgrad3_dma_kernel<true>, dim3((p.ntile_m / 2) * w.ntile_p * p.nsplit), dim3(1024), 0, st, w);
+    else if (w.x16 && w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true, true>), grid, dim3(512), 0, st, w);
     else if (w.g16) hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, false, true>), grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL((wgrad3_kernel<4, 1, 1, true>), grid, dim3(512), 0, st, w);
   } else if (fast && mode == 1 && w.M % 256 == 0) {
