@@ -1235,8 +1235,10 @@ WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg, bool wid
   const long slots = wide ? 1024 : (M % 256 == 0 && g_matmul_dtype != 0) ? W3_SLOTS_256 : 512;
   long want = 1;
   double best = -1.0;
+  const bool even = wide && g_matmul_dtype == 1;          // wgrad3_dma_kernel<BF> takes two plan steps (64 positions) at a time
   for (long w = 1; w <= maxs; ++w) {
-    const long sps = (total_steps + w - 1) / w;
+    long sps = (total_steps + w - 1) / w;
+    if (even) sps += sps & 1;
     const long ns = (total_steps + sps - 1) / sps;        // splits actually produced
     const long blocks = tiles * ns;
     const long rounds = (blocks + slots - 1) / slots;
@@ -1245,6 +1247,7 @@ WgradPlan plan_wgrad(int M, int B, int Tout, const int* cins, int nseg, bool wid
     if (eff >= 0.92 && (blocks >= slots || wide)) { want = w; break; }
   }
   p.steps_per_split = (int)((total_steps + want - 1) / want);
+  if (even) p.steps_per_split += p.steps_per_split & 1;
   p.nsplit = (int)((total_steps + p.steps_per_split - 1) / p.steps_per_split);
   p.slab_floats = (size_t)p.nsplit * p.ntile_m * p.ntile_n * BM * BN;
   p.bslab_floats = (size_t)p.nsplit * nseg * p.ntile_m * BM;

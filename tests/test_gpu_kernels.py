@@ -1335,3 +1335,110 @@ def test_encoder_stage_backward_fused_vs_oracle(gpu, matmul_mode, B, Tin, relu_i
     ref = run(False)
     for a_, b_, n in zip(got[:3], ref[:3], ('gx', 'gW', 'gb')):
         assert_close_scaled(a_, b_, 2e-5, 'fused vs four launches: ' + n)
+
+
+def _dil_wgrad_reference(ghv, xv, dils, K=2):
+    """float64 weight / bias gradients of K-tap dilated causal convs from the VALUES the kernel is handed
+    (tap j of block l sees x[t - (K - 1 - j) dil_l]; modules.py:13-16)."""
+    out = []
+    for dil in dils:
+        taps = []
+        for j in range(K):
+            sh = (K - 1 - j) * dil
+            xs = np.zeros_like(xv)
+            if sh < xv.shape[2]:
+                xs[:, :, sh:] = xv[:, :, :xv.shape[2] - sh] if sh else xv
+            taps.append(np.einsum('bot,bit->oi', ghv, xs))
+        out.append((np.stack(taps, axis=2), ghv.sum(axis=(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize('B,T,dils', [(2, 3200, (1, 2, 32, 64, 512)), (2, 1024, (4, 16)), (1, 7680, (256,))])
+def test_dil_wgrad_lds_dma_bf16_stored_operands(gpu, bf16_mode, B, T, dils):
+    """wgrad3_dma_kernel<BF> (csrc/wgrad.hip; matmul mode 1, vqvae_resblock_desc.storage & (GH_BF16 | X_BF16): configs[4]'s
+    chain): the dilated convs' weight / bias gradients with BOTH operands stored as bf16 travel global -> LDS by LDS-DMA and
+    are contracted as they lie.  Against float64 over the stored values (bf16 x bf16 products are exact in fp32: only the
+    summation order differs -> 1e-5 of scale), for: an odd tap shift (dil 1: a 2-byte-aligned DMA source), windows that
+    cross a row's first sample (dil 1, 2, 4, 16, 32), 64-t steps wholly in front of it (dil 64, 256, 512: zero-filled
+    stages), K ranges that run from one batch item into the next (T = 3200: 12.5 splits per row), several blocks per launch."""
+    from vqvae_amd import _lib
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    Cr = Cd = Cs = 256
+    Cc, K = 192, 2
+    d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, 1)
+    d.storage = _lib.STORE_GH_BF16 | _lib.STORE_X_BF16
+    rs = np.random.RandomState(zlib.crc32(repr((B, T, dils)).encode()))
+    def stored(c, sc):
+        v = O.bf16_round((rs.standard_normal((B, c, T)) * sc).astype(np.float32))
+        buf = DeviceArray((B, c, T), np.float32)          # the caller's buffer stays fp32-sized, half used
+        buf.fill_zero()
+        half = gpu.to_device(np.ascontiguousarray((v.view(np.uint32) >> 16).astype(np.uint16)).reshape(-1).view(np.float32))
+        _lib.call('vqvae_memcpy_d2d', buf.ptr, half.ptr, B * c * T * 2, gpu.stream())
+        return v.astype(np.float64), buf, half
+    xv, x16, _k1 = stored(Cr, 1.0)
+    gv, g16, _k2 = stored(Cd, 1e-2)
+    n = len(dils)
+    ws = DeviceArray((lib.vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d), n) // 4 + 1,), np.float32)
+    gW = [DeviceArray((Cd, Cr, K), np.float32) for _ in dils]
+    gb = [DeviceArray((Cd,), np.float32) for _ in dils]
+    try:
+        _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), n, (C.c_int * n)(*dils), _lib.ptr_array([x16] * n),
+                  _lib.ptr_array([g16] * n), _lib.ptr_array(gW), _lib.ptr_array(gb), 0, ws.ptr, ws.nbytes, None, None,
+                  gpu.stream())
+    finally:
+        d.storage = 0
+    for l, (wW, wb) in enumerate(_dil_wgrad_reference(gv, xv, dils, K)):
+        assert_close_scaled(gW[l].get(), wW, 1e-5, 'gWd, dil %d' % dils[l])
+        assert_close_scaled(gb[l].get(), wb, 1e-5, 'gbd, dil %d' % dils[l])
+
+
+def _presplit_store(v, bound):
+    """float32x2's pre-split storage (csrc/gemm_common.h presplit_pair): one dword per element = fp16 hi | fp16 lo << 16 of
+    v * 2^(14 - e(bound)); returns the dwords (as float32 bit patterns), the scale words and the values they decode to."""
+    bound = np.float32(bound)
+    e = int(np.floor(np.log2(np.float64(bound))))           # the exponent the kernels read from the scale words
+    y = np.ldexp(v.astype(np.float32), 14 - e)
+    hi = y.astype(np.float16)
+    lo = (y - hi.astype(np.float32)).astype(np.float16)
+    words = hi.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
+    scale = np.zeros(16, np.uint32)
+    scale[0] = bound.view(np.uint32)
+    decoded = np.ldexp(hi.astype(np.float64) + lo.astype(np.float64), e - 14)
+    return words.view(np.float32), scale, decoded
+
+
+@pytest.mark.parametrize('B,T,dils', [(2, 3200, (1, 2, 16, 32, 512)), (2, 1024, (4, 64)), (1, 7680, (256,))])
+def test_dil_wgrad_lds_dma_presplit_operands(gpu, B, T, dils):
+    """wgrad3_dma_kernel<false> (csrc/wgrad.hip; matmul mode 3 'float32x2', storage & (GH_F16X2 | X_F16X2): the default chain):
+    both operands arrive PRE-SPLIT (fp16 hi | lo dwords under a published bound), travel by LDS-DMA and are separated into
+    their pieces after the fragment read.  Against float64 over the values the dwords decode to (three fp16 products of
+    22-bit operands, fp32 accumulation -> 1e-5 of scale) for the same edge cases as the bf16 form (32-t steps here: dil 32
+    and 512 are whole steps in front of the row, 1 / 2 / 4 / 16 cross its first sample), with bounds 1.7x / 5x above the maxima."""
+    from vqvae_amd import _lib
+    from vqvae_amd.backend import DeviceArray
+    lib = _lib.load()
+    gpu.set_matmul_dtype('float32x2')
+    try:
+        Cr = Cd = Cs = 256
+        Cc, K = 192, 2
+        d = _lib.ResblockDesc(B, T, Cr, Cd, Cs, Cc, K, 1)
+        rs = np.random.RandomState(zlib.crc32(repr((B, T, dils, 3)).encode()))
+        x = (rs.standard_normal((B, Cr, T)) * 0.7).astype(np.float32)
+        g = (rs.standard_normal((B, Cd, T)) * 3e-3).astype(np.float32)
+        xw, xs, xv = _presplit_store(x, 1.7 * np.abs(x).max())
+        gw, gs, gv = _presplit_store(g, 5.0 * np.abs(g).max())
+        xd, gd, xsd, gsd = gpu.to_device(xw), gpu.to_device(gw), gpu.to_device(xs), gpu.to_device(gs)
+        n = len(dils)
+        d.storage = _lib.STORE_GH_F16X2 | _lib.STORE_X_F16X2
+        ws = DeviceArray((lib.vqvae_resstack_dil_wgrad_workspace_bytes(C.byref(d), n) // 4 + 1,), np.float32)
+        gW = [DeviceArray((Cd, Cr, K), np.float32) for _ in dils]
+        gb = [DeviceArray((Cd,), np.float32) for _ in dils]
+        _lib.call('vqvae_resstack_dil_wgrad', C.byref(d), n, (C.c_int * n)(*dils), _lib.ptr_array([xd] * n),
+                  _lib.ptr_array([gd] * n), _lib.ptr_array(gW), _lib.ptr_array(gb), 0, ws.ptr, ws.nbytes,
+                  _lib.ptr_array([xsd] * n), _lib.ptr_array([gsd] * n), gpu.stream())
+        for l, (wW, wb) in enumerate(_dil_wgrad_reference(gv, xv, dils, K)):
+            assert_close_scaled(gW[l].get(), wW, 1e-5, 'gWd, dil %d' % dils[l])
+            assert_close_scaled(gb[l].get(), wb, 1e-5, 'gbd, dil %d' % dils[l])
+    finally:
+        gpu.set_matmul_dtype(gpu.default_matmul_dtype())
