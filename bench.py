@@ -105,7 +105,7 @@ def kernel_roofline_table(upd, backend, cfg, B, mode, k_eager):
          '4 N (n_blocks (Cs + Ch + Ch + Cd) + (n_blocks - 1) Cr): g_skip, sigmoid, z read, gh written; g_res read by all but the last block'),
         ('ResidualBlock bwd: backward-data of the dilated conv + g_res (conv_gemm_x3_kernel<EPI_LINEAR>, two taps)', _lib.PROF_RESBLOCK_BWD_GX, 'mfma',
          nb * 2.0 * N * Cr * Cd * Kf, 'n_blocks * 2 N Cr Cd K'),
-        ('ResidualNet bwd: weight gradients of the dilated convs, several blocks per launch, incl. the fixed-order reduce (wgrad3_kernel)',
+        ('ResidualNet bwd: weight gradients of the dilated convs, several blocks per launch, incl. the fixed-order reduce (wgrad3_dma_kernel: both operands stored pre-split / as bf16, global -> LDS by LDS-DMA; wgrad3_kernel otherwise)',
          _lib.PROF_WGRAD_DIL, 'mfma', nb * 2.0 * N * Cd * Cr * Kf, 'n_blocks * 2 N Cd Cr K'),
         ('ResidualNet bwd: weight gradients of the res / skip 1x1 convs, incl. the reduce (wgrad3_kernel)', _lib.PROF_WGRAD_RES_SKIP, 'mfma',
          (2 * nb - 1) * 2.0 * N * Cr * Ch, '(2 n_blocks - 1) * 2 N 256 Ch'),
