@@ -843,6 +843,11 @@ def main():
                              'mfma peak as in roofline.peak_is, hbm peak 8000 GB/s; work = algorithmic FLOPs / bytes (SURVEY 8d)'
                              % (min(args.steps, 10), ktable[1]))},
         }
+        if mode == 'float32x2':
+            # the run-time guard of the mode's pre-split storage: every backward sweep of this process so far --
+            # warm-up, timed, with-input and eager steps -- compared each pre-split tensor's bound with its actual maximum on
+            # the device; `violations` = tensors whose bound was more than 2^log2_limit above it (0 = the contract held)
+            out['f32x2_contract'] = backend.f32x2_contract_violations()
         if ref_ms is not None:
             out['fp32_mfma_reference'] = {'ms_per_step': ref_ms, 'value': B * T / (ref_ms * 1e-3), 'unit': 'samples/s',
                                           'note': "the same job with --matmul float32 (v_mfma_f32_32x32x2_f32), "
