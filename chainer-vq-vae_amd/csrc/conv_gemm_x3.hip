@@ -3,9 +3,6 @@
 // operands rounded to bf16), the streaming residual 1x1 (lin128_stream_kernel), the split-K reduce, and launch_gemm, which
 // picks the kernel of a launch in every mode.
 #include "gemm_common.h"
-#ifndef X3_ABL
-#define X3_ABL 0          // dev ablations (timing only, wrong results): bit 0 = one weight DMA per step instead of NP, bit 1 = one activation load per thread and step instead of CPT
-#endif
 
 namespace vq {
 
@@ -326,7 +323,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     {                                                                                         \
       const unsigned so_ = swA + ((TAP1) ? sw1 : 0u);                                         \
       if constexpr (ADMA) {                                                                   \
-        _Pragma("unroll") for (int p = 0; p < ((X3_ABL & 1) ? 1 : NP); ++p)                   \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                                        \
           lds_dma16(lds_addr32(&As[BUF][p][0][0] + 64 * wave_u), va, rw4, so_ + (unsigned)p * wl2b); \
       } else {                                                                                \
       la0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, va, so_, 0)); \
@@ -337,9 +334,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
     }
 #define LN_FETCH_B(BV, TAP1)                                                                  \
     {                                                                                         \
-      _Pragma("unroll") for (int e = 0; e < ((X3_ABL & 2) ? 1 : CPT); ++e)                    \
+      _Pragma("unroll") for (int e = 0; e < CPT; ++e)                                         \
         BV[e] = (TAP1) ? buf_ld(rx1, vb1, sxB + (unsigned)e * xcsb) : buf_ld(rx, vb, sxB + (unsigned)e * xcsb); \
-      if (X3_ABL & 2) { _Pragma("unroll") for (int e = 1; e < CPT; ++e) BV[e] = BV[0]; }      \
       if (TAP1) { leftB -= 2; sxB += leftB > 0 ? xadvb : 0u; }                                \
     }
 #define LN_STAGE(BV, KX, BUF, PRE)                                                            \
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       if constexpr (NP == 3) ad[2 * NT + tid] = la2;                                          \
       }                                                                                       \
       stage_b(std::integral_constant<bool, (PRE)>{}, BV, KX, BUF);                            \
-      if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((X3_ABL & 2) ? 1 : CPT) : "memory");         \
+      if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CPT) : "memory");         \
     }
     auto lmma = [&](auto curc) {
       constexpr int cur = decltype(curc)::value;
@@ -363,7 +359,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && EPI == EPI_LINEAR) ? 3 : ((WM
       for (int i = 0; i < 2; ++i) {
         uint4 af[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) af[p] = As[cur][(X3_ABL & 1) ? 0 : p][lk][wm * 64 + i * 32 + li];
+        for (int p = 0; p < NP; ++p) af[p] = As[cur][p][lk][wm * 64 + i * 32 + li];
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_chain<NP>(af, bf[j], acc[i][j]);     // same product order as the loop below
       }
