@@ -149,7 +149,7 @@ def _pack_stack(params, d0, nb, stream):
 
 FUSE_PULLBACK = True     # (tests A/B it through this attribute)
 DEFER_WGRAD = True
-PB_REDUCE_GROUP = 5       # blocks per vqvae_pullback_reduce_into launch
+PB_REDUCE_GROUP = 20      # blocks per vqvae_pullback_reduce_into launch (5 while the chain's weight gradients ran 90 us longer per launch; re-measured on the LDS-DMA kernel: 5 / 7 / 10 / 20 -> 14.17 / 14.15 / 14.14 / 14.09 ms per step, two rounds on one box)
 DEFER_DIL_BLOCKS = 5      # how many of the blocks nearest the input keep their dilated-conv weight gradients for the side stream (a multiple of DIL_WGRAD_GROUP; 10 and 15 measured 0.05-0.1 ms slower: the tail they would run beside is full)
 BATCH_PULLBACK = True
 PREPACK_ASYNC = True
@@ -577,9 +577,9 @@ class ResidualStackFunction(FunctionNode):
             g_res = gx
             if pending[0] - i >= grp:          # g_res of blocks i .. pending-1 are all available
                 flush_res(i)
-            # the fused pull-back's partial sums of the blocks the chain has passed, PB_REDUCE_GROUP at a time: ~15 us between two
-            # chip-filling launches instead of one launch over all blocks in the tail (52 us alone, 160 us beside the deferred
-            # weight gradients it then shares the chip with)
+            # the fused pull-back's partial sums of the blocks the chain has passed, PB_REDUCE_GROUP at a time (round 5: ~15 us
+            # between two chip-filling launches instead of one launch over all blocks in the tail -- 52 us alone, 160 us beside
+            # the deferred weight gradients; round 6, with those 90 us shorter each: one launch behind the chain measures best)
             if pb_part is not None and (i % PB_REDUCE_GROUP == 0):
                 hi_b = min(nb, i + PB_REDUCE_GROUP)
                 _lib.call('vqvae_pullback_reduce_into', pb_part.ptr + i * (pb_part.nbytes // nb), tb['v0'].ptr, hi_b - i,
