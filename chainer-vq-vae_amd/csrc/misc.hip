@@ -796,6 +796,40 @@ __global__ __launch_bounds__(256) void embed_gather2x4_kernel(const int32_t* __r
   }
 }
 
+// The same gather with the output channel's 2 q weights staged in LDS: a workgroup walks whole (b, co) rows, so the eight
+// random reads per thread are LDS reads instead of eight gathers through the address path (54 -> ~30 us at configs[1]: the
+// kernel sits in front of the first gate launch).  Same additions in the same order: bit-identical.
+__global__ __launch_bounds__(256) void embed_gather2x4_lds_kernel(const int32_t* __restrict__ idx, int B, int T,
+                                                                  const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, int Cout, int q,
+                                                                  float* __restrict__ y,
+                                                                  const int32_t* __restrict__ run_flag) {
+  extern __shared__ float wrow[];                 // [q][2]: tap 0 | tap 1 of every class, this row's output channel
+  if (run_flag != nullptr && *run_flag == 0) return;
+  const int T4 = T >> 2, rows = B * Cout;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int co = r % Cout, b = r / Cout;
+    __syncthreads();                              // the previous row's readers are done
+    for (int i = threadIdx.x; i < 2 * q; i += 256) wrow[i] = W[(long)co * q * 2 + i];
+    __syncthreads();
+    const float bv = bias ? bias[co] : 0.f;
+    const int32_t* ib0 = idx + (long)b * T;
+    float* yr = y + (long)r * T;
+    for (int i = threadIdx.x; i < T4; i += 256) {
+      const int t = 4 * i;
+      const int4 c1 = *reinterpret_cast<const int4*>(ib0 + t);       // classes at t .. t+3   (tap 1)
+      const int cm = t > 0 ? ib0[t - 1] : -1;                         // class at t-1          (tap 0 of column t)
+      float4 o;
+      o.x = __fadd_rn(cm >= 0 ? wrow[2 * cm] : 0.f, wrow[2 * c1.x + 1]);
+      o.y = __fadd_rn(wrow[2 * c1.x], wrow[2 * c1.y + 1]);
+      o.z = __fadd_rn(wrow[2 * c1.y], wrow[2 * c1.z + 1]);
+      o.w = __fadd_rn(wrow[2 * c1.z], wrow[2 * c1.w + 1]);
+      if (bias) { o.x = __fadd_rn(o.x, bv); o.y = __fadd_rn(o.y, bv); o.z = __fadd_rn(o.z, bv); o.w = __fadd_rn(o.w, bv); }
+      *reinterpret_cast<float4*>(yr + t) = o;
+    }
+  }
+}
+
 // K == 2, T % 4 == 0 form of the bincount: four positions per lane (16-byte loads), two chunks in flight.
 // The kernel is bound by the LDS atomic unit, about 3 clocks per lane-add whatever the addresses
 // are: spreading the lanes over BC_NCOPY private copies of the histograms (8 copies, 2 waves)
@@ -1308,6 +1342,8 @@ int vqvae_embed_gather_fwd(const int32_t* idx, long idx_bstride, int B, int T, c
                            const float* b, int Cout, int q, int K, float* y, vqvae_stream_t s) {
   VQ_REQUIRE(idx && W && y && B > 0 && T > 0 && Cout > 0 && q > 0 && K >= 1, "embed_gather_fwd: bad arguments");
   if (K == 2 && T % 4 == 0 && idx_bstride == (long)T && (((uintptr_t)y) % 16 == 0) && (((uintptr_t)idx) % 16 == 0)) {
+    if (q <= 4096 && T >= 1024) hipLaunchKernelGGL(embed_gather2x4_lds_kernel, dim3((unsigned)min((long)B * Cout, 8192L)), dim3(256), (size_t)q * 8, (hipStream_t)s, idx, B, T, W, b, Cout, q, y, (const int32_t*)nullptr);
+    else
     hipLaunchKernelGGL(embed_gather2x4_kernel, dim3(grid_for((size_t)B * Cout * (T / 4), 256, 8192)), dim3(256), 0, (hipStream_t)s, idx, B, T, W, b, Cout, q, y, (const int32_t*)nullptr);
     VQ_LAUNCH_CHECK();
     return 0;
@@ -1344,6 +1380,8 @@ int vqvae_embed_onehot_fwd(const float* x, const float* W, const float* b, int B
   VQ_LAUNCH_CHECK();
   // one-hot: gather of K weight columns (bit-identical to the dense conv) ...
   if (vec4 && K == 2) {
+    if (q <= 4096 && T >= 1024) hipLaunchKernelGGL(embed_gather2x4_lds_kernel, dim3((unsigned)min((long)B * Cout, 8192L)), dim3(256), (size_t)q * 8, st, idx, B, T, W, b, Cout, q, y, (const int32_t*)flag);
+    else
     hipLaunchKernelGGL(embed_gather2x4_kernel, dim3(grid_for((size_t)B * Cout * (T / 4), 256, 8192)), dim3(256), 0, st, idx, B, T, W, b, Cout, q, y, (const int32_t*)flag);
   } else {
     hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((size_t)B * Cout * T, 256, 4096)), dim3(256), 0, st, idx, (long)T, B, T, W, b, Cout, q, K, y, (const int32_t*)flag);
