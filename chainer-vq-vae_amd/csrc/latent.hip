@@ -47,28 +47,46 @@ template <int C> struct CStackGeom {
 };
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
+// The forward runs in the head of the step, in front of the first gate launch, on an otherwise idle chip: it may keep the
+// layer's weights in LDS (132 KB per workgroup) -- the backward, which has to fit beside the decoder's deferred weight-gradient
+// workgroups, reads them from L2.  Round 6's first form fetched the A operand of every MFMA straight from L2, a lane per
+// weight ROW: 64 cache lines per wave instruction, 768 such gathers per layer and workgroup = ~21 us per layer for 3 us of
+// MFMA work.  Now W_l (C x 3 C, 48 KB) is read in whole 16-byte runs a layer ahead (24 registers per thread), written into an
+// odd-pitch LDS image behind the layer's barrier, and the A operands are ds_read_b32s like the B operands.  Same products in
+// the same order as before.
 template <int C>
-__global__ __launch_bounds__(CStackGeom<C>::NW * 64, 4) void cstack_fwd_kernel(const CStackArgs a) {
+__global__ __launch_bounds__(CStackGeom<C>::NW * 64, 2) void cstack_fwd_kernel(const CStackArgs a) {
   using G = CStackGeom<C>;
-  constexpr int TP = G::TP, NT = G::NW * 64;
+  constexpr int TP = G::TP, WP = G::WP, NT = G::NW * 64;
   extern __shared__ float lds[];
   float* act0 = lds;                     // [C][TP]
   float* act1 = lds + C * TP;
+  float* wimg = lds + 2 * C * TP;        // [C][WP]: W_l as [co][ci * 3 + j]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int b = blockIdx.x, T = a.T;
   const int mt = wave & (C / 32 - 1), nt = wave / (C / 32);       // this wave's tile: rows 32 mt .., columns 32 nt ..
   const int n = nt * 32 + li;
-  // A operand of step (j, c): W[co = 32 mt + li][ci = c + kh][j] -- straight from L2, in sixths of a layer (half a tap: C / 4 MFMA
-  // steps) through a ring of three register buffers, two sixths ahead of the MFMAs (<= 128 VGPRs: two workgroups' worth per CU)
   constexpr int H = C / 4;
-  auto fetch_a = [&](int l, int sx, float (&av)[H]) {              // sx = 2 j + half
-    const float* wr = a.W[l] + (long)(32 * mt + li) * (3 * C) + 3 * kh + (sx >> 1) + 6 * H * (sx & 1);
+  constexpr int NV = (C * 3 * C / 4 + NT - 1) / NT;                // float4 of a layer's weights per thread
+  float4 wv[NV];
+  auto fetch_w = [&](int l) {
+    const float4* w4 = reinterpret_cast<const float4*>(a.W[l]);
 #pragma unroll
-    for (int q = 0; q < H; ++q) av[q] = wr[6 * q];
+    for (int k = 0; k < NV; ++k) { const int i = k * NT + tid; wv[k] = i < C * 3 * C / 4 ? w4[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
   };
-  float r0[H], r1[H], r2[H];
-  fetch_a(0, 0, r0); fetch_a(0, 1, r1);
+  auto store_w = [&]() {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = k * NT + tid;
+      if (i < C * 3 * C / 4) {
+        const int e = 4 * i, co = e / (3 * C), r = e - co * (3 * C);      // (3 C is a multiple of 4: a float4 never leaves its row)
+        float* d = wimg + co * WP + r;
+        d[0] = wv[k].x; d[1] = wv[k].y; d[2] = wv[k].z; d[3] = wv[k].w;
+      }
+    }
+  };
+  fetch_w(0);
   // zero both activation images (halos and the columns beyond T stay zero for the whole launch)
   for (int i = tid; i < 2 * C * TP; i += NT) lds[i] = 0.f;
   __syncthreads();
@@ -76,29 +94,27 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64, 4) void cstack_fwd_kernel(c
     const float* xb = a.x + (long)b * C * T;
     for (int i = tid; i < C * T; i += NT) { const int c = i / T, t = i - c * T; act0[c * TP + CS_HALO + t] = xb[i]; }
   }
+  store_w();
   __syncthreads();
   for (int l = 0; l < a.L; ++l) {
     const float* in = (l & 1) ? act1 : act0;
     float* out = (l & 1) ? act0 : act1;
     const int dil = a.dil[l];
+    const bool more = l + 1 < a.L;
+    if (more) fetch_w(l + 1);           // in flight under this layer's MFMAs
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* br = in + kh * TP + CS_HALO + n;
-    const bool more = l + 1 < a.L;
-    auto mma6 = [&](const float (&av)[H], int sx) {                // channels c = 2 (q + H * half) + kh, column shift (j - 1) dil
+    const float* ar = wimg + (32 * mt + li) * WP + 3 * kh;
+    // step (sx = 2 j + half, q): A = W[co = 32 mt + li][ci = 2 (q + H half) + kh][j], B = in[ci][n + (j - 1) dil]
+#pragma unroll
+    for (int sx = 0; sx < 6; ++sx) {
+      const float* aq = ar + (sx >> 1) + 6 * H * (sx & 1);
       const float* bq = br + (2 * H * (sx & 1)) * TP + ((sx >> 1) - 1) * dil;
 #pragma unroll
-      for (int q = 0; q < H; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bq[2 * q * TP], acc, 0, 0, 0);
-    };
-    fetch_a(l, 2, r2); mma6(r0, 0);
-    fetch_a(l, 3, r0); mma6(r1, 1);
-    fetch_a(l, 4, r1); mma6(r2, 2);
-    fetch_a(l, 5, r2); mma6(r0, 3);
-    if (more) fetch_a(l + 1, 0, r0);
-    mma6(r1, 4);
-    if (more) fetch_a(l + 1, 1, r1);
-    mma6(r2, 5);
+      for (int q = 0; q < H; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[6 * q], bq[2 * q * TP], acc, 0, 0, 0);
+    }
     float* hb = a.h[l] + (long)b * C * T;
     const float* bias = a.b[l];
 #pragma unroll
@@ -108,7 +124,8 @@ __global__ __launch_bounds__(CStackGeom<C>::NW * 64, 4) void cstack_fwd_kernel(c
       v = fmaxf(v, 0.f);
       if (n < T) { out[m * TP + CS_HALO + n] = v; hb[(long)m * T + n] = v; }
     }
-    __syncthreads();                    // `out` is complete, every wave is done with `in`
+    __syncthreads();                    // `out` is complete, every wave is done with `in` and with the weight image
+    if (more) { store_w(); __syncthreads(); }
   }
 }
 
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256) void cstack_reduce_kernel(const float* __restr
 template <int C>
 static int cstack_launch(const CStackArgs& a, bool backward, hipStream_t st) {
   using G = CStackGeom<C>;
-  const size_t lds = G::lds_fwd;
+  const size_t lds = backward ? G::lds_fwd : G::lds_fwd + (size_t)C * G::WP * sizeof(float);      // (forward: + the layer's weight image)
   if (backward) {
     static bool attr = false;
     if (!attr) { VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cstack_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
