@@ -1,5 +1,6 @@
 // wgrad.hip -- backward-weight of every conv: contraction over the flattened (batch, time) axis, split-K into deterministic
-// partial slabs (wgrad3_kernel: modes 1-3; wgrad2_kernel: mode 0; wgrad_kernel: strided shapes), summed in a fixed order by
+// partial slabs (wgrad3_kernel: modes 1-3; wgrad3_dma_kernel: both operands stored in MFMA form -- pre-split in mode 3, bf16 in
+// mode 1 -- and brought to LDS by LDS-DMA; wgrad2_kernel: mode 0; wgrad_kernel: strided shapes), summed in a fixed order by
 // wgrad_reduce_kernel; plan_wgrad chooses the splits, launch_wgrad the kernel.
 #include "gemm_common.h"
 
